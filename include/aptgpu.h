@@ -1,0 +1,234 @@
+/*
+ * aptgpu.h — C ABI of libaptgpu.so: the MI355X (gfx950) implementation of
+ * martinber/noaa-apt's signal-to-image hot path, i.e. the body of
+ * noaa_apt::decode()  (reference: src/decode.rs:43-162, re-exported at
+ * src/noaa_apt.rs:5) and the dsp.rs / filters.rs functions it calls.
+ *
+ * This is the drop-in boundary: plain C types, plain pointers and sizes, no
+ * C++/torch types.  A Rust `extern "C"` block binds exactly these symbols
+ * (see INTEGRATION.md for the shim that gives them the reference's Rust
+ * signatures).  Every entry point names the reference interface it replaces.
+ *
+ * Conventions
+ *  - all functions return an APTGPU_* status code; on error `err` (if given)
+ *    receives the same message string the reference puts in its err::Error.
+ *  - "host" pointers are ordinary process memory; "d_" pointers are device
+ *    (HBM) memory on the plan's GPU.
+ *  - thread-safe and re-entrant: no mutable global state; a plan must not be
+ *    used from two threads at once (make one plan per thread / per stream).
+ *  - numerics: f32 throughout, every product and sum rounded separately and
+ *    accumulated in the reference's order, so outputs are bit-identical to
+ *    the reference's scalar loops (APTGPU_MODE_STRICT, the default).
+ */
+#ifndef APTGPU_H
+#define APTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------ */
+#define APTGPU_OK 0
+#define APTGPU_ERR_INTERNAL 1      /* err::Error::Internal(String)      src/err.rs:27   */
+#define APTGPU_ERR_RATE_OVERFLOW 2 /* err::Error::RateOverflow(String)  src/err.rs:31   */
+#define APTGPU_ERR_HIP 3           /* HIP runtime / device failure (Rust shim: Internal) */
+#define APTGPU_ERR_INVALID 4       /* FFI misuse: null pointer, capacity too small, ...  */
+#define APTGPU_ERR_UNSUPPORTED 5   /* reference feature not offered on the GPU path      */
+
+/* ---- filters (src/filters.rs:22-46) ------------------------------------ */
+#define APTGPU_FILTER_NOFILTER 0          /* filters::NoFilter          */
+#define APTGPU_FILTER_LOWPASS 1           /* filters::Lowpass           */
+#define APTGPU_FILTER_LOWPASS_DC_REMOVAL 2 /* filters::LowpassDcRemoval */
+
+/* A `impl filters::Filter` value: frequencies are Freq.pi_rad (fractions of
+ * pi rad/sample, src/frequency.rs:30-32), atten in positive dB. */
+typedef struct aptgpu_filter {
+    int32_t kind;
+    float cutout_pi_rad;
+    float atten;
+    float delta_w_pi_rad;
+} aptgpu_filter;
+
+/* ---- config::Settings, the fields decode() reads (src/config.rs:76-106;
+ *      read at src/decode.rs:55,57,68,70,75,98) ---------------------------- */
+typedef struct aptgpu_settings {
+    uint32_t work_rate;         /* Hz, intermediate processing rate            */
+    float resample_atten;       /* dB                                          */
+    float resample_delta_freq;  /* Hz                                          */
+    float resample_cutout;      /* Hz                                          */
+    float demodulation_atten;   /* dB                                          */
+    int32_t export_wav;         /* Settings.export_wav: deliver steps via step */
+    int32_t export_resample_filtered; /* must be 0 (APTGPU_ERR_UNSUPPORTED)    */
+} aptgpu_settings;
+
+/* ---- context::Context (src/context.rs:100-133) -------------------------- */
+/* Context::status(progress, description)  src/context.rs:127-129 */
+typedef void (*aptgpu_status_fn)(float progress, const char *description, void *user);
+/* Context::step(Step{id, variant, data, rate})  src/context.rs:132-211.
+ * variant: 0 = Variant::Signal, 1 = Variant::Filter; rate_hz 0 = None.
+ * `data` is host memory valid only during the call.  Return nonzero to abort
+ * the decode with APTGPU_ERR_INTERNAL (the reference propagates step errors). */
+typedef int (*aptgpu_step_fn)(const char *id, int variant, const float *data, size_t n,
+                              uint32_t rate_hz, void *user);
+
+typedef struct aptgpu_context {
+    aptgpu_status_fn status; /* nullable */
+    aptgpu_step_fn step;     /* nullable; only called when settings.export_wav != 0 */
+    void *user;
+    int32_t device;          /* HIP device ordinal */
+    int32_t mode;            /* APTGPU_MODE_* */
+    void *stream;            /* hipStream_t to run on, NULL = the plan's own stream */
+} aptgpu_context;
+
+#define APTGPU_MODE_STRICT 0 /* bit-exact with the reference's f32 loops; fused kernels when
+                                the (L, M, taps) combination has a specialisation          */
+#define APTGPU_MODE_GENERIC 1 /* force the unfused generic kernels (any rate combination)   */
+
+/* What find_sync()/decode() learned; the reference only logs it
+ * (`info!("Found {} sync frames")` src/decode.rs:260). */
+typedef struct aptgpu_stats {
+    uint64_t work_len;      /* samples after the first resample                 */
+    uint64_t n_sync;        /* peaks.len() of find_sync (0 when sync == 0)      */
+    uint64_t n_rows;        /* image rows returned                              */
+    uint32_t l, m;          /* interpolation / decimation factors dsp.rs:73-75  */
+    uint32_t n_resample_taps, n_lowpass_taps;
+    int32_t fused;          /* 1 if the fused specialised kernel ran            */
+    int32_t orbit_path;     /* peak-picker path: 0 doubling (LDS), 1 bitmask walk */
+} aptgpu_stats;
+
+/* ====================================================================== */
+/* 1. decode()                                                             */
+/* ====================================================================== */
+
+/* Replaces  pub fn decode(context: &mut Context, settings: &config::Settings,
+ *                         signal: &Signal, input_rate: Rate, sync: bool)
+ *                         -> err::Result<Signal>        src/decode.rs:43-49
+ * signal: host f32 samples exactly as wav::load_wav produces them (unscaled,
+ * first channel; src/wav.rs:30-51).  On success *rows_out is a malloc'd
+ * buffer of *n_out = rows*2080 floats (release with aptgpu_free).
+ * Errors and their messages are the reference's (src/decode.rs:79-83,112-118,
+ * 172-176; src/dsp.rs:69-71,82-91). */
+int aptgpu_decode(const aptgpu_context *ctx, const aptgpu_settings *settings,
+                  const float *signal, size_t n, uint32_t input_rate_hz, int sync,
+                  float **rows_out, size_t *n_out, aptgpu_stats *stats /* nullable */,
+                  char *err, size_t err_cap);
+
+/* Releases any buffer this library returned (Vec<f32> drop). */
+void aptgpu_free(void *p);
+
+/* ====================================================================== */
+/* 2. plans: device-resident and batched decode                            */
+/* ====================================================================== */
+
+/* A plan owns the designed taps, the HBM workspace and a stream for decode()
+ * calls of one (settings, input_rate, sync) combination on one GPU.  It is
+ * what a long-running caller (GUI worker thread src/gui/work.rs:174-197, or a
+ * batch driver over independent recordings) keeps between calls. */
+typedef struct aptgpu_plan aptgpu_plan;
+
+typedef struct aptgpu_plan_info {
+    uint32_t l, m;
+    uint32_t n_resample_taps, n_lowpass_taps, n_sync_taps;
+    uint32_t samples_per_work_row; /* PX_PER_ROW * work_rate / FINAL_RATE  decode.rs:55 */
+    uint32_t min_distance;         /* samples_per_work_row * 8 / 10        decode.rs:216 */
+    uint64_t max_samples;          /* capacity the plan was created for                  */
+    uint64_t max_work_len;         /* work-rate samples at max_samples                   */
+    uint64_t max_rows;             /* upper bound on rows for max_samples                */
+    int32_t fused;                 /* fused specialised kernels available                */
+    int32_t max_batch;
+} aptgpu_plan_info;
+
+/* Result record the device fills per recording (also readable from the host
+ * with aptgpu_plan_results). */
+typedef struct aptgpu_result {
+    int32_t status;    /* APTGPU_OK, or APTGPU_ERR_INTERNAL (<10 rows / <5 sync frames) */
+    int32_t reason;    /* 0 ok, 1 "<10 rows", 2 "<5 sync frames"                          */
+    uint32_t n_rows;   /* image rows written (n_out / 2080 when sync != 0)                  */
+    uint32_t n_sync;   /* peaks.len() of find_sync, 0 when sync == 0                         */
+    uint64_t work_len; /* samples after the first resample                                   */
+    uint64_t n_out;    /* floats written to d_rows                                           */
+} aptgpu_result;
+
+int aptgpu_plan_create(const aptgpu_context *ctx, const aptgpu_settings *settings,
+                       uint32_t input_rate_hz, int sync, size_t max_samples, int max_batch,
+                       aptgpu_plan **plan_out, char *err, size_t err_cap);
+void aptgpu_plan_destroy(aptgpu_plan *plan);
+int aptgpu_plan_get_info(const aptgpu_plan *plan, aptgpu_plan_info *info);
+
+/* Enqueue decode() of `count` independent recordings already resident in HBM.
+ * d_signals[i] points to n[i] device floats; d_rows[i] receives up to
+ * rows_cap[i]*2080 device floats.  Asynchronous on the plan's stream (or
+ * ctx.stream given at plan creation): no host synchronisation, so it can be
+ * captured in a hipGraph.  Outcome per recording lands in the plan's result
+ * records. */
+int aptgpu_plan_decode_device(aptgpu_plan *plan, int count, const float *const *d_signals,
+                              const size_t *n, float *const *d_rows, const size_t *rows_cap,
+                              char *err, size_t err_cap);
+/* Waits for the stream and copies the `count` result records to the host. */
+int aptgpu_plan_results(aptgpu_plan *plan, int count, aptgpu_result *results);
+/* Sync-frame positions found by the last decode of recording i (find_sync()'s
+ * return value, src/decode.rs:262); writes min(cap, n_sync) entries. */
+int aptgpu_plan_sync_positions(aptgpu_plan *plan, int i, uint64_t *pos, size_t cap,
+                               size_t *n_sync);
+int aptgpu_plan_synchronize(aptgpu_plan *plan);
+
+/* Per-kernel timing with HIP events recorded on the plan's stream around
+ * every kernel launch.  Enable, run decodes, then collect: averages are over
+ * all launches since the last enable/collect. */
+typedef struct aptgpu_kernel_time {
+    char name[48];
+    double avg_ms;
+    uint64_t launches;
+} aptgpu_kernel_time;
+int aptgpu_plan_enable_timing(aptgpu_plan *plan, int on);
+int aptgpu_plan_collect_timing(aptgpu_plan *plan, aptgpu_kernel_time *out, size_t cap,
+                               size_t *n_out);
+
+/* ====================================================================== */
+/* 3. the dsp.rs / filters.rs / decode.rs building blocks (host buffers)    */
+/* ====================================================================== */
+/* These mirror the reference functions one-to-one so stage-level parity    */
+/* tests read like the reference's own unit tests.  Outputs are malloc'd.   */
+
+/* Filter::design()                     src/filters.rs:48-54,57-88,98-132 (host math) */
+int aptgpu_filter_design(const aptgpu_filter *f, float **coeff_out, size_t *n_out);
+/* Filter::resample(input_rate, output_rate)   src/filters.rs:90-94,134-138 */
+void aptgpu_filter_resample(aptgpu_filter *f, uint32_t input_rate_hz, uint32_t output_rate_hz);
+/* generate_sync_frame(work_rate)       src/decode.rs:171-199 */
+int aptgpu_generate_sync_frame(uint32_t work_rate_hz, int8_t **frame_out, size_t *n_out,
+                               char *err, size_t err_cap);
+/* dsp::resample_with_filter(context, signal, input_rate, output_rate, filt)  src/dsp.rs:62-126 */
+int aptgpu_resample_with_filter(const aptgpu_context *ctx, const float *signal, size_t n,
+                                uint32_t input_rate_hz, uint32_t output_rate_hz,
+                                aptgpu_filter filt, float **out, size_t *n_out, char *err,
+                                size_t err_cap);
+/* dsp::resample(context, signal, input_rate, output_rate, atten, delta_w)   src/dsp.rs:132-162
+ * (the WAV->WAV tool path, src/resample.rs:36) */
+int aptgpu_resample(const aptgpu_context *ctx, const float *signal, size_t n,
+                    uint32_t input_rate_hz, uint32_t output_rate_hz, float atten,
+                    float delta_w_pi_rad, float **out, size_t *n_out, char *err, size_t err_cap);
+/* dsp::demodulate(context, signal, carrier_freq)   src/dsp.rs:350-383 */
+int aptgpu_demodulate(const aptgpu_context *ctx, const float *signal, size_t n,
+                      float carrier_pi_rad, float **out, char *err, size_t err_cap);
+/* dsp::filter(context, signal, filter)             src/dsp.rs:386-410 */
+int aptgpu_filter_signal(const aptgpu_context *ctx, const float *signal, size_t n,
+                         aptgpu_filter filt, float **out, char *err, size_t err_cap);
+/* find_sync(context, signal, work_rate)            src/decode.rs:204-263
+ * correlation_out nullable (the "sync_correlation" step). */
+int aptgpu_find_sync(const aptgpu_context *ctx, const float *signal, size_t n,
+                     uint32_t work_rate_hz, uint64_t **pos_out, size_t *n_pos,
+                     float **correlation_out, size_t *n_corr, char *err, size_t err_cap);
+
+/* ====================================================================== */
+/* 4. misc                                                                 */
+/* ====================================================================== */
+const char *aptgpu_version(void);
+int aptgpu_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APTGPU_H */

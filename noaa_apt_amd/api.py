@@ -1,0 +1,464 @@
+"""ctypes binding of include/aptgpu.h with the reference's names (see package docstring)."""
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+FINAL_RATE = 4160    # decode.rs:14
+PX_PER_ROW = 2080    # decode.rs:35
+CARRIER_FREQ = 2400  # decode.rs:38
+
+MODE_STRICT = 0
+MODE_GENERIC = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libaptgpu.so")
+_f32p = C.POINTER(C.c_float)
+_u64p = C.POINTER(C.c_uint64)
+_i8p = C.POINTER(C.c_int8)
+_ERRCAP = 1024
+
+
+# ------------------------------------------------------------------ errors (err.rs:9-44)
+class AptError(Exception):
+    code = -1
+
+
+class InternalError(AptError):       # err::Error::Internal
+    code = 1
+
+
+class RateOverflowError(AptError):   # err::Error::RateOverflow
+    code = 2
+
+
+class HipError(AptError):            # device/runtime failure
+    code = 3
+
+
+class InvalidError(AptError):        # FFI misuse
+    code = 4
+
+
+class UnsupportedError(AptError):
+    code = 5
+
+
+_ERRORS = {c.code: c for c in (InternalError, RateOverflowError, HipError, InvalidError,
+                               UnsupportedError)}
+
+
+def _check(rc, err=None):
+    if rc != 0:
+        msg = err.value.decode("utf-8", "replace") if err is not None else ""
+        raise _ERRORS.get(rc, AptError)(msg or f"aptgpu status {rc}")
+
+
+# ------------------------------------------------------------------ C structs
+class _CFilter(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("cutout_pi_rad", C.c_float), ("atten", C.c_float),
+                ("delta_w_pi_rad", C.c_float)]
+
+
+class _CSettings(C.Structure):
+    _fields_ = [("work_rate", C.c_uint32), ("resample_atten", C.c_float),
+                ("resample_delta_freq", C.c_float), ("resample_cutout", C.c_float),
+                ("demodulation_atten", C.c_float), ("export_wav", C.c_int32),
+                ("export_resample_filtered", C.c_int32)]
+
+
+_STATUS_FN = C.CFUNCTYPE(None, C.c_float, C.c_char_p, C.c_void_p)
+_STEP_FN = C.CFUNCTYPE(C.c_int, C.c_char_p, C.c_int, _f32p, C.c_size_t, C.c_uint32, C.c_void_p)
+
+
+class _CContext(C.Structure):
+    _fields_ = [("status", _STATUS_FN), ("step", _STEP_FN), ("user", C.c_void_p),
+                ("device", C.c_int32), ("mode", C.c_int32), ("stream", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("work_len", C.c_uint64), ("n_sync", C.c_uint64), ("n_rows", C.c_uint64),
+                ("l", C.c_uint32), ("m", C.c_uint32), ("n_resample_taps", C.c_uint32),
+                ("n_lowpass_taps", C.c_uint32), ("fused", C.c_int32), ("orbit_path", C.c_int32)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("l", C.c_uint32), ("m", C.c_uint32), ("n_resample_taps", C.c_uint32),
+                ("n_lowpass_taps", C.c_uint32), ("n_sync_taps", C.c_uint32),
+                ("samples_per_work_row", C.c_uint32), ("min_distance", C.c_uint32),
+                ("max_samples", C.c_uint64), ("max_work_len", C.c_uint64),
+                ("max_rows", C.c_uint64), ("fused", C.c_int32), ("max_batch", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_int32), ("reason", C.c_int32), ("n_rows", C.c_uint32),
+                ("n_sync", C.c_uint32), ("work_len", C.c_uint64), ("n_out", C.c_uint64)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("avg_ms", C.c_double), ("launches", C.c_uint64)]
+
+
+# ------------------------------------------------------------------ library loading
+_lib = None
+
+
+def lib_path():
+    return _LIB
+
+
+def build():
+    """Compile libaptgpu.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j4", "all"])
+
+
+def lib():
+    """The loaded libaptgpu.so.  Raises if it has not been built — there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise ImportError(f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; "
+                          f"g.build()'` (or `make -C noaa_apt_amd/csrc`) first")
+    L = C.CDLL(_LIB)
+    vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
+    L.aptgpu_version.restype = C.c_char_p
+    L.aptgpu_device_count.restype = i32
+    L.aptgpu_free.argtypes = [vp]
+    L.aptgpu_free.restype = None
+    L.aptgpu_decode.argtypes = [C.POINTER(_CContext), C.POINTER(_CSettings), _f32p, sz, u32, i32,
+                                C.POINTER(_f32p), C.POINTER(sz), C.POINTER(Stats), C.c_char_p, sz]
+    L.aptgpu_plan_create.argtypes = [C.POINTER(_CContext), C.POINTER(_CSettings), u32, i32, sz,
+                                     i32, C.POINTER(vp), C.c_char_p, sz]
+    L.aptgpu_plan_destroy.argtypes = [vp]
+    L.aptgpu_plan_destroy.restype = None
+    L.aptgpu_plan_get_info.argtypes = [vp, C.POINTER(PlanInfo)]
+    L.aptgpu_plan_decode_device.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp),
+                                            C.POINTER(sz), C.c_char_p, sz]
+    L.aptgpu_plan_results.argtypes = [vp, i32, C.POINTER(Result)]
+    L.aptgpu_plan_sync_positions.argtypes = [vp, i32, _u64p, sz, C.POINTER(sz)]
+    L.aptgpu_plan_synchronize.argtypes = [vp]
+    L.aptgpu_plan_enable_timing.argtypes = [vp, i32]
+    L.aptgpu_plan_collect_timing.argtypes = [vp, C.POINTER(KernelTime), sz, C.POINTER(sz)]
+    L.aptgpu_filter_design.argtypes = [C.POINTER(_CFilter), C.POINTER(_f32p), C.POINTER(sz)]
+    L.aptgpu_filter_resample.argtypes = [C.POINTER(_CFilter), u32, u32]
+    L.aptgpu_filter_resample.restype = None
+    L.aptgpu_generate_sync_frame.argtypes = [u32, C.POINTER(_i8p), C.POINTER(sz), C.c_char_p, sz]
+    L.aptgpu_resample_with_filter.argtypes = [C.POINTER(_CContext), _f32p, sz, u32, u32, _CFilter,
+                                              C.POINTER(_f32p), C.POINTER(sz), C.c_char_p, sz]
+    L.aptgpu_resample.argtypes = [C.POINTER(_CContext), _f32p, sz, u32, u32, C.c_float, C.c_float,
+                                  C.POINTER(_f32p), C.POINTER(sz), C.c_char_p, sz]
+    L.aptgpu_demodulate.argtypes = [C.POINTER(_CContext), _f32p, sz, C.c_float, C.POINTER(_f32p),
+                                    C.c_char_p, sz]
+    L.aptgpu_filter_signal.argtypes = [C.POINTER(_CContext), _f32p, sz, _CFilter, C.POINTER(_f32p),
+                                       C.c_char_p, sz]
+    L.aptgpu_find_sync.argtypes = [C.POINTER(_CContext), _f32p, sz, u32, C.POINTER(_u64p),
+                                   C.POINTER(sz), C.POINTER(_f32p), C.POINTER(sz), C.c_char_p, sz]
+    _lib = L
+    return L
+
+
+def version():
+    return lib().aptgpu_version().decode()
+
+
+def device_count():
+    return int(lib().aptgpu_device_count())
+
+
+def _take(ptr, n, dtype=np.float32):
+    n = int(n)
+    out = np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True) if n else np.zeros(0, dtype)
+    lib().aptgpu_free(C.cast(ptr, C.c_void_p))
+    return out
+
+
+def _as_f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_f32p)
+
+
+# ------------------------------------------------------------------ frequency.rs
+@dataclass(frozen=True)
+class Rate:
+    """Sample rate in Hz (frequency.rs:98-117)."""
+    hz_: int
+
+    @staticmethod
+    def hz(r):
+        return Rate(int(r))
+
+    def get_hz(self):
+        return self.hz_
+
+
+@dataclass(frozen=True)
+class Freq:
+    """Discrete-time frequency as a fraction of pi rad/sample, f32 (frequency.rs:30-88)."""
+    pi_rad_: float
+
+    @staticmethod
+    def pi_rad(f):
+        return Freq(float(np.float32(f)))
+
+    @staticmethod
+    def hz(f, rate: Rate):
+        return Freq(float(np.float32(2.0) * np.float32(f) / np.float32(rate.get_hz())))
+
+    def get_pi_rad(self):
+        return self.pi_rad_
+
+    def __truediv__(self, o):
+        return Freq(float(np.float32(self.pi_rad_) / np.float32(o)))
+
+
+# ------------------------------------------------------------------ config.rs / context.rs
+@dataclass
+class Settings:
+    """The config::Settings fields decode() reads; defaults = the `standard` profile
+    (/root/reference/src/default_settings.toml:108-116)."""
+    work_rate: int = 12480
+    resample_atten: float = 30.0
+    resample_delta_freq: float = 1000.0
+    resample_cutout: float = 4800.0
+    demodulation_atten: float = 25.0
+    export_wav: bool = False
+    export_resample_filtered: bool = False
+
+    @staticmethod
+    def profile(name):
+        p = {"standard": dict(work_rate=12480, resample_atten=30.0, resample_delta_freq=1000.0,
+                              resample_cutout=4800.0, demodulation_atten=25.0),
+             "fast": dict(work_rate=16640, resample_atten=30.0, resample_delta_freq=3000.0,
+                          resample_cutout=4800.0, demodulation_atten=23.0),
+             "slow": dict(work_rate=20800, resample_atten=40.0, resample_delta_freq=500.0,
+                          resample_cutout=4800.0, demodulation_atten=25.0)}[name]
+        return Settings(**p)
+
+    def _c(self):
+        return _CSettings(self.work_rate, self.resample_atten, self.resample_delta_freq,
+                          self.resample_cutout, self.demodulation_atten,
+                          1 if self.export_wav else 0, 1 if self.export_resample_filtered else 0)
+
+
+@dataclass
+class Context:
+    """context::Context: progress callback + step export (context.rs:100-211)."""
+    ui_callback: Optional[Callable[[float, str], None]] = None
+    step_callback: Optional[Callable[[str, int, np.ndarray, Optional[int]], None]] = None
+    device: int = 0
+    mode: int = MODE_STRICT
+    stream: int = 0
+    _keep: list = field(default_factory=list, repr=False)
+
+    @staticmethod
+    def decode(ui_callback=None, step_callback=None, device=0, mode=MODE_STRICT):
+        return Context(ui_callback, step_callback, device, mode)
+
+    def _c(self):
+        def status(progress, text, _user):
+            if self.ui_callback:
+                self.ui_callback(float(progress), text.decode())
+
+        def step(ident, variant, data, n, rate, _user):
+            if self.step_callback:
+                arr = (np.ctypeslib.as_array(data, shape=(int(n),)).copy() if n
+                       else np.zeros(0, np.float32))
+                try:
+                    self.step_callback(ident.decode(), int(variant), arr, int(rate) or None)
+                except Exception:  # propagate like `?`
+                    return 1
+            return 0
+
+        s, t = _STATUS_FN(status), _STEP_FN(step)
+        self._keep = [s, t]
+        return _CContext(s, t, None, self.device, self.mode, self.stream or None)
+
+
+# ------------------------------------------------------------------ filters.rs
+@dataclass
+class NoFilter:
+    kind = 0
+
+    def _c(self):
+        return _CFilter(0, 0.0, 0.0, 0.0)
+
+    def design(self):
+        return _design(self._c())
+
+    def resample(self, input_rate: Rate, output_rate: Rate):
+        pass
+
+
+@dataclass
+class Lowpass:
+    cutout: Freq
+    atten: float
+    delta_w: Freq
+    kind = 1
+
+    def _c(self):
+        return _CFilter(self.kind, self.cutout.get_pi_rad(), self.atten, self.delta_w.get_pi_rad())
+
+    def design(self):
+        return _design(self._c())
+
+    def resample(self, input_rate: Rate, output_rate: Rate):
+        c = self._c()
+        lib().aptgpu_filter_resample(C.byref(c), input_rate.get_hz(), output_rate.get_hz())
+        self.cutout, self.delta_w = Freq(float(c.cutout_pi_rad)), Freq(float(c.delta_w_pi_rad))
+
+
+@dataclass
+class LowpassDcRemoval(Lowpass):
+    kind = 2
+
+
+def _design(cf):
+    out, n = _f32p(), C.c_size_t()
+    _check(lib().aptgpu_filter_design(C.byref(cf), C.byref(out), C.byref(n)))
+    return _take(out, n.value)
+
+
+# ------------------------------------------------------------------ decode.rs / dsp.rs
+def decode(context: Optional[Context], settings: Settings, signal, input_rate: Rate, sync: bool,
+           return_stats=False):
+    """noaa_apt::decode — returns the raw image, line by line (flat f32, rows*2080)."""
+    ctx = (context or Context())
+    cctx, cs = ctx._c(), settings._c()
+    x, xp = _as_f32(signal)
+    out, n, st = _f32p(), C.c_size_t(), Stats()
+    err = C.create_string_buffer(_ERRCAP)
+    rc = lib().aptgpu_decode(C.byref(cctx), C.byref(cs), xp, x.size, input_rate.get_hz(),
+                             1 if sync else 0, C.byref(out), C.byref(n), C.byref(st), err, _ERRCAP)
+    _check(rc, err)
+    rows = _take(out, n.value)
+    return (rows, st) if return_stats else rows
+
+
+def resample_with_filter(context, signal, input_rate: Rate, output_rate: Rate, filt):
+    cctx = (context or Context())._c()
+    x, xp = _as_f32(signal)
+    out, n = _f32p(), C.c_size_t()
+    err = C.create_string_buffer(_ERRCAP)
+    _check(lib().aptgpu_resample_with_filter(C.byref(cctx), xp, x.size, input_rate.get_hz(),
+                                             output_rate.get_hz(), filt._c(), C.byref(out),
+                                             C.byref(n), err, _ERRCAP), err)
+    return _take(out, n.value)
+
+
+def resample(context, signal, input_rate: Rate, output_rate: Rate, atten, delta_w: Freq):
+    cctx = (context or Context())._c()
+    x, xp = _as_f32(signal)
+    out, n = _f32p(), C.c_size_t()
+    err = C.create_string_buffer(_ERRCAP)
+    _check(lib().aptgpu_resample(C.byref(cctx), xp, x.size, input_rate.get_hz(),
+                                 output_rate.get_hz(), atten, delta_w.get_pi_rad(), C.byref(out),
+                                 C.byref(n), err, _ERRCAP), err)
+    return _take(out, n.value)
+
+
+def demodulate(context, signal, carrier_freq: Freq):
+    cctx = (context or Context())._c()
+    x, xp = _as_f32(signal)
+    out = _f32p()
+    err = C.create_string_buffer(_ERRCAP)
+    _check(lib().aptgpu_demodulate(C.byref(cctx), xp, x.size, carrier_freq.get_pi_rad(),
+                                   C.byref(out), err, _ERRCAP), err)
+    return _take(out, x.size)
+
+
+def filter(context, signal, filt):  # noqa: A001 - the reference's name (dsp.rs:386)
+    cctx = (context or Context())._c()
+    x, xp = _as_f32(signal)
+    out = _f32p()
+    err = C.create_string_buffer(_ERRCAP)
+    _check(lib().aptgpu_filter_signal(C.byref(cctx), xp, x.size, filt._c(), C.byref(out), err,
+                                      _ERRCAP), err)
+    return _take(out, x.size)
+
+
+def find_sync(context, signal, work_rate: Rate, return_correlation=False):
+    cctx = (context or Context())._c()
+    x, xp = _as_f32(signal)
+    pos, npos, corr, ncorr = _u64p(), C.c_size_t(), _f32p(), C.c_size_t()
+    err = C.create_string_buffer(_ERRCAP)
+    _check(lib().aptgpu_find_sync(C.byref(cctx), xp, x.size, work_rate.get_hz(), C.byref(pos),
+                                  C.byref(npos), C.byref(corr) if return_correlation else None,
+                                  C.byref(ncorr), err, _ERRCAP), err)
+    p = _take(pos, npos.value, np.uint64)
+    return (p, _take(corr, ncorr.value)) if return_correlation else p
+
+
+def generate_sync_frame(work_rate: Rate):
+    out, n = _i8p(), C.c_size_t()
+    err = C.create_string_buffer(_ERRCAP)
+    _check(lib().aptgpu_generate_sync_frame(work_rate.get_hz(), C.byref(out), C.byref(n), err,
+                                            _ERRCAP), err)
+    return _take(out, n.value, np.int8)
+
+
+# ------------------------------------------------------------------ plans (device-resident)
+class Plan:
+    """aptgpu_plan: device-resident / batched decode().  Device pointers are plain ints
+    (e.g. torch.Tensor.data_ptr()); torch is only the allocator, never on the compute path."""
+
+    def __init__(self, settings: Settings, input_rate: Rate, sync=True, max_samples=0, max_batch=1,
+                 device=0, mode=MODE_STRICT, stream=0):
+        self._ctx = Context(device=device, mode=mode, stream=stream)
+        cctx, cs = self._ctx._c(), settings._c()
+        self._p = C.c_void_p()
+        err = C.create_string_buffer(_ERRCAP)
+        _check(lib().aptgpu_plan_create(C.byref(cctx), C.byref(cs), input_rate.get_hz(),
+                                        1 if sync else 0, int(max_samples), int(max_batch),
+                                        C.byref(self._p), err, _ERRCAP), err)
+        self.info = PlanInfo()
+        _check(lib().aptgpu_plan_get_info(self._p, C.byref(self.info)))
+
+    def close(self):
+        if self._p:
+            lib().aptgpu_plan_destroy(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode_device(self, d_signals: Sequence[int], n: Sequence[int], d_rows: Sequence[int],
+                      rows_cap: Sequence[int]):
+        k = len(d_signals)
+        sig = (C.c_void_p * k)(*d_signals)
+        rows = (C.c_void_p * k)(*d_rows)
+        nn = (C.c_size_t * k)(*n)
+        cap = (C.c_size_t * k)(*rows_cap)
+        err = C.create_string_buffer(_ERRCAP)
+        _check(lib().aptgpu_plan_decode_device(self._p, k, sig, nn, rows, cap, err, _ERRCAP), err)
+
+    def results(self, count=1) -> List[Result]:
+        arr = (Result * count)()
+        _check(lib().aptgpu_plan_results(self._p, count, arr))
+        return list(arr)
+
+    def sync_positions(self, i=0, cap=1 << 20):
+        buf = (C.c_uint64 * cap)()
+        n = C.c_size_t()
+        _check(lib().aptgpu_plan_sync_positions(self._p, i, buf, cap, C.byref(n)))
+        return np.array(buf[:min(cap, n.value)], dtype=np.uint64)
+
+    def synchronize(self):
+        _check(lib().aptgpu_plan_synchronize(self._p))
+
+    def enable_timing(self, on=True):
+        _check(lib().aptgpu_plan_enable_timing(self._p, 1 if on else 0))
+
+    def collect_timing(self):
+        arr = (KernelTime * 32)()
+        n = C.c_size_t()
+        _check(lib().aptgpu_plan_collect_timing(self._p, arr, 32, C.byref(n)))
+        return {arr[i].name.decode(): (arr[i].avg_ms, int(arr[i].launches))
+                for i in range(min(32, n.value))}

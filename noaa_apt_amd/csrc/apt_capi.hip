@@ -1,0 +1,635 @@
+// apt_capi.hip — the extern "C" surface declared in include/aptgpu.h.
+// No exception crosses the ABI; apt::Error maps to status code + message.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "apt_plan.hpp"
+
+namespace {
+
+using apt::Error;
+using apt::ErrorKind;
+
+void put_err(char *err, size_t cap, const std::string &msg)
+{
+    if (err && cap) std::snprintf(err, cap, "%s", msg.c_str());
+}
+
+int fail(const Error &e, char *err, size_t cap)
+{
+    put_err(err, cap, e.message);
+    return static_cast<int>(e.kind);
+}
+
+template <typename Fn>
+int guarded(char *err, size_t cap, Fn &&fn)
+{
+    try {
+        return fn();
+    } catch (const Error &e) {
+        return fail(e, err, cap);
+    } catch (const std::bad_alloc &) {
+        put_err(err, cap, "out of host memory");
+        return APTGPU_ERR_INVALID;
+    } catch (const std::exception &e) {
+        put_err(err, cap, e.what());
+        return APTGPU_ERR_INTERNAL;
+    }
+}
+
+template <typename T>
+T *host_alloc(size_t n)
+{
+    T *p = static_cast<T *>(std::malloc((n ? n : 1) * sizeof(T)));
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+
+struct PlanDeleter {
+    void operator()(aptgpu_plan *p) const { aptgpu_plan_destroy(p); }
+};
+using PlanPtr = std::unique_ptr<aptgpu_plan, PlanDeleter>;
+
+void status(const aptgpu_context *ctx, float progress, const std::string &text)
+{
+    if (ctx && ctx->status) ctx->status(progress, text.c_str(), ctx->user);
+}
+
+// Context::step through the C callback; a nonzero return aborts like `?` in the reference.
+void step(const aptgpu_context *ctx, bool on, const char *id, int variant, const float *data,
+          size_t n, uint32_t rate)
+{
+    if (!on || !ctx || !ctx->step) return;
+    if (ctx->step(id, variant, data, n, rate, ctx->user) != 0)
+        throw Error{ErrorKind::Internal, std::string("step callback failed at \"") + id + "\""};
+}
+
+apt::Signal download(const float *d, size_t n, hipStream_t s)
+{
+    apt::Signal h(n);
+    if (n) {
+        apt::hip_check(hipMemcpyAsync(h.data(), d, n * sizeof(float), hipMemcpyDeviceToHost, s),
+                       "hipMemcpyAsync D2H");
+        apt::hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+    }
+    return h;
+}
+
+const char *kTooShort = "Got less than 10 rows of samples, audio file is too short";
+const char *kFewSync = "Found less than 5 sync frames, audio file is too short or too noisy";
+const char *kNotMultiple = "work_rate is not multiple of FINAL_RATE";
+
+aptgpu_context default_ctx()
+{
+    aptgpu_context c{};
+    return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *aptgpu_version(void) { return "aptgpu 0.1.0 (gfx950)"; }
+
+int aptgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void aptgpu_free(void *p) { std::free(p); }
+
+// ------------------------------------------------------------------ plans
+int aptgpu_plan_create(const aptgpu_context *ctx, const aptgpu_settings *settings,
+                       uint32_t input_rate_hz, int sync, size_t max_samples, int max_batch,
+                       aptgpu_plan **plan_out, char *err, size_t err_cap)
+{
+    if (!settings || !plan_out) {
+        put_err(err, err_cap, "null argument");
+        return APTGPU_ERR_INVALID;
+    }
+    return guarded(err, err_cap, [&] {
+        *plan_out = apt::plan_create(ctx, *settings, input_rate_hz, sync != 0, max_samples, max_batch);
+        return APTGPU_OK;
+    });
+}
+
+void aptgpu_plan_destroy(aptgpu_plan *plan)
+{
+    if (!plan) return;
+    (void)hipSetDevice(plan->device);
+    if (plan->stream) (void)hipStreamSynchronize(plan->stream);
+    if (plan->own_stream && plan->stream) (void)hipStreamDestroy(plan->stream);
+    delete plan;
+}
+
+int aptgpu_plan_get_info(const aptgpu_plan *plan, aptgpu_plan_info *info)
+{
+    if (!plan || !info) return APTGPU_ERR_INVALID;
+    info->l = plan->l;
+    info->m = plan->m;
+    info->n_resample_taps = static_cast<uint32_t>(plan->taps_resample.size());
+    info->n_lowpass_taps = static_cast<uint32_t>(plan->taps_lowpass.size());
+    info->n_sync_taps = plan->n_sync_taps;
+    info->samples_per_work_row = plan->spr;
+    info->min_distance = plan->md;
+    info->max_samples = plan->max_samples;
+    info->max_work_len = plan->max_work_len;
+    info->max_rows = plan->max_rows;
+    info->fused = plan->fused ? 1 : 0;
+    info->max_batch = plan->max_batch;
+    return APTGPU_OK;
+}
+
+int aptgpu_plan_decode_device(aptgpu_plan *plan, int count, const float *const *d_signals,
+                              const size_t *n, float *const *d_rows, const size_t *rows_cap,
+                              char *err, size_t err_cap)
+{
+    if (!plan || !d_signals || !n || !d_rows || !rows_cap || count < 0 ||
+        count > plan->max_batch) {
+        put_err(err, err_cap, "bad argument to aptgpu_plan_decode_device");
+        return APTGPU_ERR_INVALID;
+    }
+    return guarded(err, err_cap, [&] {
+        apt::hip_check(hipSetDevice(plan->device), "hipSetDevice");
+        for (int i = 0; i < count; ++i) {
+            if (n[i] > plan->max_samples)
+                throw Error{ErrorKind::Invalid, "recording longer than the plan's max_samples"};
+            plan->enqueue(i, d_signals[i], n[i], d_rows[i], rows_cap[i] * 2080u, false);
+        }
+        return APTGPU_OK;
+    });
+}
+
+int aptgpu_plan_synchronize(aptgpu_plan *plan)
+{
+    if (!plan) return APTGPU_ERR_INVALID;
+    (void)hipSetDevice(plan->device);
+    return hipStreamSynchronize(plan->stream) == hipSuccess ? APTGPU_OK : APTGPU_ERR_HIP;
+}
+
+int aptgpu_plan_results(aptgpu_plan *plan, int count, aptgpu_result *results)
+{
+    if (!plan || !results || count < 0 || count > plan->max_batch) return APTGPU_ERR_INVALID;
+    static_assert(sizeof(aptgpu_result) == sizeof(apt::gpu::Result), "result layout");
+    (void)hipSetDevice(plan->device);
+    if (hipMemcpyAsync(results, plan->d_results.ptr, sizeof(aptgpu_result) * count,
+                       hipMemcpyDeviceToHost, plan->stream) != hipSuccess)
+        return APTGPU_ERR_HIP;
+    return hipStreamSynchronize(plan->stream) == hipSuccess ? APTGPU_OK : APTGPU_ERR_HIP;
+}
+
+int aptgpu_plan_sync_positions(aptgpu_plan *plan, int i, uint64_t *pos, size_t cap, size_t *n_sync)
+{
+    if (!plan || i < 0 || i >= plan->max_batch || !n_sync) return APTGPU_ERR_INVALID;
+    aptgpu_result r{};
+    (void)hipSetDevice(plan->device);
+    if (hipMemcpyAsync(&r, plan->d_results.ptr + i, sizeof r, hipMemcpyDeviceToHost,
+                       plan->stream) != hipSuccess ||
+        hipStreamSynchronize(plan->stream) != hipSuccess)
+        return APTGPU_ERR_HIP;
+    *n_sync = r.n_sync;
+    size_t take = r.n_sync < cap ? r.n_sync : cap;
+    if (!plan->sync || !pos || take == 0) return APTGPU_OK;
+    if (take > plan->slots[i].peaks.count) take = plan->slots[i].peaks.count;
+    std::vector<uint32_t> tmp(take);
+    if (hipMemcpyAsync(tmp.data(), plan->slots[i].peaks.ptr, take * sizeof(uint32_t),
+                       hipMemcpyDeviceToHost, plan->stream) != hipSuccess ||
+        hipStreamSynchronize(plan->stream) != hipSuccess)
+        return APTGPU_ERR_HIP;
+    for (size_t k = 0; k < take; ++k) pos[k] = tmp[k];
+    return APTGPU_OK;
+}
+
+int aptgpu_plan_enable_timing(aptgpu_plan *plan, int on)
+{
+    if (!plan) return APTGPU_ERR_INVALID;
+    plan->timer.enable(on != 0);
+    return APTGPU_OK;
+}
+
+int aptgpu_plan_collect_timing(aptgpu_plan *plan, aptgpu_kernel_time *out, size_t cap, size_t *n_out)
+{
+    if (!plan || !n_out) return APTGPU_ERR_INVALID;
+    try {
+        (void)hipSetDevice(plan->device);
+        auto v = plan->timer.collect(plan->stream);
+        *n_out = v.size();
+        for (size_t i = 0; i < v.size() && i < cap && out; ++i) out[i] = v[i];
+        return APTGPU_OK;
+    } catch (const Error &) {
+        return APTGPU_ERR_HIP;
+    }
+}
+
+// ------------------------------------------------------------------ decode()
+int aptgpu_decode(const aptgpu_context *ctx_in, const aptgpu_settings *settings,
+                  const float *signal, size_t n, uint32_t input_rate_hz, int sync,
+                  float **rows_out, size_t *n_out, aptgpu_stats *stats, char *err, size_t err_cap)
+{
+    if (!settings || (!signal && n) || !rows_out || !n_out) {
+        put_err(err, err_cap, "null argument");
+        return APTGPU_ERR_INVALID;
+    }
+    *rows_out = nullptr;
+    *n_out = 0;
+    aptgpu_context ctx = ctx_in ? *ctx_in : default_ctx();
+    const bool steps = settings->export_wav != 0 && ctx.step != nullptr;
+
+    return guarded(err, err_cap, [&]() -> int {
+        const uint32_t work = settings->work_rate;
+        // decode.rs:59
+        step(&ctx, steps, "input", 0, signal, n, input_rate_hz);
+        // decode.rs:63
+        status(&ctx, 0.1f, "Resampling to " + std::to_string(work));
+
+        PlanPtr plan(apt::plan_create(&ctx, *settings, input_rate_hz, sync != 0, n, 1));
+        if (plan->spr == 0) throw Error{ErrorKind::Invalid, "work_rate too small"};
+        hipStream_t s = plan->stream;
+        const uint64_t w = plan->work_len_for(n);
+        aptgpu_plan::Slot &sl = plan->slots[0];
+
+        apt::DeviceBuffer<float> d_in, d_rows;
+        d_in.alloc(n + 16);
+        apt::hip_check(hipMemcpyAsync(d_in.ptr, signal, n * sizeof(float), hipMemcpyHostToDevice, s),
+                       "hipMemcpyAsync H2D");
+        const uint64_t out_cap =
+            sync ? static_cast<uint64_t>(plan->max_rows) * 2080u : plan->out_len_nosync(w) + 16;
+        d_rows.alloc(out_cap);
+
+        plan->enqueue(0, d_in.ptr, n, d_rows.ptr, out_cap, steps);
+
+        // dsp.rs:96 / :106 — the resample filter, then the resample steps
+        step(&ctx, steps, "resample_filter", 1, plan->taps_resample.data(),
+             plan->taps_resample.size(), 0);
+        if (w < 10ull * plan->spr) throw Error{ErrorKind::Internal, kTooShort};  // decode.rs:79-83
+        if (steps) {
+            if (plan->l > 1) {
+                // dsp.rs:281-285: expanded signal is empty unless export_resample_filtered
+                step(&ctx, steps, "resample_filtered", 0, nullptr, 0, input_rate_hz * plan->l);
+            }
+            apt::Signal r = download(sl.resampled.ptr, w, s);
+            step(&ctx, steps, "resample_decimated", 0, r.data(), r.size(), work);
+        }
+
+        status(&ctx, 0.4f, "Demodulating");  // decode.rs:87
+        if (steps) {
+            apt::Signal d = download(sl.demodulated.ptr, w, s);
+            step(&ctx, steps, "demodulation_result", 0, d.data(), d.size(), 0);
+        }
+        status(&ctx, 0.42f, "Filtering");  // decode.rs:93
+        apt::Signal filtered_host;
+        if (steps) {
+            step(&ctx, steps, "filter_filter", 1, plan->taps_lowpass.data(),
+                 plan->taps_lowpass.size(), 0);
+            filtered_host = download(sl.filtered.ptr, w, s);
+            step(&ctx, steps, "filter_result", 0, filtered_host.data(), filtered_host.size(), 0);
+        }
+
+        aptgpu_result res{};
+        if (sync) {
+            status(&ctx, 0.5f, "Syncing");  // decode.rs:107
+            if (!plan->work_is_multiple) throw Error{ErrorKind::Internal, kNotMultiple};
+            if (steps) {
+                apt::Signal c = download(sl.correlation.ptr, w - plan->n_sync_taps, s);
+                step(&ctx, steps, "sync_correlation", 0, c.data(), c.size(), 0);
+            }
+            if (aptgpu_plan_results(plan.get(), 1, &res) != APTGPU_OK)
+                throw Error{ErrorKind::Hip, "could not read the result record"};
+            if (res.n_sync < 5) throw Error{ErrorKind::Internal, kFewSync};  // decode.rs:112-118
+            if (steps) {
+                // "sync_result": the aligned rows at work_rate (decode.rs:150)
+                apt::DeviceBuffer<float> d_al;
+                d_al.alloc(static_cast<uint64_t>(res.n_rows) * plan->spr + 16);
+                apt::gpu::gather_rows(s, sl.filtered.ptr, sl.peaks.ptr, plan->d_results.ptr, plan->spr,
+                                      1, true, d_al.ptr, res.n_rows);
+                apt::Signal al = download(d_al.ptr, static_cast<uint64_t>(res.n_rows) * plan->spr, s);
+                step(&ctx, steps, "sync_result", 0, al.data(), al.size(), work);
+                status(&ctx, 0.90f, "Resampling to 4160");
+                // final resample_with_filter(NoFilter), l == 1 branch (dsp.rs:106-122)
+                const float one = 1.f;
+                step(&ctx, steps, "resample_filter", 1, &one, 1, 0);
+                apt::gpu::gather_rows(s, sl.filtered.ptr, sl.peaks.ptr, plan->d_results.ptr, plan->spr,
+                                      1, false, d_al.ptr, res.n_rows);
+                al = download(d_al.ptr, static_cast<uint64_t>(res.n_rows) * plan->spr, s);
+                step(&ctx, steps, "filter_filter", 1, &one, 1, 0);
+                step(&ctx, steps, "filter_result", 0, al.data(), al.size(), 0);
+                step(&ctx, steps, "resample_filtered", 0, al.data(), al.size(), work);
+            } else {
+                status(&ctx, 0.90f, "Resampling to 4160");  // decode.rs:154
+            }
+        } else {
+            status(&ctx, 0.5f, "Skipping Syncing");  // decode.rs:136
+            step(&ctx, steps, "sync_correlation", 0, nullptr, 0, work);  // decode.rs:139
+            if (aptgpu_plan_results(plan.get(), 1, &res) != APTGPU_OK)
+                throw Error{ErrorKind::Hip, "could not read the result record"};
+            if (steps) {
+                const uint64_t aligned = w / plan->spr * plan->spr;
+                step(&ctx, steps, "sync_result", 0, filtered_host.data(), aligned, work);
+            }
+            status(&ctx, 0.90f, "Resampling to 4160");
+        }
+        if (res.status != APTGPU_OK)
+            throw Error{ErrorKind::Internal, res.reason == 2 ? kFewSync
+                                             : res.reason == 3 ? kNotMultiple
+                                                               : kTooShort};
+
+        float *rows = host_alloc<float>(res.n_out);
+        if (res.n_out) {
+            if (hipMemcpyAsync(rows, d_rows.ptr, res.n_out * sizeof(float), hipMemcpyDeviceToHost,
+                               s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess) {
+                std::free(rows);
+                throw Error{ErrorKind::Hip, "D2H copy of the image rows failed"};
+            }
+        }
+        if (steps) step(&ctx, steps, "resample_decimated", 0, rows, res.n_out, apt::FINAL_RATE);
+        *rows_out = rows;
+        *n_out = res.n_out;
+        if (stats) {
+            stats->work_len = w;
+            stats->n_sync = res.n_sync;
+            stats->n_rows = res.n_rows;
+            stats->l = plan->l;
+            stats->m = plan->m;
+            stats->n_resample_taps = static_cast<uint32_t>(plan->taps_resample.size());
+            stats->n_lowpass_taps = static_cast<uint32_t>(plan->taps_lowpass.size());
+            stats->fused = plan->fused ? 1 : 0;
+            stats->orbit_path = 1;
+        }
+        return APTGPU_OK;
+    });
+}
+
+// ------------------------------------------------------------------ building blocks
+int aptgpu_filter_design(const aptgpu_filter *f, float **coeff_out, size_t *n_out)
+{
+    if (!f || !coeff_out || !n_out) return APTGPU_ERR_INVALID;
+    auto flt = apt::make_filter(f->kind, f->cutout_pi_rad, f->atten, f->delta_w_pi_rad);
+    if (!flt) return APTGPU_ERR_INVALID;
+    try {
+        apt::Signal c = flt->design();
+        float *p = host_alloc<float>(c.size());
+        std::memcpy(p, c.data(), c.size() * sizeof(float));
+        *coeff_out = p;
+        *n_out = c.size();
+        return APTGPU_OK;
+    } catch (...) {
+        return APTGPU_ERR_INVALID;
+    }
+}
+
+void aptgpu_filter_resample(aptgpu_filter *f, uint32_t input_rate_hz, uint32_t output_rate_hz)
+{
+    if (!f || f->kind == APTGPU_FILTER_NOFILTER) return;
+    auto flt = apt::make_filter(f->kind, f->cutout_pi_rad, f->atten, f->delta_w_pi_rad);
+    if (!flt) return;
+    flt->resample(apt::Rate::hz(input_rate_hz), apt::Rate::hz(output_rate_hz));
+    if (auto *lp = dynamic_cast<apt::Lowpass *>(flt.get())) {
+        f->cutout_pi_rad = lp->cutout.get_pi_rad();
+        f->delta_w_pi_rad = lp->delta_w.get_pi_rad();
+    } else if (auto *dc = dynamic_cast<apt::LowpassDcRemoval *>(flt.get())) {
+        f->cutout_pi_rad = dc->cutout.get_pi_rad();
+        f->delta_w_pi_rad = dc->delta_w.get_pi_rad();
+    }
+}
+
+int aptgpu_generate_sync_frame(uint32_t work_rate_hz, int8_t **frame_out, size_t *n_out, char *err,
+                               size_t err_cap)
+{
+    if (!frame_out || !n_out) return APTGPU_ERR_INVALID;
+    return guarded(err, err_cap, [&] {
+        std::vector<int8_t> g;
+        std::string msg;
+        if (!apt::generate_sync_frame(apt::Rate::hz(work_rate_hz), &g, &msg))
+            throw Error{ErrorKind::Internal, msg};
+        int8_t *p = host_alloc<int8_t>(g.size());
+        std::memcpy(p, g.data(), g.size());
+        *frame_out = p;
+        *n_out = g.size();
+        return APTGPU_OK;
+    });
+}
+
+namespace {
+
+struct Scratch {
+    int device;
+    hipStream_t stream = nullptr;
+    bool own = false;
+    explicit Scratch(const aptgpu_context *ctx) : device(ctx ? ctx->device : 0)
+    {
+        apt::hip_check(hipSetDevice(device), "hipSetDevice");
+        if (ctx && ctx->stream) {
+            stream = static_cast<hipStream_t>(ctx->stream);
+        } else {
+            apt::hip_check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking),
+                           "hipStreamCreate");
+            own = true;
+        }
+    }
+    ~Scratch()
+    {
+        if (own && stream) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipStreamDestroy(stream);
+        }
+    }
+    apt::DeviceBuffer<float> upload(const float *h, size_t n, size_t pad = 16)
+    {
+        apt::DeviceBuffer<float> d;
+        d.alloc(n + pad);
+        if (n)
+            apt::hip_check(hipMemcpyAsync(d.ptr, h, n * sizeof(float), hipMemcpyHostToDevice, stream),
+                           "hipMemcpyAsync H2D");
+        return d;
+    }
+    float *download_malloc(const float *d, size_t n)
+    {
+        float *p = host_alloc<float>(n);
+        if (n) {
+            if (hipMemcpyAsync(p, d, n * sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                hipStreamSynchronize(stream) != hipSuccess) {
+                std::free(p);
+                throw Error{ErrorKind::Hip, "D2H copy failed"};
+            }
+        }
+        return p;
+    }
+};
+
+// resample_with_filter, dsp.rs:62-126, on host buffers.
+int resample_with_filter_impl(const aptgpu_context *ctx, const float *signal, size_t n,
+                              uint32_t in_hz, uint32_t out_hz, apt::Filter &filt, float **out,
+                              size_t *n_out)
+{
+    if (out_hz == 0) throw Error{ErrorKind::Internal, "Can't resample to 0Hz"};
+    if (in_hz == 0) throw Error{ErrorKind::Invalid, "input_rate is 0"};
+    const apt::Rate in_rate = apt::Rate::hz(in_hz), out_rate = apt::Rate::hz(out_hz);
+    const apt::LM lm = apt::interpolation_factors(in_rate, out_rate);
+    Scratch sc(ctx);
+    if (lm.l > 1) {
+        apt::Rate interpolated{};
+        if (!in_rate.checked_mul(lm.l, &interpolated)) {
+            char buf[512];
+            std::snprintf(buf, sizeof buf,
+                          "Can't resample, looks like the sample rates do not have a big\n"
+                          "                divisor in common. input_rate: %u, output_rate: %u, "
+                          "l: %u, m: %u",
+                          in_hz, out_hz, lm.l, lm.m);
+            throw Error{ErrorKind::RateOverflow, buf};
+        }
+        filt.resample(in_rate, interpolated);
+        const apt::Signal coeff = filt.design();
+        const uint64_t w = apt::fast_resampling_len(n, lm.l, lm.m, coeff.size());
+        auto d_x = sc.upload(signal, n);
+        auto d_c = sc.upload(coeff.data(), coeff.size());
+        apt::DeviceBuffer<float> d_y;
+        d_y.alloc(w + 16);
+        apt::gpu::resample_generic(sc.stream, d_x.ptr, n, d_c.ptr,
+                                   static_cast<uint32_t>(coeff.size()), lm.l, lm.m, d_y.ptr, w);
+        *out = sc.download_malloc(d_y.ptr, w);
+        *n_out = w;
+    } else {
+        const apt::Signal coeff = filt.design();
+        const uint64_t w = n / lm.m;
+        auto d_x = sc.upload(signal, n);
+        auto d_c = sc.upload(coeff.data(), coeff.size());
+        apt::DeviceBuffer<float> d_y;
+        d_y.alloc(w + 16);
+        apt::gpu::fir_decimate(sc.stream, d_x.ptr, n, d_c.ptr, static_cast<uint32_t>(coeff.size()),
+                               lm.m, d_y.ptr, w);
+        *out = sc.download_malloc(d_y.ptr, w);
+        *n_out = w;
+    }
+    return APTGPU_OK;
+}
+
+}  // namespace
+
+int aptgpu_resample_with_filter(const aptgpu_context *ctx, const float *signal, size_t n,
+                                uint32_t input_rate_hz, uint32_t output_rate_hz,
+                                aptgpu_filter filt, float **out, size_t *n_out, char *err,
+                                size_t err_cap)
+{
+    if ((!signal && n) || !out || !n_out) return APTGPU_ERR_INVALID;
+    return guarded(err, err_cap, [&] {
+        auto f = apt::make_filter(filt.kind, filt.cutout_pi_rad, filt.atten, filt.delta_w_pi_rad);
+        if (!f) throw Error{ErrorKind::Invalid, "unknown filter kind"};
+        return resample_with_filter_impl(ctx, signal, n, input_rate_hz, output_rate_hz, *f, out,
+                                         n_out);
+    });
+}
+
+int aptgpu_resample(const aptgpu_context *ctx, const float *signal, size_t n,
+                    uint32_t input_rate_hz, uint32_t output_rate_hz, float atten,
+                    float delta_w_pi_rad, float **out, size_t *n_out, char *err, size_t err_cap)
+{
+    if ((!signal && n) || !out || !n_out) return APTGPU_ERR_INVALID;
+    return guarded(err, err_cap, [&] {
+        if (input_rate_hz == 0) throw Error{ErrorKind::Invalid, "input_rate is 0"};
+        const apt::Rate in_rate = apt::Rate::hz(input_rate_hz);
+        // dsp.rs:140-150
+        const apt::Freq cutout =
+            output_rate_hz > input_rate_hz
+                ? apt::Freq::hz(static_cast<float>(input_rate_hz) / 2.f, in_rate)
+                : apt::Freq::hz(static_cast<float>(output_rate_hz) / 2.f, in_rate);
+        apt::Lowpass f(cutout, atten, apt::Freq::pi_rad(delta_w_pi_rad));
+        return resample_with_filter_impl(ctx, signal, n, input_rate_hz, output_rate_hz, f, out, n_out);
+    });
+}
+
+int aptgpu_demodulate(const aptgpu_context *ctx, const float *signal, size_t n,
+                      float carrier_pi_rad, float **out, char *err, size_t err_cap)
+{
+    if ((!signal && n) || !out) return APTGPU_ERR_INVALID;
+    return guarded(err, err_cap, [&] {
+        if (n == 0) throw Error{ErrorKind::Invalid, "empty signal (the reference panics)"};
+        Scratch sc(ctx);
+        const float phi = 2.f * apt::Freq::pi_rad(carrier_pi_rad).get_rad();  // dsp.rs:360
+        auto d_x = sc.upload(signal, n);
+        apt::DeviceBuffer<float> d_y;
+        d_y.alloc(n + 16);
+        apt::gpu::demodulate(sc.stream, d_x.ptr, n, cosf(phi) * 2.f, sinf(phi), d_y.ptr);
+        *out = sc.download_malloc(d_y.ptr, n);
+        return APTGPU_OK;
+    });
+}
+
+int aptgpu_filter_signal(const aptgpu_context *ctx, const float *signal, size_t n,
+                         aptgpu_filter filt, float **out, char *err, size_t err_cap)
+{
+    if ((!signal && n) || !out) return APTGPU_ERR_INVALID;
+    return guarded(err, err_cap, [&] {
+        auto f = apt::make_filter(filt.kind, filt.cutout_pi_rad, filt.atten, filt.delta_w_pi_rad);
+        if (!f) throw Error{ErrorKind::Invalid, "unknown filter kind"};
+        const apt::Signal coeff = f->design();
+        Scratch sc(ctx);
+        auto d_x = sc.upload(signal, n);
+        auto d_c = sc.upload(coeff.data(), coeff.size());
+        apt::DeviceBuffer<float> d_y;
+        d_y.alloc(n + 16);
+        apt::gpu::fir_decimate(sc.stream, d_x.ptr, n, d_c.ptr, static_cast<uint32_t>(coeff.size()), 1,
+                               d_y.ptr, n);
+        *out = sc.download_malloc(d_y.ptr, n);
+        return APTGPU_OK;
+    });
+}
+
+int aptgpu_find_sync(const aptgpu_context *ctx, const float *signal, size_t n,
+                     uint32_t work_rate_hz, uint64_t **pos_out, size_t *n_pos,
+                     float **correlation_out, size_t *n_corr_out, char *err, size_t err_cap)
+{
+    if ((!signal && n) || !pos_out || !n_pos) return APTGPU_ERR_INVALID;
+    return guarded(err, err_cap, [&] {
+        if (work_rate_hz % apt::FINAL_RATE != 0) throw Error{ErrorKind::Internal, kNotMultiple};
+        const uint32_t pw = work_rate_hz / apt::FINAL_RATE;
+        const uint64_t spr64 = static_cast<uint64_t>(apt::PX_PER_ROW) * work_rate_hz / apt::FINAL_RATE;
+        const uint32_t spr = static_cast<uint32_t>(spr64);
+        const uint32_t md = static_cast<uint32_t>(static_cast<uint64_t>(spr) * 8 / 10);
+        const uint32_t g = 38 * pw;
+        if (pw == 0 || n < g)
+            throw Error{ErrorKind::Invalid, "signal shorter than the sync frame (the reference panics)"};
+        if (static_cast<uint64_t>(md) * 8 > 160u * 1024u)
+            throw Error{ErrorKind::Unsupported, "work_rate too large for the sync search (LDS)"};
+        const uint64_t n_corr = n - g;
+        Scratch sc(ctx);
+        auto d_f = sc.upload(signal, n);
+        apt::DeviceBuffer<float> d_c;
+        d_c.alloc(n_corr + 64);
+        apt::DeviceBuffer<uint64_t> d_bits;
+        d_bits.alloc(n_corr / 64 + md / 64 + 4);
+        const uint32_t cap = static_cast<uint32_t>(n / spr + 4);
+        apt::DeviceBuffer<uint32_t> d_peaks;
+        d_peaks.alloc(cap);
+        apt::DeviceBuffer<apt::gpu::Result> d_res;
+        d_res.alloc(1);
+        apt::gpu::correlate(sc.stream, d_f.ptr, n_corr, pw, d_c.ptr);
+        apt::gpu::terminals(sc.stream, d_c.ptr, n_corr, md, d_bits.ptr);
+        apt::gpu::orbit_walk(sc.stream, d_bits.ptr, n_corr, n, spr, md, d_peaks.ptr, cap, d_res.ptr);
+        apt::gpu::Result r{};
+        apt::hip_check(hipMemcpyAsync(&r, d_res.ptr, sizeof r, hipMemcpyDeviceToHost, sc.stream),
+                       "hipMemcpyAsync");
+        apt::hip_check(hipStreamSynchronize(sc.stream), "hipStreamSynchronize");
+        std::vector<uint32_t> tmp(r.n_sync);
+        if (r.n_sync)
+            apt::hip_check(hipMemcpy(tmp.data(), d_peaks.ptr, r.n_sync * sizeof(uint32_t),
+                                     hipMemcpyDeviceToHost),
+                           "hipMemcpy peaks");
+        uint64_t *pos = host_alloc<uint64_t>(r.n_sync);
+        for (size_t k = 0; k < r.n_sync; ++k) pos[k] = tmp[k];
+        *pos_out = pos;
+        *n_pos = r.n_sync;
+        if (correlation_out) {
+            *correlation_out = sc.download_malloc(d_c.ptr, n_corr);
+            if (n_corr_out) *n_corr_out = n_corr;
+        }
+        return APTGPU_OK;
+    });
+}
+
+}  // extern "C"

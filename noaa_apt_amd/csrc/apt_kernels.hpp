@@ -1,0 +1,49 @@
+// apt_kernels.hpp — launch wrappers of the gfx950 kernels (definitions in
+// apt_kernels_generic.hip and apt_kernels_fused.hip).  All launches are
+// asynchronous on the given stream and never synchronise with the host.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace apt::gpu {
+
+// Device-side result record == aptgpu_result (include/aptgpu.h).
+struct Result {
+    int32_t status;
+    int32_t reason;
+    uint32_t n_rows;
+    uint32_t n_sync;
+    uint64_t work_len;
+    uint64_t n_out;
+};
+
+// ---- generic kernels (any l, m, tap count) --------------------------------------
+// fast_resampling, dsp.rs:186-289: out[k], k < w
+void resample_generic(hipStream_t s, const float *x, uint64_t n, const float *coeff,
+                      uint32_t ntaps, uint32_t l, uint32_t m, float *out, uint64_t w);
+// filter() followed by decimate(m), dsp.rs:386-410 + 294-307: out[k] = filter(x)[k*m]
+void fir_decimate(hipStream_t s, const float *x, uint64_t n, const float *coeff, uint32_t ntaps,
+                  uint32_t m, float *out, uint64_t n_out);
+// demodulate, dsp.rs:350-383
+void demodulate(hipStream_t s, const float *x, uint64_t n, float cosphi2, float sinphi, float *out);
+// the cross-correlation of find_sync, decode.rs:225-233 (pw = work_rate / 4160)
+void correlate(hipStream_t s, const float *f, uint64_t n_corr, uint32_t pw, float *corr);
+// terminal flags of the peak picker: bit i of `bits` set <=> no corr[j] > corr[i] for
+// j in (i, i+md]; corr[0] is clamped to >= 0 (the initial (0, 0.) peak, decode.rs:208).
+// md must be a multiple of 64; needs 2*md*4 bytes of LDS.
+void terminals(hipStream_t s, const float *corr, uint64_t n_corr, uint32_t md, uint64_t *bits);
+// the orbit of the peak picker over the terminal bitmask (one wave): writes the peak list
+// (find_sync's return value) and fills the result record.
+void orbit_walk(hipStream_t s, const uint64_t *bits, uint64_t n_corr, uint64_t work_len,
+                uint32_t spr, uint32_t md, uint32_t *peaks, uint32_t peaks_cap, Result *res);
+// row gather (decode.rs:120-134) taking every pw-th sample; raw = plain copy (the
+// "sync_result" step), !raw = through the final NoFilter stage (decode.rs:158-159)
+void gather_rows(hipStream_t s, const float *f, const uint32_t *peaks, const Result *res,
+                 uint32_t spr, uint32_t pw, bool raw, float *rows, uint32_t rows_cap);
+
+// writes a result record from the host's knowledge (too-short recording, no-sync path)
+void set_result(hipStream_t s, Result *res, Result value);
+
+}  // namespace apt::gpu

@@ -1,0 +1,389 @@
+// apt_kernels_generic.hip — gfx950 kernels for ANY (l, m, tap-count) combination.
+//
+// One thread per output, reference summation order, every product and sum rounded
+// separately (__fmul_rn/__fadd_rn are never contracted into FMAs), so each kernel is
+// bit-identical to the reference loop it cites.  These are the fallback / A-B baseline
+// for the fused specialised kernels in apt_kernels_fused.hip, and the path used when
+// the caller asks for the intermediate "steps" (Context::step).
+#include "apt_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+namespace apt::gpu {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline unsigned grid_for(uint64_t n, unsigned block, unsigned cap = 256u * 32u)
+{
+    uint64_t g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g == 0) g = 1;
+    return static_cast<unsigned>(g);
+}
+
+// ---------------------------------------------------------------------------------
+// fast_resampling (dsp.rs:186-289) in polyphase closed form.
+// Output k sits at t = off + k*m on the interpolated axis; its window holds input
+// samples x0, x0+1, ... with x0 = ceil(k*m / l), multiplied by coeff[p + i*l],
+// p = x0*l - k*m, while p + i*l <= 2*off; inputs at or beyond n are skipped (:257).
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_resample_generic(const float *__restrict__ x, uint64_t n, const float *__restrict__ coeff,
+                   uint32_t jlim, uint32_t l, uint32_t m, float *__restrict__ out, uint64_t w)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t k = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < w;
+         k += stride) {
+        const uint64_t km = k * m;
+        uint64_t xi = (km + l - 1) / l;
+        const uint32_t p = static_cast<uint32_t>(xi * l - km);
+        float sum = 0.f;
+        for (uint32_t j = p; j < jlim; j += l, ++xi) {
+            if (xi < n) sum = __fadd_rn(sum, __fmul_rn(coeff[j], x[xi]));
+        }
+        out[k] = sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// filter (dsp.rs:386-410) evaluated only at i = k*m (decimate, dsp.rs:294-307):
+// out[k] = sum_{j < ntaps, j < i} x[i-j]*h[j], ascending j.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_fir_decimate(const float *__restrict__ x, const float *__restrict__ h, uint32_t ntaps,
+               uint32_t m, float *__restrict__ out, uint64_t n_out)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t k = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n_out;
+         k += stride) {
+        const uint64_t i = k * m;
+        const uint32_t jn = i < ntaps ? static_cast<uint32_t>(i) : ntaps;
+        float sum = 0.f;
+        for (uint32_t j = 0; j < jn; ++j) sum = __fadd_rn(sum, __fmul_rn(x[i - j], h[j]));
+        out[k] = sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// demodulate (dsp.rs:350-383): y[0] = 0,
+// y[i] = sqrt(x[i-1]^2 + x[i]^2 - x[i-1]*x[i]*cosphi2) / sinphi  in exactly that order.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float demod_pair(float prev, float curr, float cosphi2, float sinphi)
+{
+    const float a = __fadd_rn(__fmul_rn(prev, prev), __fmul_rn(curr, curr));
+    const float b = __fmul_rn(__fmul_rn(prev, curr), cosphi2);
+    return __fdiv_rn(__fsqrt_rn(__fsub_rn(a, b)), sinphi);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_demodulate(const float *__restrict__ x, uint64_t n, float cosphi2, float sinphi,
+             float *__restrict__ y)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+         i += stride) {
+        y[i] = (i == 0) ? 0.f : demod_pair(x[i - 1], x[i], cosphi2, sinphi);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// cross-correlation with the +-1 sync template (decode.rs:225-233), sequential adds
+// from 0.0 in template order: 2pw x (-), 7 x [2pw x (-), 2pw x (+)], 8pw x (-).
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_correlate(const float *__restrict__ f, uint64_t n_corr, uint32_t pw, float *__restrict__ corr)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    const uint32_t pulse = 2 * pw;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_corr;
+         i += stride) {
+        const float *p = f + i;
+        float c = 0.f;
+        for (uint32_t j = 0; j < pulse; ++j) c = __fsub_rn(c, *p++);
+        for (int rep = 0; rep < 7; ++rep) {
+            for (uint32_t j = 0; j < pulse; ++j) c = __fsub_rn(c, *p++);
+            for (uint32_t j = 0; j < pulse; ++j) c = __fadd_rn(c, *p++);
+        }
+        for (uint32_t j = 0; j < 8 * pw; ++j) c = __fsub_rn(c, *p++);
+        corr[i] = c;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Terminal flags for the peak picker of find_sync (decode.rs:239-253).
+//
+// The reference's picker keeps (idx, val) of the last peak; while i - idx <= md it
+// replaces the peak whenever corr[i] > val.  A tracking phase that starts at s therefore
+// climbs the chain of strict prefix maxima until no larger value exists within md samples:
+// it stops on the first "terminal" at or after s, where
+//     T[i]  <=>  no j in (i, i+md] (j < n_corr) has corr[j] > corr[i].
+// (The chain can never step over a terminal t: the record it would land on lies in t's
+// window, so it would have to be <= corr[t] <= the value it exceeds.)
+// corr[0] is clamped to max(corr[0], 0) because the picker starts from the peak (0, 0.).
+//
+// One workgroup per chunk of md positions: sliding-window max by the two-block method
+// (suffix max of the chunk, prefix max of the following md samples), block-wide scans
+// in LDS, 64 flags per wave packed by ballot.
+// ---------------------------------------------------------------------------------
+constexpr int kTermThreads = 1024;
+constexpr float kNegInf = -__builtin_huge_valf();
+
+// In-place inclusive max-scan of a[0..n) in LDS by the whole workgroup; `reverse` scans
+// from the end (suffix max).  Strips of `per` contiguous elements per thread.
+__device__ void block_scan_max(float *a, int n, bool reverse, float *wave_tot)
+{
+    const int tid = threadIdx.x;
+    const int per = (n + kTermThreads - 1) / kTermThreads;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    // logical index q in scan order -> physical index
+    auto phys = [&](int q) { return reverse ? (n - 1 - q) : q; };
+
+    const int q0 = tid * per;
+    float run = kNegInf;
+    for (int e = 0; e < per; ++e) {
+        const int q = q0 + e;
+        if (q < n) {
+            run = fmaxf(run, a[phys(q)]);
+            a[phys(q)] = run;
+        }
+    }
+    // exclusive prefix of strip totals across the workgroup
+    float inc = run;
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc = fmaxf(inc, o);
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    float carry = kNegInf;
+    for (int wv = 0; wv < wave; ++wv) carry = fmaxf(carry, wave_tot[wv]);
+    const float up = __shfl_up(inc, 1, 64);
+    if (lane > 0) carry = fmaxf(carry, up);
+    for (int e = 0; e < per; ++e) {
+        const int q = q0 + e;
+        if (q < n) a[phys(q)] = fmaxf(a[phys(q)], carry);
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kTermThreads)
+k_terminals(const float *__restrict__ corr, uint64_t n_corr, uint32_t md,
+            uint64_t *__restrict__ bits)
+{
+    extern __shared__ float lds[];
+    float *own = lds;        // corr[b0 .. b0+md), later its suffix max
+    float *nxt = lds + md;   // corr[b0+md .. b0+2md), later its prefix max
+    __shared__ float wave_tot[kTermThreads / 64];
+
+    const uint64_t b0 = static_cast<uint64_t>(blockIdx.x) * md;
+    for (uint32_t i = threadIdx.x; i < 2 * md; i += kTermThreads) {
+        const uint64_t g = b0 + i;
+        float v = kNegInf;
+        if (g < n_corr) {
+            v = corr[g];
+            if (g == 0 && !(v > 0.f)) v = 0.f;
+        }
+        lds[i] = v;
+    }
+    __syncthreads();
+
+    block_scan_max(own, md, /*reverse=*/true, wave_tot);
+    block_scan_max(nxt, md, /*reverse=*/false, wave_tot);
+
+    // thread t handles positions t, t+1024, ...: a wave covers 64 consecutive flags
+    const int iters = (md + kTermThreads - 1) / kTermThreads;
+    for (int it = 0; it < iters; ++it) {
+        const uint32_t i = it * kTermThreads + threadIdx.x;
+        bool term = false;
+        if (i < md && b0 + i < n_corr) {
+            float v = corr[b0 + i];  // the scan overwrote own[]; L2-hot re-read
+            if (b0 + i == 0 && !(v > 0.f)) v = 0.f;
+            // window (i, i+md] = own[i+1 .. md) U nxt[0 .. i]
+            const float wmax = fmaxf((i + 1 < md) ? own[i + 1] : kNegInf, nxt[i]);
+            term = !(wmax > v);
+        }
+        const unsigned long long word = __ballot(term);
+        if ((threadIdx.x & 63) == 0 && i < md) bits[(b0 + i) >> 6] = word;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// The orbit of the peak picker, one wave.
+//   peaks = [firstT(0)]; len = 1
+//   loop: s = max(last + md + 1, (len+1)*spr); stop if s >= n_corr
+//         c = s / spr; push s (c - len - 1) times; push firstT(s); len = c
+// where firstT(s) = first terminal >= s, found by a 64-word-wide scan of the bitmask.
+// This is decode.rs:239-253 verbatim once tracking phases are replaced by firstT().
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t first_terminal(const uint64_t *__restrict__ bits,
+                                                   uint64_t n_words, uint64_t s)
+{
+    const int lane = threadIdx.x & 63;
+    uint64_t w0 = s >> 6;
+    const uint32_t sh = static_cast<uint32_t>(s & 63);
+    bool first = true;
+    while (true) {
+        const uint64_t wi = w0 + lane;
+        uint64_t word = (wi < n_words) ? bits[wi] : 0ull;
+        if (first && lane == 0) word &= (~0ull) << sh;
+        const unsigned long long any = __ballot(word != 0ull);
+        if (any) {
+            const int src = __ffsll(static_cast<long long>(any)) - 1;
+            const uint64_t pos = wi * 64 + (__ffsll(static_cast<long long>(word)) - 1);
+            return __shfl(pos, src, 64);
+        }
+        first = false;
+        w0 += 64;
+        if (w0 >= n_words) return ~0ull;  // cannot happen: position n_corr-1 is a terminal
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_orbit_walk(const uint64_t *__restrict__ bits, uint64_t n_corr, uint64_t work_len, uint32_t spr,
+             uint32_t md, uint32_t *__restrict__ peaks, uint32_t peaks_cap,
+             Result *__restrict__ res)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t n_words = (n_corr + 63) >> 6;
+    uint64_t len = 1;
+    uint64_t u = 0;
+    if (n_corr > 0) u = first_terminal(bits, n_words, 0);
+    if (lane == 0 && peaks_cap > 0) peaks[0] = static_cast<uint32_t>(u);
+    // Rows are peaks[0 .. len-1) whose row fits strictly inside the signal
+    // (decode.rs:125-132).  Positions never decrease, so the rows kept are a prefix;
+    // count them as we go and take the last peak back out at the end.
+    uint64_t fit = (u + spr < work_len) ? 1 : 0;
+    uint64_t last_fit = fit;
+    while (n_corr > 0) {
+        const uint64_t a = u + md + 1;
+        const uint64_t b = (len + 1) * spr;
+        const uint64_t s = a > b ? a : b;
+        if (s >= n_corr) break;
+        const uint64_t c = s / spr;
+        for (uint64_t q = len + lane; q + 1 < c; q += 64)
+            if (q < peaks_cap) peaks[q] = static_cast<uint32_t>(s);
+        if (s + spr < work_len) fit += c - len - 1;
+        u = first_terminal(bits, n_words, s);
+        if (lane == 0 && c - 1 < peaks_cap) peaks[c - 1] = static_cast<uint32_t>(u);
+        last_fit = (u + spr < work_len) ? 1 : 0;
+        fit += last_fit;
+        len = c;
+    }
+    if (lane == 0) {
+        res->n_sync = static_cast<uint32_t>(len);
+        res->n_rows = static_cast<uint32_t>(fit - last_fit);
+        res->work_len = work_len;
+        res->n_out = (fit - last_fit) * 2080u;
+        if (len < 5) {  // decode.rs:112-118
+            res->status = 1;
+            res->reason = 2;
+            res->n_rows = 0;
+            res->n_out = 0;
+        } else {
+            res->status = 0;
+            res->reason = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Row gather (decode.rs:120-134) fused with the final resample_with_filter(NoFilter)
+// to 4160 Hz (decode.rs:158-159 -> filter([1.]) + decimate(pw), dsp.rs:106-116):
+//   px[r*2080 + c] = 0.0 + F[peaks[r] + pw*c] * 1.0,  and px[0] = 0 (the `i > j` guard).
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_gather_rows(const float *__restrict__ f, const uint32_t *__restrict__ peaks,
+              const Result *__restrict__ res, uint32_t spr, uint32_t pw, int raw,
+              float *__restrict__ rows, uint32_t rows_cap)
+{
+    uint32_t n_rows = res->n_rows;
+    if (n_rows > rows_cap) n_rows = rows_cap;
+    const uint32_t px_per_row = spr / pw;  // 2080 when pw = work_rate / 4160
+    for (uint32_t r = blockIdx.y; r < n_rows; r += gridDim.y) {
+        const float *src = f + peaks[r];
+        for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < px_per_row;
+             c += gridDim.x * blockDim.x) {
+            float v = src[static_cast<uint64_t>(c) * pw];
+            if (!raw) {  // filter([1.]): sum = 0.0 + x*1.0, and nothing at all for i == 0
+                v = __fadd_rn(0.f, __fmul_rn(v, 1.f));
+                if (r == 0 && c == 0) v = 0.f;
+            }
+            rows[static_cast<uint64_t>(r) * px_per_row + c] = v;
+        }
+    }
+}
+
+__global__ void k_set_result(Result *res, Result value) { *res = value; }
+
+}  // namespace
+
+void set_result(hipStream_t s, Result *res, Result value)
+{
+    hipLaunchKernelGGL(k_set_result, dim3(1), dim3(1), 0, s, res, value);
+}
+
+void resample_generic(hipStream_t s, const float *x, uint64_t n, const float *coeff,
+                      uint32_t ntaps, uint32_t l, uint32_t m, float *out, uint64_t w)
+{
+    if (w == 0) return;
+    const uint32_t jlim = 2 * ((ntaps - 1) / 2) + 1;  // n <= t + offset  <=>  j <= 2*offset
+    hipLaunchKernelGGL(k_resample_generic, dim3(grid_for(w, kBlock)), dim3(kBlock), 0, s, x, n,
+                       coeff, jlim, l, m, out, w);
+}
+
+void fir_decimate(hipStream_t s, const float *x, uint64_t /*n*/, const float *coeff,
+                  uint32_t ntaps, uint32_t m, float *out, uint64_t n_out)
+{
+    if (n_out == 0) return;
+    hipLaunchKernelGGL(k_fir_decimate, dim3(grid_for(n_out, kBlock)), dim3(kBlock), 0, s, x, coeff,
+                       ntaps, m, out, n_out);
+}
+
+void demodulate(hipStream_t s, const float *x, uint64_t n, float cosphi2, float sinphi, float *out)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_demodulate, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, x, n, cosphi2,
+                       sinphi, out);
+}
+
+void correlate(hipStream_t s, const float *f, uint64_t n_corr, uint32_t pw, float *corr)
+{
+    if (n_corr == 0) return;
+    hipLaunchKernelGGL(k_correlate, dim3(grid_for(n_corr, kBlock)), dim3(kBlock), 0, s, f, n_corr,
+                       pw, corr);
+}
+
+void terminals(hipStream_t s, const float *corr, uint64_t n_corr, uint32_t md, uint64_t *bits)
+{
+    if (n_corr == 0) return;
+    const unsigned blocks = static_cast<unsigned>((n_corr + md - 1) / md);
+    const size_t lds = static_cast<size_t>(2) * md * sizeof(float);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_terminals),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds));
+    hipLaunchKernelGGL(k_terminals, dim3(blocks), dim3(kTermThreads), lds, s, corr, n_corr, md,
+                       bits);
+}
+
+void orbit_walk(hipStream_t s, const uint64_t *bits, uint64_t n_corr, uint64_t work_len,
+                uint32_t spr, uint32_t md, uint32_t *peaks, uint32_t peaks_cap, Result *res)
+{
+    hipLaunchKernelGGL(k_orbit_walk, dim3(1), dim3(64), 0, s, bits, n_corr, work_len, spr, md,
+                       peaks, peaks_cap, res);
+}
+
+void gather_rows(hipStream_t s, const float *f, const uint32_t *peaks, const Result *res,
+                 uint32_t spr, uint32_t pw, bool raw, float *rows, uint32_t rows_cap)
+{
+    if (rows_cap == 0) return;
+    const unsigned gy = rows_cap < 4096u ? rows_cap : 4096u;
+    const unsigned gx = (spr / pw + 4 * kBlock - 1) / (4 * kBlock);
+    hipLaunchKernelGGL(k_gather_rows, dim3(gx ? gx : 1, gy), dim3(kBlock), 0, s, f, peaks, res, spr,
+                       pw, raw ? 1 : 0, rows, rows_cap);
+}
+
+}  // namespace apt::gpu

@@ -1,0 +1,306 @@
+// apt_plan.hip — plan construction (host-side design, HBM workspace) and the
+// kernel pipeline of decode() (reference: src/decode.rs:43-162).
+#include "apt_plan.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace apt {
+
+void hip_check(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) {
+        throw Error{ErrorKind::Hip, std::string(what) + ": " + hipGetErrorString(e)};
+    }
+}
+
+// ---------------------------------------------------------------- KernelTimer
+KernelTimer::~KernelTimer()
+{
+    for (auto &p : pairs_) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
+    for (auto e : pool_) (void)hipEventDestroy(e);
+}
+
+void KernelTimer::enable(bool on) { on_ = on; }
+
+hipEvent_t KernelTimer::take()
+{
+    if (!pool_.empty()) {
+        hipEvent_t e = pool_.back();
+        pool_.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hip_check(hipEventCreate(&e), "hipEventCreate");
+    return e;
+}
+
+void KernelTimer::begin(hipStream_t s, const char *name)
+{
+    if (!on_) return;
+    Pair p{name, take(), take()};
+    hip_check(hipEventRecord(p.a, s), "hipEventRecord");
+    pairs_.push_back(p);
+}
+
+void KernelTimer::end(hipStream_t s)
+{
+    if (!on_) return;
+    hip_check(hipEventRecord(pairs_.back().b, s), "hipEventRecord");
+}
+
+std::vector<aptgpu_kernel_time> KernelTimer::collect(hipStream_t s)
+{
+    hip_check(hipStreamSynchronize(s), "hipStreamSynchronize");
+    std::vector<aptgpu_kernel_time> out;
+    for (auto &p : pairs_) {
+        float ms = 0.f;
+        hip_check(hipEventElapsedTime(&ms, p.a, p.b), "hipEventElapsedTime");
+        aptgpu_kernel_time *slot = nullptr;
+        for (auto &o : out)
+            if (std::strcmp(o.name, p.name) == 0) slot = &o;
+        if (!slot) {
+            aptgpu_kernel_time t{};
+            std::snprintf(t.name, sizeof t.name, "%s", p.name);
+            out.push_back(t);
+            slot = &out.back();
+        }
+        slot->avg_ms += ms;
+        slot->launches += 1;
+        pool_.push_back(p.a);
+        pool_.push_back(p.b);
+    }
+    pairs_.clear();
+    for (auto &o : out)
+        if (o.launches) o.avg_ms /= static_cast<double>(o.launches);
+    return out;
+}
+
+// ---------------------------------------------------------------- plan_create
+aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &settings,
+                         uint32_t input_rate, bool sync, size_t max_samples, int max_batch)
+{
+    if (settings.export_resample_filtered)
+        throw Error{ErrorKind::Unsupported,
+                    "export_resample_filtered is not available on the GPU path"};
+    if (input_rate == 0) throw Error{ErrorKind::Invalid, "input_rate is 0"};
+    if (max_batch < 1) max_batch = 1;
+
+    auto plan = std::make_unique<aptgpu_plan>();
+    plan->device = ctx ? ctx->device : 0;
+    plan->mode = ctx ? ctx->mode : APTGPU_MODE_STRICT;
+    plan->settings = settings;
+    plan->input_rate = input_rate;
+    plan->sync = sync;
+    plan->max_samples = max_samples;
+    plan->max_batch = max_batch;
+
+    // decode.rs:55 — u32 arithmetic; the reference would panic on overflow
+    const uint64_t spr64 = static_cast<uint64_t>(PX_PER_ROW) * settings.work_rate;
+    if (spr64 > 0xFFFFFFFFull) throw Error{ErrorKind::Invalid, "work_rate too large"};
+    plan->spr = static_cast<uint32_t>(spr64 / FINAL_RATE);
+
+    const Rate in_rate = Rate::hz(input_rate);
+    const Rate work_rate = Rate::hz(settings.work_rate);
+
+    // ---- first resample: decode.rs:65-77 -> dsp.rs:62-126
+    if (work_rate.get_hz() == 0) throw Error{ErrorKind::Internal, "Can't resample to 0Hz"};
+    LowpassDcRemoval f1(Freq::hz(settings.resample_cutout, in_rate), settings.resample_atten,
+                        Freq::hz(settings.resample_delta_freq, in_rate));
+    const LM lm = interpolation_factors(in_rate, work_rate);
+    plan->l = lm.l;
+    plan->m = lm.m;
+    if (lm.l > 1) {
+        Rate interpolated{};
+        if (!in_rate.checked_mul(lm.l, &interpolated)) {
+            char buf[512];
+            std::snprintf(buf, sizeof buf,
+                          "Can't resample, looks like the sample rates do not have a big\n"
+                          "                divisor in common. input_rate: %u, output_rate: %u, "
+                          "l: %u, m: %u",
+                          in_rate.get_hz(), work_rate.get_hz(), lm.l, lm.m);
+            throw Error{ErrorKind::RateOverflow, buf};
+        }
+        f1.resample(in_rate, interpolated);
+    }
+    plan->taps_resample = f1.design();
+
+    // ---- demodulation constants: decode.rs:89, dsp.rs:360-363 (phi = 2*get_rad())
+    const Freq carrier = Freq::hz(static_cast<float>(CARRIER_FREQ), work_rate);
+    const float phi = 2.f * carrier.get_rad();
+    plan->cosphi2 = cosf(phi) * 2.f;
+    plan->sinphi = sinf(phi);
+
+    // ---- low-pass: decode.rs:95-100
+    const Freq cutout = Freq::pi_rad(static_cast<float>(FINAL_RATE) /
+                                     static_cast<float>(work_rate.get_hz()));
+    Lowpass f2(cutout, settings.demodulation_atten, cutout / 5.f);
+    plan->taps_lowpass = f2.design();
+
+    // ---- sync geometry: decode.rs:204-216
+    plan->work_is_multiple = (work_rate.get_hz() % FINAL_RATE) == 0;
+    plan->pw = work_rate.get_hz() / FINAL_RATE;
+    plan->n_sync_taps = 38 * plan->pw;
+    plan->md = static_cast<uint32_t>(static_cast<uint64_t>(plan->spr) * 8 / 10);
+    if (sync && plan->work_is_multiple && static_cast<uint64_t>(plan->md) * 8 > 160u * 1024u)
+        throw Error{ErrorKind::Unsupported, "work_rate too large for the sync search (LDS)"};
+
+    // ---- final resample to 4160 Hz: decode.rs:158-159
+    const LM lm2 = interpolation_factors(work_rate, Rate::hz(FINAL_RATE));
+    plan->l2 = lm2.l;
+    plan->m2 = lm2.m;
+    if (lm2.l > 1) {
+        Rate tmp{};
+        if (!work_rate.checked_mul(lm2.l, &tmp)) {
+            char buf[512];
+            std::snprintf(buf, sizeof buf,
+                          "Can't resample, looks like the sample rates do not have a big\n"
+                          "                divisor in common. input_rate: %u, output_rate: %u, "
+                          "l: %u, m: %u",
+                          work_rate.get_hz(), FINAL_RATE, lm2.l, lm2.m);
+            throw Error{ErrorKind::RateOverflow, buf};
+        }
+    }
+
+    // ---- device side
+    hip_check(hipSetDevice(plan->device), "hipSetDevice");
+    if (ctx && ctx->stream) {
+        plan->stream = static_cast<hipStream_t>(ctx->stream);
+        plan->own_stream = false;
+    } else {
+        hip_check(hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking),
+                  "hipStreamCreate");
+        plan->own_stream = true;
+    }
+
+    plan->max_work_len = plan->work_len_for(max_samples);
+    const uint64_t rows = plan->spr ? plan->max_work_len / plan->spr + 2 : 2;
+    plan->max_rows = static_cast<uint32_t>(rows);
+
+    auto upload = [&](DeviceBuffer<float> &dst, const Signal &src) {
+        dst.alloc(src.size());
+        hip_check(hipMemcpy(dst.ptr, src.data(), src.size() * sizeof(float),
+                            hipMemcpyHostToDevice),
+                  "hipMemcpy taps");
+    };
+    upload(plan->d_taps_resample, plan->taps_resample);
+    upload(plan->d_taps_lowpass, plan->taps_lowpass);
+    upload(plan->d_one, Signal{1.f});
+
+    plan->slots.resize(static_cast<size_t>(max_batch));
+    const uint64_t w = plan->max_work_len;
+    for (auto &sl : plan->slots) {
+        sl.resampled.alloc(w + 64);
+        sl.demodulated.alloc(w + 64);
+        sl.filtered.alloc(w + 64);
+        if (sync) {
+            sl.correlation.alloc(w + 64);
+            sl.bits.alloc(w / 64 + plan->md / 64 + 4);
+            sl.peaks.alloc(plan->max_rows + 2);
+        }
+    }
+    plan->d_results.alloc(static_cast<size_t>(max_batch));
+    hip_check(hipMemset(plan->d_results.ptr, 0, sizeof(gpu::Result) * max_batch), "hipMemset");
+    return plan.release();
+}
+
+}  // namespace apt
+
+// ------------------------------------------------------------------ geometry
+uint64_t aptgpu_plan::work_len_for(uint64_t n) const
+{
+    if (l > 1) return apt::fast_resampling_len(n, l, m, taps_resample.size());
+    return n / m;  // decimate, dsp.rs:299-303
+}
+
+uint64_t aptgpu_plan::out_len_nosync(uint64_t work_len) const
+{
+    const uint64_t aligned = spr ? work_len / spr * spr : 0;  // decode.rs:142-147
+    if (l2 > 1) return apt::fast_resampling_len(aligned, l2, m2, 1);
+    return aligned / m2;
+}
+
+// ------------------------------------------------------------------ pipeline
+// The kernel sequence of decode() for one recording already in HBM.
+void aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows,
+                          uint64_t rows_cap_floats, bool /*keep_steps*/)
+{
+    using namespace apt::gpu;
+    Slot &sl = slots[static_cast<size_t>(i)];
+    Result *res = d_results.ptr + i;
+    const uint64_t w = work_len_for(n);
+
+    auto timed = [&](const char *name, auto &&launch) {
+        timer.begin(stream, name);
+        launch();
+        timer.end(stream);
+    };
+
+    // decode.rs:79-83 — fewer than 10 rows of samples
+    if (w < 10ull * spr) {
+        set_result(stream, res, Result{APTGPU_ERR_INTERNAL, 1, 0, 0, w, 0});
+        return;
+    }
+
+    // 1. resample to work_rate (dsp.rs:62-126)
+    if (l > 1) {
+        timed("resample_generic", [&] {
+            resample_generic(stream, d_signal, n, d_taps_resample.ptr,
+                             static_cast<uint32_t>(taps_resample.size()), l, m, sl.resampled.ptr, w);
+        });
+    } else {
+        timed("fir_decimate", [&] {
+            fir_decimate(stream, d_signal, n, d_taps_resample.ptr,
+                         static_cast<uint32_t>(taps_resample.size()), m, sl.resampled.ptr, w);
+        });
+    }
+    // 2. AM envelope (dsp.rs:350-383)
+    timed("demodulate",
+          [&] { demodulate(stream, sl.resampled.ptr, w, cosphi2, sinphi, sl.demodulated.ptr); });
+    // 3. low-pass (dsp.rs:386-410)
+    timed("lowpass", [&] {
+        fir_decimate(stream, sl.demodulated.ptr, w, d_taps_lowpass.ptr,
+                     static_cast<uint32_t>(taps_lowpass.size()), 1, sl.filtered.ptr, w);
+    });
+
+    if (sync && !work_is_multiple) {
+        // generate_sync_frame, decode.rs:172-176
+        set_result(stream, res, Result{APTGPU_ERR_INTERNAL, 3, 0, 0, w, 0});
+    } else if (sync) {
+        // 4. find_sync (decode.rs:204-263): correlation, terminal flags, orbit
+        const uint64_t n_corr = w - n_sync_taps;  // w >= 10*spr > 38*pw
+        timed("correlate", [&] { correlate(stream, sl.filtered.ptr, n_corr, pw, sl.correlation.ptr); });
+        timed("terminals", [&] { terminals(stream, sl.correlation.ptr, n_corr, md, sl.bits.ptr); });
+        timed("orbit_walk", [&] {
+            orbit_walk(stream, sl.bits.ptr, n_corr, w, spr, md, sl.peaks.ptr,
+                       static_cast<uint32_t>(sl.peaks.count), res);
+        });
+        // 5. aligned rows + final /pw (decode.rs:120-134,158-159)
+        uint64_t rows_cap = rows_cap_floats / 2080u;
+        if (rows_cap > max_rows) rows_cap = max_rows;
+        timed("gather_rows", [&] {
+            gather_rows(stream, sl.filtered.ptr, sl.peaks.ptr, res, spr, pw, false, d_rows,
+                        static_cast<uint32_t>(rows_cap));
+        });
+    } else {
+        // decode.rs:135-159 — crop to whole rows, resample_with_filter(NoFilter)
+        const uint64_t aligned = w / spr * spr;
+        uint64_t n_out = out_len_nosync(w);
+        if (n_out > rows_cap_floats) n_out = rows_cap_floats;
+        if (l2 > 1) {
+            timed("final_resample", [&] {
+                resample_generic(stream, sl.filtered.ptr, aligned, d_one.ptr, 1, l2, m2, d_rows, n_out);
+            });
+        } else {
+            timed("final_decimate", [&] {
+                fir_decimate(stream, sl.filtered.ptr, aligned, d_one.ptr, 1, m2, d_rows, n_out);
+            });
+        }
+        set_result(stream, res,
+                   Result{APTGPU_OK, 0, static_cast<uint32_t>(n_out / 2080u), 0, w, n_out});
+    }
+}

@@ -1,0 +1,134 @@
+// apt_plan.hpp — the decode() plan: designed taps, HBM workspace, stream, pipeline.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/aptgpu.h"
+#include "apt_host.hpp"
+#include "apt_kernels.hpp"
+
+namespace apt {
+
+// Throws apt::Error on failure.
+void hip_check(hipError_t e, const char *what);
+
+template <typename T>
+struct DeviceBuffer {
+    T *ptr = nullptr;
+    size_t count = 0;
+    DeviceBuffer() = default;
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    DeviceBuffer(DeviceBuffer &&o) noexcept : ptr(o.ptr), count(o.count) { o.ptr = nullptr; o.count = 0; }
+    DeviceBuffer &operator=(DeviceBuffer &&o) noexcept
+    {
+        if (this != &o) {
+            release();
+            ptr = o.ptr;
+            count = o.count;
+            o.ptr = nullptr;
+            o.count = 0;
+        }
+        return *this;
+    }
+    ~DeviceBuffer() { release(); }
+    void alloc(size_t n)
+    {
+        release();
+        count = n;
+        if (n) hip_check(hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T)), "hipMalloc");
+    }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+};
+
+// Event-pair timing of kernel launches on the plan's stream.
+class KernelTimer {
+public:
+    ~KernelTimer();
+    void enable(bool on);
+    bool enabled() const { return on_; }
+    void begin(hipStream_t s, const char *name);
+    void end(hipStream_t s);
+    // synchronises the stream, folds all recorded pairs into per-name averages
+    std::vector<aptgpu_kernel_time> collect(hipStream_t s);
+
+private:
+    struct Pair {
+        const char *name;
+        hipEvent_t a, b;
+    };
+    bool on_ = false;
+    std::vector<Pair> pairs_;
+    std::vector<hipEvent_t> pool_;
+    hipEvent_t take();
+};
+
+}  // namespace apt
+
+// The opaque C-ABI plan.
+struct aptgpu_plan {
+    int device = 0;
+    int mode = APTGPU_MODE_STRICT;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    aptgpu_settings settings{};
+    uint32_t input_rate = 0;
+    bool sync = true;
+
+    // first resample (decode.rs:65-77)
+    uint32_t l = 1, m = 1;
+    apt::Signal taps_resample;
+    // demodulation (decode.rs:89; dsp.rs:360-363)
+    float cosphi2 = 0.f, sinphi = 0.f;
+    // low-pass (decode.rs:95-102)
+    apt::Signal taps_lowpass;
+    // sync (decode.rs:204-216)
+    uint32_t spr = 0, md = 0, pw = 0, n_sync_taps = 0;
+    bool work_is_multiple = false;
+    // final resample to 4160 (decode.rs:158-159)
+    uint32_t l2 = 1, m2 = 1;
+
+    size_t max_samples = 0;
+    uint64_t max_work_len = 0;
+    uint32_t max_rows = 0;
+    int max_batch = 1;
+    bool fused = false;
+
+    apt::DeviceBuffer<float> d_taps_resample, d_taps_lowpass, d_one;
+    struct Slot {
+        apt::DeviceBuffer<float> resampled, demodulated, filtered, correlation;
+        apt::DeviceBuffer<uint64_t> bits;
+        apt::DeviceBuffer<uint32_t> peaks;
+    };
+    std::vector<Slot> slots;
+    apt::DeviceBuffer<apt::gpu::Result> d_results;
+
+    apt::KernelTimer timer;
+
+    // geometry for an n-sample recording
+    uint64_t work_len_for(uint64_t n) const;
+    uint64_t out_len_nosync(uint64_t work_len) const;
+
+    // enqueue the whole decode() of one device-resident recording into slot `i`
+    void enqueue(int i, const float *d_signal, uint64_t n, float *d_rows, uint64_t rows_cap_floats,
+                 bool keep_steps);
+};
+
+namespace apt {
+
+// Builds a plan; throws apt::Error with the reference's messages.
+aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &settings,
+                         uint32_t input_rate, bool sync, size_t max_samples, int max_batch);
+
+}  // namespace apt

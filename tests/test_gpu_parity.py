@@ -1,0 +1,281 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Tolerance: NONE.  Strict mode rounds every product and sum separately in the reference's
+order, so every comparison below is bit-for-bit (uint32 views), positions exact.
+"""
+import numpy as np
+import pytest
+
+import noaa_apt_amd as apt
+from noaa_apt_amd.testing.synth import synth_apt, synth_noise
+
+pytestmark = pytest.mark.gpu
+
+f32 = np.float32
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, f32).view(np.uint32)
+
+
+def assert_bitexact(got, want, what=""):
+    got = np.asarray(got, f32)
+    want = np.asarray(want, f32)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    if not np.array_equal(_bits(got), _bits(want)):
+        bad = np.flatnonzero(_bits(got) != _bits(want))
+        raise AssertionError(f"{what}: {bad.size} of {got.size} differ, first at {bad[0]}: "
+                             f"{got[bad[0]]!r} vs {want[bad[0]]!r}")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert apt.device_count() >= 1, "no HIP device: the GPU tests must run on the GPU box"
+    return apt.Context(device=0)
+
+
+# ------------------------------------------------------------------ stages
+@pytest.mark.parametrize("rate", [48000, 96000, 11025, 44100, 22050])
+def test_resample_with_filter_polyphase(ctx, oracle, rate):
+    x = synth_noise(rate, 1.5, 3)
+    work = 12480
+    cut, dw = oracle.freq_hz(4800., rate), oracle.freq_hz(1000., rate)
+    want = oracle.resample_with_filter(x, rate, work, oracle.LOWPASS_DC_REMOVAL, cut, 30., dw)
+    got = apt.resample_with_filter(ctx, x, apt.Rate.hz(rate), apt.Rate.hz(work),
+                                   apt.LowpassDcRemoval(apt.Freq.pi_rad(cut), 30., apt.Freq.pi_rad(dw)))
+    assert_bitexact(got, want, f"resample {rate}->12480")
+
+
+@pytest.mark.parametrize("in_rate,out_rate", [(24960, 12480), (12480, 4160), (12480, 12480), (37440, 12480)])
+def test_resample_with_filter_l_equals_1(ctx, oracle, in_rate, out_rate):
+    """l == 1 branch: filter() then decimate() (dsp.rs:106-116)."""
+    x = synth_noise(in_rate, 0.7, 4)
+    cut, dw = oracle.freq_hz(4800., in_rate), oracle.freq_hz(1000., in_rate)
+    for kind, args in ((oracle.NOFILTER, (0., 0., 0.)), (oracle.LOWPASS, (cut, 30., dw))):
+        want = oracle.resample_with_filter(x, in_rate, out_rate, kind, *args)
+        filt = apt.NoFilter() if kind == oracle.NOFILTER else apt.Lowpass(apt.Freq.pi_rad(cut), 30., apt.Freq.pi_rad(dw))
+        got = apt.resample_with_filter(ctx, x, apt.Rate.hz(in_rate), apt.Rate.hz(out_rate), filt)
+        assert_bitexact(got, want, f"l==1 {in_rate}->{out_rate} kind {kind}")
+
+
+def test_resample_tool_path(ctx, oracle):
+    """dsp::resample (WAV->WAV tool) incl. up-sampling; rate pairs of test/test.sh:48-52."""
+    x = synth_noise(11025, 0.8, 9)
+    for out_rate in (48000, 6000, 3675, 80000):
+        want = oracle.resample(x, 11025, out_rate, 40., 0.1)
+        got = apt.resample(ctx, x, apt.Rate.hz(11025), apt.Rate.hz(out_rate), 40., apt.Freq.pi_rad(0.1))
+        assert_bitexact(got, want, f"resample 11025->{out_rate}")
+
+
+def test_resample_edge_cases(ctx, oracle):
+    rng = np.random.default_rng(1)
+    # taps longer than the signal (dsp.rs:454-468), tiny signals, 1-sample signal
+    for n in (1, 2, 17, 100, 1000):
+        x = rng.standard_normal(n).astype(f32) * 1000
+        want = oracle.resample_with_filter(x, 48000, 12480, oracle.LOWPASS_DC_REMOVAL,
+                                           oracle.freq_hz(4800., 48000), 30., oracle.freq_hz(1000., 48000))
+        got = apt.resample_with_filter(ctx, x, apt.Rate.hz(48000), apt.Rate.hz(12480),
+                                       apt.LowpassDcRemoval(apt.Freq.hz(4800., apt.Rate.hz(48000)), 30.,
+                                                            apt.Freq.hz(1000., apt.Rate.hz(48000))))
+        assert_bitexact(got, want, f"short n={n}")
+
+
+def test_rate_overflow(ctx):
+    # dsp.rs:420-434
+    with pytest.raises(apt.RateOverflowError):
+        apt.resample_with_filter(ctx, np.zeros(1000, f32), apt.Rate.hz(99371), apt.Rate.hz(93911), apt.NoFilter())
+    with pytest.raises(apt.InternalError) as e:
+        apt.resample_with_filter(ctx, np.zeros(10, f32), apt.Rate.hz(48000), apt.Rate.hz(0), apt.NoFilter())
+    assert str(e.value) == "Can't resample to 0Hz"
+
+
+def test_demodulate(ctx, oracle):
+    x = synth_apt(12480, 3, 2, amplitude=1500., noise_sigma=30.)
+    for work in (12480, 16640, 20800):
+        pr = oracle.freq_hz(2400., work)
+        assert_bitexact(apt.demodulate(ctx, x, apt.Freq.pi_rad(pr)), oracle.demodulate(x, pr), f"demod {work}")
+    # values that make the radicand slightly negative / zero / denormal
+    y = np.array([0, 0, 1e-30, -1e-30, 1, 1, -1, 3e38, 3e38, 1e-45, 0], f32)
+    pr = oracle.freq_hz(2400., 12480)
+    assert_bitexact(apt.demodulate(ctx, y, apt.Freq.pi_rad(pr)), oracle.demodulate(y, pr), "demod specials")
+
+
+def test_filter(ctx, oracle):
+    x = synth_noise(12480, 2, 6)
+    c2 = f32(4160) / f32(12480)
+    want = oracle.fir(x, oracle.filter_design(oracle.LOWPASS, c2, 25., c2 / f32(5)))
+    got = apt.filter(ctx, x, apt.Lowpass(apt.Freq.pi_rad(c2), 25., apt.Freq.pi_rad(c2) / 5.0))
+    assert_bitexact(got, want, "lowpass")
+    assert got[0] == 0.0  # the `i > j` guard (dsp.rs:399)
+    assert_bitexact(apt.filter(ctx, x[:5], apt.NoFilter()), oracle.fir(x[:5], np.ones(1, f32)), "nofilter")
+
+
+def _fsm_cases():
+    rng = np.random.default_rng(42)
+    n = 2080 * 23 + 977
+    return {
+        "zeros": np.zeros(n, f32),
+        "noise": rng.standard_normal(n).astype(f32),
+        "noise_pos": (rng.standard_normal(n) + 5).astype(f32),
+        "noise_neg": (rng.standard_normal(n) - 5).astype(f32),
+        "ramp_up": np.arange(n, dtype=f32),
+        "ramp_down": -np.arange(n, dtype=f32),
+        "plateaus": np.repeat(rng.integers(0, 4, n // 64 + 1), 64)[:n].astype(f32),
+        "quantised": rng.integers(-3, 4, n).astype(f32),
+        "sparse_spikes": np.where(rng.random(n) < 0.0007, rng.random(n) * 100, 0).astype(f32),
+        "slow_sine": np.sin(np.arange(n) / 700.0).astype(f32),
+        "rising_sine": (np.sin(np.arange(n) / 37.0) + np.arange(n) / 900.0).astype(f32),
+    }
+
+
+@pytest.mark.parametrize("name", list(_fsm_cases().keys()))
+@pytest.mark.parametrize("work_rate", [4160, 8320, 12480])
+def test_find_sync_adversarial(ctx, oracle, name, work_rate):
+    f = _fsm_cases()[name]
+    want_pos, want_corr = oracle.find_sync(f, work_rate, return_correlation=True)
+    got_pos, got_corr = apt.find_sync(ctx, f, apt.Rate.hz(work_rate), return_correlation=True)
+    assert_bitexact(got_corr, want_corr, "correlation")
+    assert got_pos.tolist() == want_pos.tolist()
+
+
+def test_find_sync_short_and_edges(ctx, oracle):
+    rng = np.random.default_rng(3)
+    for n in (38, 39, 100, 1664, 1665, 2080, 2081, 4160, 4161, 5000):
+        f = rng.standard_normal(n).astype(f32)
+        want = oracle.find_sync(f, 4160)
+        got = apt.find_sync(ctx, f, apt.Rate.hz(4160))
+        assert got.tolist() == want.tolist(), n
+    with pytest.raises(apt.InternalError):
+        apt.find_sync(ctx, np.zeros(5000, f32), apt.Rate.hz(11025))
+
+
+# ------------------------------------------------------------------ decode()
+DECODE_CASES = [
+    # (rate, seconds, seed, profile, kwargs)
+    (48000, 14, 2, "standard", {}),
+    (48000, 14, 12, "standard", dict(ppm=40.0)),
+    (96000, 12, 3, "standard", {}),
+    (11025, 20, 1, "standard", {}),
+    (44100, 12, 4, "standard", {}),
+    (48000, 12, 5, "fast", {}),
+    (48000, 12, 6, "slow", {}),
+    (24960, 12, 7, "standard", {}),   # l == 1 first stage
+    (48000, 12, 8, "standard", dict(noise_sigma=6000.0)),  # heavy noise
+]
+
+
+@pytest.mark.parametrize("rate,seconds,seed,profile,kw", DECODE_CASES)
+@pytest.mark.parametrize("sync", [True, False])
+def test_decode_bitexact(ctx, oracle, rate, seconds, seed, profile, kw, sync):
+    x = synth_apt(rate, seconds, seed, **kw)
+    s = apt.Settings.profile(profile)
+    os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                       "resample_cutout", "demodulation_atten")}
+    want, st = oracle.decode(x, rate, sync, settings=os_, want_steps=True)
+    got, stats = apt.decode(ctx, s, x, apt.Rate.hz(rate), sync, return_stats=True)
+    assert stats.n_resample_taps == st["resample_filter"].size
+    assert stats.n_lowpass_taps == st["filter_filter"].size
+    assert stats.work_len == st["resampled"].size
+    if sync:
+        assert stats.n_sync == st["sync_pos"].size
+    assert_bitexact(got, want, f"decode {rate} {profile} sync={sync}")
+    assert got.size % 2080 == 0
+
+
+def test_decode_noise_fixture_like(ctx, oracle):
+    """Stand-in for test/noise_48000hz.wav (really 11025 Hz, 30 s of noise)."""
+    x = synth_noise(11025, 30.0, 77)
+    assert_bitexact(apt.decode(ctx, apt.Settings(), x, apt.Rate.hz(11025), True),
+                    oracle.decode(x, 11025, True), "noise decode")
+
+
+def test_decode_zeros_and_dc(ctx, oracle):
+    for x in (np.zeros(48000 * 8, f32), np.full(48000 * 8, 1234.0, f32)):
+        assert_bitexact(apt.decode(ctx, apt.Settings(), x, apt.Rate.hz(48000), True),
+                        oracle.decode(x, 48000, True), "zeros/dc")
+
+
+def test_decode_errors(ctx):
+    with pytest.raises(apt.InternalError) as e:
+        apt.decode(ctx, apt.Settings(), np.zeros(48000, f32), apt.Rate.hz(48000), True)
+    assert str(e.value) == "Got less than 10 rows of samples, audio file is too short"
+    with pytest.raises(apt.InternalError) as e:  # work_rate not a multiple of 4160 -> find_sync error
+        apt.decode(ctx, apt.Settings(work_rate=11025), synth_apt(48000, 12, 1), apt.Rate.hz(48000), True)
+    assert str(e.value) == "work_rate is not multiple of FINAL_RATE"
+    with pytest.raises(apt.RateOverflowError):
+        apt.decode(ctx, apt.Settings(work_rate=93911), np.zeros(99371 * 12, f32), apt.Rate.hz(99371), True)
+
+
+def test_decode_nosync_odd_work_rate(ctx, oracle):
+    """sync == false with a work_rate that is not a multiple of 4160: the final stage goes
+    through fast_resampling with NoFilter taps (l > 1)."""
+    x = synth_apt(48000, 12, 21)
+    s = apt.Settings(work_rate=11025)
+    os_ = dict(work_rate=11025, resample_atten=30., resample_delta_freq=1000., resample_cutout=4800.,
+               demodulation_atten=25.)
+    assert_bitexact(apt.decode(ctx, s, x, apt.Rate.hz(48000), False),
+                    oracle.decode(x, 48000, False, settings=os_), "nosync odd work rate")
+
+
+def test_status_callbacks_in_reference_order(ctx):
+    seen = []
+    c = apt.Context(ui_callback=lambda p, t: seen.append((round(p, 2), t)), device=0)
+    apt.decode(c, apt.Settings(), synth_apt(48000, 12, 1), apt.Rate.hz(48000), True)
+    assert seen == [(0.1, "Resampling to 12480"), (0.4, "Demodulating"), (0.42, "Filtering"),
+                    (0.5, "Syncing"), (0.9, "Resampling to 4160")]
+    seen.clear()
+    apt.decode(c, apt.Settings(), synth_apt(48000, 12, 1), apt.Rate.hz(48000), False)
+    assert seen[3] == (0.5, "Skipping Syncing")
+
+
+def test_steps_export(ctx, oracle):
+    """Context::step: every intermediate the reference would export, bit-identical."""
+    x = synth_apt(48000, 12, 31)
+    got = []
+    c = apt.Context(step_callback=lambda i, v, d, r: got.append((i, v, d, r)), device=0)
+    s = apt.Settings(export_wav=True)
+    rows = apt.decode(c, s, x, apt.Rate.hz(48000), True)
+    want_rows, st = oracle.decode(x, 48000, True, want_steps=True)
+    assert_bitexact(rows, want_rows)
+    ids = [g[0] for g in got]
+    assert ids == ["input", "resample_filter", "resample_filtered", "resample_decimated",
+                   "demodulation_result", "filter_filter", "filter_result", "sync_correlation",
+                   "sync_result", "resample_filter", "filter_filter", "filter_result",
+                   "resample_filtered", "resample_decimated"]
+    by = {}
+    for i, v, d, r in got:
+        by.setdefault(i, []).append((v, d, r))
+    assert_bitexact(by["input"][0][1], x)
+    assert_bitexact(by["resample_filter"][0][1], st["resample_filter"])
+    assert by["resample_filtered"][0][1].size == 0 and by["resample_filtered"][0][2] == 48000 * 13
+    assert_bitexact(by["resample_decimated"][0][1], st["resampled"])
+    assert_bitexact(by["demodulation_result"][0][1], st["demodulated"])
+    assert_bitexact(by["filter_filter"][0][1], st["filter_filter"])
+    assert_bitexact(by["filter_result"][0][1], st["filtered"])
+    assert_bitexact(by["sync_correlation"][0][1], st["correlation"])
+    assert_bitexact(by["sync_result"][0][1], st["aligned"])
+    assert by["resample_filter"][1][1].tolist() == [1.0]
+    assert_bitexact(by["resample_decimated"][1][1], want_rows)
+
+
+# ------------------------------------------------------------------ plans / batch
+def test_plan_device_resident_batch(ctx, oracle):
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    recs = [synth_apt(48000, 11 + i, 100 + i, ppm=10.0 * i) for i in range(3)]
+    nmax = max(r.size for r in recs)
+    plan = apt.Plan(apt.Settings(), apt.Rate.hz(48000), True, max_samples=nmax, max_batch=3,
+                    stream=torch.cuda.current_stream().cuda_stream)
+    d_in = [torch.from_numpy(r).to(dev) for r in recs]
+    cap = int(plan.info.max_rows)
+    d_out = [torch.empty(cap * 2080, dtype=torch.float32, device=dev) for _ in recs]
+    for _ in range(2):  # run twice: the plan is reusable
+        plan.decode_device([t.data_ptr() for t in d_in], [r.size for r in recs],
+                           [t.data_ptr() for t in d_out], [cap] * 3)
+    res = plan.results(3)
+    for i, r in enumerate(recs):
+        want, st = oracle.decode(r, 48000, True, want_steps=True)
+        assert res[i].status == 0 and res[i].n_out == want.size
+        assert_bitexact(d_out[i][:res[i].n_out].cpu().numpy(), want, f"batch {i}")
+        assert plan.sync_positions(i).tolist() == st["sync_pos"].tolist()
+    plan.close()
