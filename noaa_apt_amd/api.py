@@ -115,11 +115,28 @@ def build():
     subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j4", "all"])
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so whose SONAME
+    (libamdhip64.so.7) equals /opt/rocm's; whichever is loaded first satisfies the other's
+    NEEDED entry only in one direction (torch asks for "libamdhip64.so").  Loading torch's
+    copy first makes libaptgpu.so and torch share it, so torch tensors' device pointers and
+    streams are valid in our launches regardless of import order.  Without torch installed,
+    libaptgpu.so's RUNPATH finds /opt/rocm's runtime as usual."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """The loaded libaptgpu.so.  Raises if it has not been built — there is no fallback."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_hip_runtime()
     if not os.path.exists(_LIB):
         raise ImportError(f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; "
                           f"g.build()'` (or `make -C noaa_apt_amd/csrc`) first")

@@ -9,6 +9,9 @@
 
 #include <hip/hip_runtime.h>
 
+// never fuse a*b+c: the reference rounds the product and the sum separately
+#pragma clang fp contract(off)
+
 namespace apt::gpu {
 
 namespace {
@@ -74,7 +77,9 @@ __device__ __forceinline__ float demod_pair(float prev, float curr, float cosphi
 {
     const float a = __fadd_rn(__fmul_rn(prev, prev), __fmul_rn(curr, curr));
     const float b = __fmul_rn(__fmul_rn(prev, curr), cosphi2);
-    return __fdiv_rn(__fsqrt_rn(__fsub_rn(a, b)), sinphi);
+    // __fsqrt_rn is the *native approximate* sqrt in this HIP; __builtin_sqrtf and `/` are
+    // IEEE-correct under -fhip-fp32-correctly-rounded-divide-sqrt (set in the Makefile).
+    return __builtin_sqrtf(__fsub_rn(a, b)) / sinphi;
 }
 
 __global__ void __launch_bounds__(kBlock)
