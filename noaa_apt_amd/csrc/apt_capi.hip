@@ -609,8 +609,29 @@ int aptgpu_find_sync(const aptgpu_context *ctx, const float *signal, size_t n,
         apt::DeviceBuffer<apt::gpu::Result> d_res;
         d_res.alloc(1);
         apt::gpu::correlate(sc.stream, d_f.ptr, n_corr, pw, d_c.ptr);
-        apt::gpu::terminals(sc.stream, d_c.ptr, n_corr, md, d_bits.ptr);
-        apt::gpu::orbit_walk(sc.stream, d_bits.ptr, n_corr, n, spr, md, d_peaks.ptr, cap, d_res.ptr);
+        if (ctx && ctx->mode == APTGPU_MODE_GENERIC) {
+            apt::gpu::terminals(sc.stream, d_c.ptr, n_corr, md, d_bits.ptr);
+            apt::gpu::orbit_walk(sc.stream, d_bits.ptr, n_corr, n, spr, md, d_peaks.ptr, cap, d_res.ptr);
+        } else {
+            const uint64_t ng = n_corr / apt::gpu::sync_group_size() + 2;
+            const uint64_t chunks = ng / apt::gpu::sync_chunk_groups() + 2;
+            apt::DeviceBuffer<float> d_gm;
+            d_gm.alloc(ng + 64);
+            apt::DeviceBuffer<uint64_t> d_words;
+            d_words.alloc(ng + 64);
+            apt::DeviceBuffer<uint32_t> d_slot, d_cnt, d_flags;
+            d_slot.alloc(chunks * apt::gpu::sync_slot_cap());
+            d_cnt.alloc(chunks);
+            d_flags.alloc(4);
+            apt::hip_check(hipMemsetAsync(d_flags.ptr, 0, 16, sc.stream), "hipMemsetAsync");
+            const char *fw = std::getenv("APTGPU_FORCE_WALK");
+            apt::gpu::group_max(sc.stream, d_c.ptr, n_corr, d_gm.ptr);
+            apt::gpu::sync_nodes(sc.stream, d_gm.ptr, d_c.ptr, n_corr, spr, md, d_words.ptr, d_slot.ptr,
+                                 d_cnt.ptr, d_flags.ptr);
+            apt::gpu::sync_orbit(sc.stream, d_words.ptr, d_slot.ptr, d_cnt.ptr, d_flags.ptr, n_corr, n,
+                                 spr, md, d_peaks.ptr, cap, d_res.ptr, fw && fw[0] == '1');
+            apt::hip_check(hipStreamSynchronize(sc.stream), "hipStreamSynchronize");
+        }
         apt::gpu::Result r{};
         apt::hip_check(hipMemcpyAsync(&r, d_res.ptr, sizeof r, hipMemcpyDeviceToHost, sc.stream),
                        "hipMemcpyAsync");

@@ -43,6 +43,35 @@ void orbit_walk(hipStream_t s, const uint64_t *bits, uint64_t n_corr, uint64_t w
 void gather_rows(hipStream_t s, const float *f, const uint32_t *peaks, const Result *res,
                  uint32_t spr, uint32_t pw, bool raw, float *rows, uint32_t rows_cap);
 
+// ---- fused specialised front end (apt_kernels_fused.hip) --------------------------
+// true when a <L, M, T1, T2, PW> specialisation exists
+bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
+uint32_t fused_group_size(uint32_t l);
+uint32_t fused_taps_per_branch(uint32_t l, uint32_t t1);
+// host: reorder the T1 taps step-major [TP][L] (hs[i*L+b] = coeff[p_b + i*L], 0 past T1)
+void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, float *hs);
+// x -> F (filtered work-rate signal) and, if gm_out != nullptr, the per-group maxima of
+// the sync cross-correlation.  Returns false if no specialisation matches.
+bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
+                     const float *x, uint64_t n, const float *hs, const float *h2, float cosphi2,
+                     float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w,
+                     uint64_t n_corr);
+
+// ---- parallel peak picker (apt_kernels_sync.hip) ------------------------------------
+uint32_t sync_group_size();    // correlation positions per group (52)
+uint32_t sync_chunk_groups();  // groups per k_sync_nodes workgroup
+uint32_t sync_slot_cap();      // node terminals kept per chunk
+// corr -> per-group maxima (unfused path; the fused front end writes them itself)
+void group_max(hipStream_t s, const float *corr, uint64_t n_corr, float *gm);
+// coarse/fine terminal detection -> terminal words + ordered node-terminal lists
+void sync_nodes(hipStream_t s, const float *gm, const float *corr, uint64_t n_corr, uint32_t spr,
+                uint32_t md, uint64_t *words, uint32_t *slot_nt, uint32_t *slot_cnt, uint32_t *flags);
+// orbit of the picker (LDS pointer doubling, or the sequential walk as fallback)
+void sync_orbit(hipStream_t s, const uint64_t *words, const uint32_t *slot_nt,
+                const uint32_t *slot_cnt, uint32_t *flags, uint64_t n_corr, uint64_t work_len,
+                uint32_t spr, uint32_t md, uint32_t *peaks, uint32_t peaks_cap, Result *res,
+                bool force_walk);
+
 // writes a result record from the host's knowledge (too-short recording, no-sync path)
 void set_result(hipStream_t s, Result *res, Result value);
 

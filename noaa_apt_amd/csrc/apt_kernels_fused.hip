@@ -1,5 +1,361 @@
-// apt_kernels_fused.hip — fused, specialised gfx950 kernels.
+// apt_kernels_fused.hip — the fused, specialised front end of decode() for gfx950.
+//
+//   x (input rate) --polyphase FIR--> R --AM envelope--> D --low-pass--> F --sync corr--> C
+//
+// One launch produces F (the filtered work-rate signal, the only intermediate that goes
+// back to HBM) and GM (the maximum of the sync cross-correlation over groups of GS
+// consecutive positions — all the peak picker needs; see apt_kernels_sync.hip).  R, D
+// and C never leave the CU.  Reference: src/decode.rs:77-110, src/dsp.rs:186-289,
+// 350-410, src/decode.rs:225-233.
+//
+// Mapping (template <L, M, T1, T2, PW>):  thread "a" owns the L consecutive work-rate
+// samples k = L*a .. L*a+L-1.  All of them read the same input window x[M*a ..], each
+// through its own polyphase branch of the T1-tap filter, so
+//   * the window (c_{L-1}+TP floats) is read once from LDS into registers,
+//   * the branch taps are wave-uniform -> scalar loads (s_load_dwordx*) through the
+//     scalar cache, no LDS traffic and no VGPRs for coefficients,
+//   * every product and sum is a separate v_mul_f32 / v_add_f32 in the reference's
+//     order: bit-identical to the scalar Rust loop (no FMA; #pragma fp contract(off)).
+// A workgroup of 256 threads covers 256*L work samples: 4 threads of pre-halo (the
+// low-pass and envelope look back 37 samples), 240 threads of owned outputs and 12
+// threads of post-halo (the correlation looks ahead 38*PW-1 samples).  LDS: the input
+// tile, later overwritten by R and then F (region P), plus D (region Q).
 #include "apt_kernels.hpp"
 
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#pragma clang fp contract(off)
+
 namespace apt::gpu {
+
+namespace {
+
+constexpr int kFusedThreads = 256;
+constexpr int kPreThreads = 4;
+constexpr int kOwnThreads = 240;
+constexpr float kNegInfF = -__builtin_huge_valf();
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int L, int M>
+__host__ __device__ constexpr int branch_first(int b)  // c_b = ceil(b*M / L)
+{
+    return (b * M + L - 1) / L;
+}
+template <int L, int M>
+__host__ __device__ constexpr int branch_phase(int b)  // p_b = c_b*L - b*M
+{
+    return branch_first<L, M>(b) * L - b * M;
+}
+
+template <int L, int M, int T1, int T2, int PW>
+struct FusedGeom {
+    static constexpr int TP = (T1 + L - 1) / L;                       // taps per branch (max)
+    static constexpr int CLAST = branch_first<L, M>(L - 1);           // last branch's first sample
+    static constexpr int WIN = CLAST + TP;                            // input window per thread
+    static constexpr int TILE_K = kFusedThreads * L;                  // work samples per tile
+    static constexpr int OWN_K = kOwnThreads * L;                     // owned work samples
+    static constexpr int PRE_K = kPreThreads * L;
+    static constexpr int XT = (kFusedThreads - 1) * M + WIN + 2;          // input floats per tile
+    static constexpr int XT_PAD = (XT + 3) & ~3;
+    static constexpr int G = 38 * PW;                                 // sync template length
+    static constexpr int FWIN = L + G - 1;                            // F window per thread
+    // one LDS region: the x tile, then R/F at [0, TILE_K+G), D at D_OFF, C at C_OFF
+    static constexpr int D_OFF = (TILE_K + G + 3) & ~3;
+    static constexpr int C_OFF = D_OFF + TILE_K;
+    static constexpr int LDS_FLOATS = XT_PAD > (C_OFF + TILE_K) ? XT_PAD : (C_OFF + TILE_K);
+    static constexpr int GS = 4 * L;                                  // correlation group size
+    static_assert(PRE_K >= T2 + 1, "pre-halo too small for the low-pass");
+    static_assert((kFusedThreads - kPreThreads - kOwnThreads) * L >= G - 1, "post-halo too small");
+    static_assert(OWN_K % 4 == 0, "owned range must be float4-aligned");
+};
+
+// sign of the sync template at index j (decode.rs:188-198): + inside the seven high pulses
+template <int PW>
+__host__ __device__ constexpr bool sync_plus(int j)
+{
+    const int pulse = 2 * PW;
+    if (j < pulse || j >= pulse + 14 * pulse) return false;
+    return (((j - pulse) / pulse) & 1) == 1;
+}
+
+template <int L, int M, int T1, int T2, int PW>
+__global__ void __launch_bounds__(kFusedThreads, 3)
+k_fused(const float *__restrict__ x, uint64_t n, const float *__restrict__ hs /*[TP][L] step-major*/,
+        const float *__restrict__ h2 /*[T2]*/, float cosphi2, float sinphi,
+        float *__restrict__ f_out, float *__restrict__ c_out, float *__restrict__ gm_out,
+        uint64_t w, uint64_t n_corr)
+{
+    using Gm = FusedGeom<L, M, T1, T2, PW>;
+    extern __shared__ float lds[];
+    float *P = lds;                  // x tile -> R -> F
+    float *Q = lds + Gm::D_OFF;      // D (inside the dead part of the x tile)
+    float *CS = lds + Gm::C_OFF;     // correlation staging for coalesced stores
+
+    const int tid = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t o0 = tile * Gm::OWN_K;            // first owned work sample
+    const int64_t k0 = o0 - Gm::PRE_K;              // first work sample of the tile
+    const int64_t a0 = k0 / L;                      // may be negative (tile 0)
+    const int64_t xs0 = a0 * M;                     // first input sample of the tile
+
+    // ---- stage 0: input tile -> LDS (coalesced 16-byte loads, zero outside [0, n))
+    for (int q = tid * 4; q < Gm::XT_PAD; q += kFusedThreads * 4) {
+        const int64_t g = xs0 + q;
+        float4 v;
+        if (g >= 0 && g + 3 < static_cast<int64_t>(n)) {
+            v = *reinterpret_cast<const float4 *>(x + g);
+        } else {
+            v.x = (g >= 0 && g < static_cast<int64_t>(n)) ? x[g] : 0.f;
+            v.y = (g + 1 >= 0 && g + 1 < static_cast<int64_t>(n)) ? x[g + 1] : 0.f;
+            v.z = (g + 2 >= 0 && g + 2 < static_cast<int64_t>(n)) ? x[g + 2] : 0.f;
+            v.w = (g + 3 >= 0 && g + 3 < static_cast<int64_t>(n)) ? x[g + 3] : 0.f;
+        }
+        *reinterpret_cast<float4 *>(P + q) = v;
+    }
+    __syncthreads();
+
+    // ---- stage 1: polyphase resampler, L outputs per thread (dsp.rs:252-263)
+    // Tap step i of every branch b reads xw[c_b + i]: a window of CLAST+1 samples sliding
+    // by one per step.  The loop is unrolled in chunks of CH steps fenced by scheduling
+    // barriers so only ~CLAST+2*CH samples and one chunk of taps are live at a time.
+    const int64_t kt = k0 + static_cast<int64_t>(tid) * L;  // this thread's first work sample
+    float r[L];
+    {
+        constexpr int CH = 4;
+        float xw[Gm::WIN + 1];
+        const float *src = P + tid * M;
+        constexpr bool kPairs = (M % 2) == 0;  // 8-byte aligned window -> ds_read_b64
+        auto load_range = [&](auto lo_c, auto hi_c) {
+            constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+            if constexpr (kPairs) {
+#pragma unroll
+                for (int q = lo; q < hi; q += 2) {
+                    const float2 v = *reinterpret_cast<const float2 *>(src + q);
+                    xw[q] = v.x;
+                    xw[q + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int q = lo; q < hi; ++q) xw[q] = src[q];
+            }
+        };
+        constexpr int kFirst = (Gm::CLAST + CH + 1) & ~1;
+        load_range(std::integral_constant<int, 0>{}, std::integral_constant<int, kFirst>{});
+#pragma unroll
+        for (int b = 0; b < L; ++b) r[b] = 0.f;
+        static_for<0, (Gm::TP + CH - 1) / CH>([&](auto cc) {
+            constexpr int c0 = decltype(cc)::value * CH;
+            constexpr int lo = (Gm::CLAST + c0 + CH + 1) & ~1;
+            constexpr int hi_raw = (Gm::CLAST + c0 + 2 * CH + 1) & ~1;
+            constexpr int hi = hi_raw < ((Gm::WIN + 1) & ~1) ? hi_raw : ((Gm::WIN + 1) & ~1);
+            if constexpr (lo < hi) load_range(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{});
+#pragma unroll
+            for (int i = c0; i < c0 + CH; ++i) {
+                if (i < Gm::TP) {
+#pragma unroll
+                    for (int b = 0; b < L; ++b) {
+                        if (branch_phase<L, M>(b) + i * L < T1)
+                            r[b] = r[b] + hs[i * L + b] * xw[branch_first<L, M>(b) + i];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        const bool live = kt >= 0;
+#pragma unroll
+        for (int b = 0; b < L; ++b)
+            if (!live || static_cast<uint64_t>(kt + b) >= w) r[b] = 0.f;
+    }
+    __syncthreads();  // everyone is done reading the x tile
+#pragma unroll
+    for (int b = 0; b < L; ++b) P[tid * L + b] = r[b];
+    __syncthreads();
+
+    // ---- stage 2: AM envelope from consecutive samples (dsp.rs:369-377)
+    {
+        float prev = (tid > 0) ? P[tid * L - 1] : 0.f;
+#pragma unroll
+        for (int b = 0; b < L; ++b) {
+            const float curr = r[b];
+            float d = 0.f;
+            if (kt + b >= 1) {
+                const float s = (prev * prev) + (curr * curr);
+                const float c = (prev * curr) * cosphi2;
+                d = __builtin_sqrtf(s - c) / sinphi;
+            }
+            Q[tid * L + b] = d;
+            prev = curr;
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 3: causal low-pass with the `i > j` guard (dsp.rs:396-404)
+    float f[L];
+    {
+        constexpr int DW = L + T2 - 1;
+        float dw[DW];  // D[kt - (T2-1) .. kt + L - 1]
+        const int base = tid * L - (T2 - 1);
+#pragma unroll
+        for (int q = 0; q < DW; ++q) dw[q] = (base + q >= 0) ? Q[base + q] : 0.f;
+#pragma unroll
+        for (int b = 0; b < L; ++b) f[b] = 0.f;
+        if (kt >= T2) {
+#pragma unroll
+            for (int j = 0; j < T2; ++j) {
+#pragma unroll
+                for (int b = 0; b < L; ++b) f[b] = f[b] + dw[(T2 - 1) + b - j] * h2[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < T2; ++j) {
+#pragma unroll
+                for (int b = 0; b < L; ++b)
+                    if (kt + b > j) f[b] = f[b] + dw[(T2 - 1) + b - j] * h2[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < L; ++b) P[tid * L + b] = f[b];  // R is dead: P now holds F
+    __syncthreads();
+
+    // owned F -> HBM, coalesced 16-byte stores
+    for (int q = tid * 4; q < Gm::OWN_K; q += kFusedThreads * 4) {
+        const int64_t g = o0 + q;
+        if (g + 3 < static_cast<int64_t>(w)) {
+            *reinterpret_cast<float4 *>(f_out + g) = *reinterpret_cast<const float4 *>(P + Gm::PRE_K + q);
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (g + e < static_cast<int64_t>(w)) f_out[g + e] = P[Gm::PRE_K + q + e];
+        }
+    }
+
+    // ---- stage 4: sync cross-correlation (decode.rs:225-233), its group maxima, and C
+    if (gm_out != nullptr) {
+        constexpr int CJ = 2 * PW;  // one template pulse per chunk
+        float fw[Gm::FWIN + CJ];
+        const float *src = P + tid * L;
+        auto load_f = [&](auto lo_c, auto hi_c) {
+            constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+#pragma unroll
+            for (int q = lo; q < hi; ++q) fw[q] = src[q];
+        };
+        load_f(std::integral_constant<int, 0>{}, std::integral_constant<int, L + CJ>{});
+        float c[L];
+#pragma unroll
+        for (int b = 0; b < L; ++b) c[b] = 0.f;
+        static_for<0, (Gm::G + CJ - 1) / CJ>([&](auto cc) {
+            constexpr int j0 = decltype(cc)::value * CJ;
+            constexpr int lo = L + j0 + CJ;
+            constexpr int hi = (lo + CJ) < Gm::FWIN ? (lo + CJ) : Gm::FWIN;
+            if constexpr (lo < hi) load_f(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{});
+#pragma unroll
+            for (int j = j0; j < j0 + CJ; ++j) {
+                if (j < Gm::G) {
+#pragma unroll
+                    for (int b = 0; b < L; ++b) {
+                        if (sync_plus<PW>(j))
+                            c[b] = c[b] + fw[b + j];
+                        else
+                            c[b] = c[b] - fw[b + j];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        float mx = kNegInfF;
+#pragma unroll
+        for (int b = 0; b < L; ++b) {
+            const int64_t pos = kt + b;
+            float v = c[b];
+            if (pos == 0 && !(v > 0.f)) v = 0.f;  // the picker starts from the peak (0, 0.)
+            if (pos >= 0 && static_cast<uint64_t>(pos) < n_corr) mx = fmaxf(mx, v);
+            CS[tid * L + b] = c[b];
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        if ((tid & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads) {
+            const int64_t grp = kt / Gm::GS;
+            if (static_cast<uint64_t>(kt) < n_corr) gm_out[grp] = mx;
+        }
+        __syncthreads();
+        // owned C -> HBM, coalesced 16-byte stores (read by the fine stage of the picker)
+        for (int q = tid * 4; q < Gm::OWN_K; q += kFusedThreads * 4) {
+            const int64_t g = o0 + q;
+            if (g + 3 < static_cast<int64_t>(n_corr)) {
+                *reinterpret_cast<float4 *>(c_out + g) =
+                    *reinterpret_cast<const float4 *>(CS + Gm::PRE_K + q);
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (g + e < static_cast<int64_t>(n_corr)) c_out[g + e] = CS[Gm::PRE_K + q + e];
+            }
+        }
+    }
+}
+
+template <int L, int M, int T1, int T2, int PW>
+void launch_fused(hipStream_t s, const float *x, uint64_t n, const float *hb, const float *h2,
+                  float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w,
+                  uint64_t n_corr)
+{
+    using Gm = FusedGeom<L, M, T1, T2, PW>;
+    const size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
+    auto kern = k_fused<L, M, T1, T2, PW>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        attr_set = true;
+    }
+    const unsigned tiles = static_cast<unsigned>((w + Gm::OWN_K - 1) / Gm::OWN_K);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(kFusedThreads), lds, s, x, n, hb, h2, cosphi2, sinphi,
+                       f_out, c_out, gm_out, w, n_corr);
+}
+
+}  // namespace
+
+bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
+{
+    return l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3;
+}
+
+uint32_t fused_group_size(uint32_t l) { return 4 * l; }
+
+uint32_t fused_taps_per_branch(uint32_t l, uint32_t t1) { return (t1 + l - 1) / l; }
+
+void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, float *hb)
+{
+    const uint32_t tp = (t1 + l - 1) / l;
+    for (uint32_t b = 0; b < l; ++b) {
+        const uint32_t cb = (b * m + l - 1) / l;
+        const uint32_t pb = cb * l - b * m;
+        for (uint32_t i = 0; i < tp; ++i) {
+            const uint32_t j = pb + i * l;
+            hb[i * l + b] = j < t1 ? coeff[j] : 0.f;  // step-major [TP][L]
+        }
+    }
+}
+
+bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
+                     const float *x, uint64_t n, const float *hb, const float *h2, float cosphi2,
+                     float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w,
+                     uint64_t n_corr)
+{
+    if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
+        launch_fused<13, 50, 959, 37, 3>(s, x, n, hb, h2, cosphi2, sinphi, f_out, c_out, gm_out, w,
+                                         n_corr);
+        return true;
+    }
+    return false;
+}
+
 }  // namespace apt::gpu

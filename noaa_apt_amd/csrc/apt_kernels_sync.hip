@@ -1,0 +1,486 @@
+// apt_kernels_sync.hip — the peak picker of find_sync() (src/decode.rs:204-263) as a
+// parallel computation.
+//
+// What the reference does, sequentially over the cross-correlation corr[0..n):
+//   peaks = [(0, 0.)]
+//   for i: if i - last.idx > md:  while i/spr > len(peaks): push (i, corr[i])
+//          elif corr[i] > last.val: replace last by (i, corr[i])
+//
+// Facts used here (proved in DESIGN.md §Peak picker, checked against the oracle on
+// adversarial inputs by tests/test_oracle_numpy_crosscheck.py and tests/test_gpu_parity.py):
+//  (1) A tracking phase that starts at position s ends on the first TERMINAL t >= s, where
+//      T[i] <=> no j in (i, i+md] has corr[j] > corr[i]   (corr[0] clamped to >= 0 for
+//      the initial (0, 0.) peak).  The chain of strict records can never step over a
+//      terminal.
+//  (2) The picker is therefore the orbit  s -> u = firstT(s) -> s' = max(u+md+1,
+//      (cell(s)+1)*spr)  over start positions; pushes fill peaks[cell(prev) .. cell(s)-2]
+//      with s and peaks[cell(s)-1] with u.
+//  (3) Starts are grid points c*spr or u+md+1 for a terminal u, and firstT(s) is either s
+//      itself (then s is a terminal with s-md-1 terminal, or a grid terminal) or the head of
+//      a run of terminals.  So only NODE TERMINALS matter: heads, terminals t with t-md-1
+//      terminal, and terminals on the grid — a few per image row.
+//
+// Kernels (GS = 52 correlation positions per group; md = 32*pw groups, spr = 40*pw groups):
+//   k_group_max   corr -> GM (unfused path only; the fused front end emits GM itself)
+//   k_sync_nodes  coarse: a group can hold a terminal only if GM[g] is not exceeded by the
+//                 next md/GS-1 group maxima; fine: exact test on the few candidates;
+//                 emits terminal words (fallback input) and ordered node-terminal lists
+//   k_sync_orbit  one workgroup: gathers the node terminals into LDS, builds the
+//                 functional graph over start nodes, extracts the orbit of the root by
+//                 pointer doubling, writes the peak list and the result record; falls
+//                 back to a sequential walk over the terminal words when a capacity is
+//                 exceeded (pathological inputs, very long recordings).
+#include "apt_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+namespace apt::gpu {
+
+namespace {
+
+constexpr int GS = 52;
+constexpr uint64_t kGroupMask = (1ull << GS) - 1;
+constexpr float kNegInf = -__builtin_huge_valf();
+
+// ------------------------------------------------------------------ k_group_max
+__global__ void __launch_bounds__(256)
+k_group_max(const float *__restrict__ corr, uint64_t n_corr, float *__restrict__ gm, uint32_t ng)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    const uint64_t base = static_cast<uint64_t>(g) * GS;
+    float mx = kNegInf;
+    for (int o = 0; o < GS; ++o) {
+        const uint64_t i = base + o;
+        if (i < n_corr) {
+            float v = corr[i];
+            if (i == 0 && !(v > 0.f)) v = 0.f;
+            mx = fmaxf(mx, v);
+        }
+    }
+    gm[g] = mx;
+}
+
+// ------------------------------------------------------------------ k_sync_nodes
+constexpr int kNodesThreads = 256;
+constexpr int kChunkGroups = 256;  // own groups per workgroup
+constexpr int kRMax = 416;         // md/GS <= 416  (work_rate <= 54080)
+constexpr int kSlotCap = 96;       // node terminals kept per chunk before "overflow"
+
+__global__ void __launch_bounds__(kNodesThreads)
+k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict__ corr,
+             uint64_t n_corr, uint32_t r_groups /* md/GS */, uint32_t grid_groups /* spr/GS */,
+             uint64_t *__restrict__ words_out, uint32_t *__restrict__ slot_nt,
+             uint32_t *__restrict__ slot_cnt, uint32_t *__restrict__ flags)
+{
+    // window of groups [gw0, gw0 + nwin): gw0 = g0 - R - 1, nwin = CG + R + 1
+    __shared__ float s_gm[kChunkGroups + 2 * kRMax + 2];
+    __shared__ float s_wm[kChunkGroups + kRMax + 1];
+    __shared__ uint64_t s_words[kChunkGroups + kRMax + 1];
+    __shared__ uint16_t s_cand[kChunkGroups + kRMax + 1];
+    __shared__ uint32_t s_ncand;
+    __shared__ uint32_t s_scan[kNodesThreads / 64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int R = static_cast<int>(r_groups);
+    const int64_t g0 = static_cast<int64_t>(blockIdx.x) * kChunkGroups;
+    const int64_t gw0 = g0 - R - 1;
+    const int nwin = kChunkGroups + R + 1;
+    const uint64_t md = static_cast<uint64_t>(R) * GS;
+
+    if (tid == 0) s_ncand = 0;
+    for (int q = tid; q < nwin + R; q += kNodesThreads) {
+        const int64_t g = gw0 + q;
+        s_gm[q] = (g >= 0 && g < static_cast<int64_t>(ng)) ? gm[g] : kNegInf;
+    }
+    __syncthreads();
+
+    // coarse: WM[g] = max(GM[g+1 .. g+R-1]) — the full groups inside every window of group g
+    for (int q = tid; q < nwin; q += kNodesThreads) {
+        const int64_t g = gw0 + q;
+        float wm = kNegInf;
+        for (int d = 1; d < R; ++d) wm = fmaxf(wm, s_gm[q + d]);
+        s_wm[q] = wm;
+        s_words[q] = 0ull;
+        const bool valid = g >= 0 && g < static_cast<int64_t>(ng);
+        if (valid && !(wm > s_gm[q])) s_cand[atomicAdd(&s_ncand, 1u)] = static_cast<uint16_t>(q);
+    }
+    __syncthreads();
+
+    // fine: exact terminal test for the candidate groups, one wave per candidate
+    const uint32_t ncand = s_ncand;
+    for (uint32_t ci = wave; ci < ncand; ci += kNodesThreads / 64) {
+        const int q = s_cand[ci];
+        const int64_t g = gw0 + q;
+        const uint64_t i = static_cast<uint64_t>(g) * GS + lane;
+        float c = kNegInf;
+        const bool in = lane < GS && i < n_corr;
+        if (in) {
+            c = corr[i];
+            if (i == 0 && !(c > 0.f)) c = 0.f;
+        }
+        float c2 = kNegInf;
+        if (lane < GS && i + md < n_corr) c2 = corr[i + md];
+        // suffix max over lanes > lane (rest of this group)
+        float sfx = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_down(sfx, d, 64);
+            if (lane + d < 64) sfx = fmaxf(sfx, o);
+        }
+        float sfx_ex = __shfl_down(sfx, 1, 64);
+        if (lane == 63) sfx_ex = kNegInf;
+        // prefix max over lanes <= lane of the group md positions ahead
+        float pfx = c2;
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_up(pfx, d, 64);
+            if (lane >= d) pfx = fmaxf(pfx, o);
+        }
+        const float wmax = fmaxf(fmaxf(sfx_ex, s_wm[q]), pfx);
+        const bool term = in && !(wmax > c);
+        const unsigned long long word = __ballot(term) & kGroupMask;
+        if (lane == 0) s_words[q] = word;
+    }
+    __syncthreads();
+
+    // node terminals of the own groups: heads, terminals whose (t - md - 1) is a terminal,
+    // terminals on the grid
+    const int q = tid + R + 1;  // own group index inside the window
+    const int64_t g = g0 + tid;
+    uint64_t nw = 0;
+    if (g < static_cast<int64_t>(ng)) {
+        const uint64_t w = s_words[q];
+        const uint64_t prev_bit = s_words[q - 1] >> (GS - 1);
+        const uint64_t heads = w & ~(((w << 1) | prev_bit) & kGroupMask);
+        const uint64_t shifted = ((s_words[q - R] << 1) | (s_words[q - R - 1] >> (GS - 1))) & kGroupMask;
+        const uint64_t on_grid = (g % grid_groups == 0) ? 1ull : 0ull;
+        nw = w & (heads | shifted | on_grid);
+        words_out[g] = w;
+    }
+    // ordered compaction of the node-terminal positions of this chunk
+    const uint32_t cnt = static_cast<uint32_t>(__popcll(nw));
+    uint32_t inc = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_scan[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int wv = 0; wv < wave; ++wv) base += s_scan[wv];
+    uint32_t total = 0;
+    for (int wv = 0; wv < kNodesThreads / 64; ++wv) total += s_scan[wv];
+    uint32_t ofs = base + inc - cnt;
+    uint64_t bitsleft = nw;
+    while (bitsleft) {
+        const int b = __ffsll(static_cast<long long>(bitsleft)) - 1;
+        bitsleft &= bitsleft - 1;
+        if (ofs < kSlotCap)
+            slot_nt[static_cast<uint64_t>(blockIdx.x) * kSlotCap + ofs] =
+                static_cast<uint32_t>(static_cast<uint64_t>(g) * GS + b);
+        ++ofs;
+    }
+    if (tid == 0) {
+        slot_cnt[blockIdx.x] = total;
+        if (total > kSlotCap) atomicOr(&flags[0], 1u);
+    }
+}
+
+// ------------------------------------------------------------------ k_sync_orbit
+constexpr int kOrbitThreads = 1024;
+constexpr int kNtCap = 12288;   // node terminals held in LDS
+constexpr int kCellCap = 8192;  // image rows (grid cells) handled by the doubling path
+constexpr int kNodeCap = kNtCap + kCellCap + 2;
+constexpr int kMaxChunks = 16384;
+
+struct OrbitGeom {
+    uint64_t n_corr, work_len;
+    uint32_t spr, md;
+};
+
+// first terminal at or after s in the 52-bit group words (the fallback walk)
+__device__ __forceinline__ uint64_t first_terminal52(const uint64_t *__restrict__ words,
+                                                     uint64_t n_groups, uint64_t s)
+{
+    const int lane = threadIdx.x & 63;
+    uint64_t g0 = s / GS;
+    const uint32_t sh = static_cast<uint32_t>(s % GS);
+    bool first = true;
+    while (true) {
+        const uint64_t gi = g0 + lane;
+        uint64_t word = (gi < n_groups) ? words[gi] : 0ull;
+        if (first && lane == 0) word &= (~0ull) << sh;
+        const unsigned long long any = __ballot(word != 0ull);
+        if (any) {
+            const int src = __ffsll(static_cast<long long>(any)) - 1;
+            const uint64_t pos = gi * GS + (__ffsll(static_cast<long long>(word)) - 1);
+            return __shfl(pos, src, 64);
+        }
+        first = false;
+        g0 += 64;
+        if (g0 >= n_groups) return ~0ull;  // cannot happen: position n_corr-1 is a terminal
+    }
+}
+
+// sequential orbit over the terminal words, one wave (any input, any size)
+__device__ void orbit_walk52(const uint64_t *__restrict__ words, const OrbitGeom &gq,
+                             uint32_t *__restrict__ peaks, uint32_t peaks_cap,
+                             Result *__restrict__ res)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t n_groups = (gq.n_corr + GS - 1) / GS;
+    const uint64_t spr = gq.spr, md = gq.md;
+    uint64_t len = 1;
+    uint64_t u = 0;
+    if (gq.n_corr > 0) u = first_terminal52(words, n_groups, 0);
+    if (lane == 0 && peaks_cap > 0) peaks[0] = static_cast<uint32_t>(u);
+    uint64_t fit = (u + spr < gq.work_len) ? 1 : 0;
+    uint64_t last_fit = fit;
+    while (gq.n_corr > 0) {
+        const uint64_t a = u + md + 1;
+        const uint64_t b = (len + 1) * spr;
+        const uint64_t s = a > b ? a : b;
+        if (s >= gq.n_corr) break;
+        const uint64_t c = s / spr;
+        for (uint64_t q = len + lane; q + 1 < c; q += 64)
+            if (q < peaks_cap) peaks[q] = static_cast<uint32_t>(s);
+        if (s + spr < gq.work_len) fit += c - len - 1;
+        u = first_terminal52(words, n_groups, s);
+        if (lane == 0 && c - 1 < peaks_cap) peaks[c - 1] = static_cast<uint32_t>(u);
+        last_fit = (u + spr < gq.work_len) ? 1 : 0;
+        fit += last_fit;
+        len = c;
+    }
+    if (lane == 0) {
+        const bool few = len < 5;  // decode.rs:112-118
+        res->status = few ? 1 : 0;
+        res->reason = few ? 2 : 0;
+        res->n_sync = static_cast<uint32_t>(len);
+        res->n_rows = few ? 0 : static_cast<uint32_t>(fit - last_fit);
+        res->work_len = gq.work_len;
+        res->n_out = few ? 0 : (fit - last_fit) * 2080u;
+    }
+}
+
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint64_t key)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(kOrbitThreads)
+k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ slot_nt,
+             const uint32_t *__restrict__ slot_cnt, uint32_t n_chunks,
+             uint32_t *__restrict__ flags, OrbitGeom gq, uint32_t *__restrict__ peaks,
+             uint32_t peaks_cap, Result *__restrict__ res, int force_walk)
+{
+    extern __shared__ uint32_t lds_u32[];
+    uint32_t *s_nt = lds_u32;                                         // [kNtCap]
+    uint16_t *s_ja = reinterpret_cast<uint16_t *>(s_nt + kNtCap);     // [kNodeCap]
+    uint16_t *s_jb = s_ja + kNodeCap;                                 // [kNodeCap]
+    uint16_t *s_path = s_jb + kNodeCap;                               // [kCellCap + 2]
+    __shared__ uint32_t s_wave[kOrbitThreads / 64];
+    __shared__ uint32_t s_total;
+    __shared__ uint32_t s_plen;
+    __shared__ unsigned long long s_fit;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const uint64_t spr = gq.spr, md = gq.md, n_corr = gq.n_corr;
+
+    // number of grid cells that can hold a start: c in [2, kc]
+    const uint64_t kc = n_corr ? (n_corr - 1) / spr : 0;
+    bool walk = force_walk != 0 || flags[0] != 0 || kc + 2 > kCellCap || n_chunks > kMaxChunks ||
+                n_corr == 0;
+
+    // ---- gather the per-chunk node-terminal lists into one sorted LDS array
+    uint32_t total = 0;
+    if (!walk) {
+        // exclusive scan of slot_cnt in strips of `per`
+        const uint32_t per = (n_chunks + kOrbitThreads - 1) / kOrbitThreads;
+        const uint32_t c_lo = tid * per;
+        uint32_t mine = 0;
+        for (uint32_t e = 0; e < per; ++e)
+            if (c_lo + e < n_chunks) mine += slot_cnt[c_lo + e];
+        uint32_t inc = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int wv = 0; wv < wave; ++wv) base += s_wave[wv];
+        if (tid == kOrbitThreads - 1) s_total = base + inc;
+        __syncthreads();
+        total = s_total;
+        if (total > kNtCap || total == 0) {
+            walk = true;  // uniform: s_total is shared
+        } else {
+            uint32_t ofs = base + inc - mine;
+            for (uint32_t e = 0; e < per; ++e) {
+                const uint32_t ch = c_lo + e;
+                if (ch >= n_chunks) break;
+                const uint32_t cnt = slot_cnt[ch];
+                for (uint32_t k = 0; k < cnt; ++k)
+                    s_nt[ofs + k] = slot_nt[static_cast<uint64_t>(ch) * kSlotCap + k];
+                ofs += cnt;
+            }
+        }
+        __syncthreads();
+    }
+
+    if (walk) {
+        if (wave == 0) orbit_walk52(words, gq, peaks, peaks_cap, res);
+        if (tid == 0) {
+            flags[1] = 1u;  // report which path ran
+            flags[0] = 0u;  // re-arm the overflow flag for the next decode
+        }
+        return;
+    }
+
+    // ---- nodes: 0 = root, 1 .. ng = grid cells 2 .. kc, then one per node terminal, END
+    const uint32_t n_grid = kc >= 2 ? static_cast<uint32_t>(kc - 1) : 0;
+    const uint32_t base_d = 1 + n_grid;
+    const uint32_t n_nodes = base_d + total + 1;
+    const uint32_t END = n_nodes - 1;
+
+    auto node_start = [&](uint32_t v, uint64_t *cell) -> uint64_t {
+        // start position and the cell used for the "(cell+1)*spr" term
+        if (v == 0) { *cell = 1; return 0; }
+        if (v < base_d) { *cell = v + 1; return static_cast<uint64_t>(v + 1) * spr; }
+        const uint64_t s = static_cast<uint64_t>(s_nt[v - base_d]) + md + 1;
+        *cell = s / spr;
+        return s;
+    };
+
+    for (uint32_t v = tid; v < n_nodes; v += kOrbitThreads) {
+        uint32_t nx = END;
+        if (v != END) {
+            uint64_t cell;
+            const uint64_t s = node_start(v, &cell);
+            if (s < n_corr) {
+                uint32_t ui = lower_bound_u32(s_nt, total, s);  // exists: see fact (3)
+                if (ui >= total) ui = total - 1;
+                const uint64_t u = s_nt[ui];
+                const uint64_t a = u + md + 1;
+                const uint64_t b = (cell + 1) * spr;
+                const uint64_t s2 = a > b ? a : b;
+                if (s2 < n_corr) nx = (a >= b) ? base_d + ui : static_cast<uint32_t>(cell);  // grid(cell+1) = id cell
+            }
+        }
+        s_ja[v] = static_cast<uint16_t>(nx);
+    }
+    if (tid == 0) s_path[0] = 0;
+    __syncthreads();
+
+    // ---- orbit of the root by pointer doubling: path[m + 2^r] = J_r[path[m]], J_{r+1} = J_r o J_r
+    const uint32_t path_cap = static_cast<uint32_t>(kc) + 2;  // root + at most one start per cell
+    uint16_t *ja = s_ja, *jb = s_jb;
+    for (uint32_t span = 1; span < path_cap; span <<= 1) {
+        for (uint32_t mI = tid; mI < span && mI + span < path_cap; mI += kOrbitThreads)
+            s_path[mI + span] = ja[s_path[mI]];
+        for (uint32_t v = tid; v < n_nodes; v += kOrbitThreads) jb[v] = ja[ja[v]];
+        __syncthreads();
+        uint16_t *t = ja; ja = jb; jb = t;
+    }
+
+    // ---- peak list: path[k] (k >= 1) starts at s in cell c; pushes fill
+    // peaks[cell(prev) .. c-2] with s and peaks[c-1] with u = firstT(s)
+    if (tid == 0) { s_plen = 1; s_fit = 0ull; }
+    __syncthreads();
+    unsigned long long fit_local = 0;
+    for (uint32_t k = tid; k < path_cap; k += kOrbitThreads) {
+        const uint32_t v = s_path[k];
+        if (v == END) continue;
+        uint64_t cell;
+        const uint64_t s = node_start(v, &cell);
+        uint32_t ui = (v == 0) ? 0u : lower_bound_u32(s_nt, total, s);
+        if (ui >= total) ui = total - 1;
+        const uint64_t u = s_nt[ui];
+        const bool is_last = (k + 1 >= path_cap) || s_path[k + 1] == END;
+        if (k == 0) {
+            if (peaks_cap > 0) peaks[0] = static_cast<uint32_t>(u);
+            if (!is_last && u + spr < gq.work_len) ++fit_local;
+            if (is_last) s_plen = 1;
+            continue;
+        }
+        uint64_t pcell;
+        (void)node_start(s_path[k - 1], &pcell);
+        // cell of the previous start: for the root the list holds 1 entry
+        const uint64_t c_prev = (k - 1 == 0) ? 1 : pcell;
+        const uint64_t c = s / spr;
+        for (uint64_t qv = c_prev; qv + 1 < c; ++qv)
+            if (qv < peaks_cap) peaks[qv] = static_cast<uint32_t>(s);
+        if (c - 1 < peaks_cap) peaks[c - 1] = static_cast<uint32_t>(u);
+        if (s + spr < gq.work_len) fit_local += c - c_prev - 1;
+        if (!is_last && u + spr < gq.work_len) ++fit_local;  // the last peak is dropped
+        if (is_last) s_plen = static_cast<uint32_t>(c);
+    }
+    atomicAdd(&s_fit, fit_local);
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t len = s_plen;
+        const bool few = len < 5;  // decode.rs:112-118
+        const uint64_t rows = s_fit;
+        res->status = few ? 1 : 0;
+        res->reason = few ? 2 : 0;
+        res->n_sync = len;
+        res->n_rows = few ? 0 : static_cast<uint32_t>(rows);
+        res->work_len = gq.work_len;
+        res->n_out = few ? 0 : rows * 2080u;
+        flags[1] = 0u;
+        flags[0] = 0u;
+    }
+}
+
+}  // namespace
+
+uint32_t sync_group_size() { return GS; }
+uint32_t sync_chunk_groups() { return kChunkGroups; }
+uint32_t sync_slot_cap() { return kSlotCap; }
+
+void group_max(hipStream_t s, const float *corr, uint64_t n_corr, float *gm)
+{
+    const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
+    if (ng == 0) return;
+    hipLaunchKernelGGL(k_group_max, dim3((ng + 255) / 256), dim3(256), 0, s, corr, n_corr, gm, ng);
+}
+
+void sync_nodes(hipStream_t s, const float *gm, const float *corr, uint64_t n_corr, uint32_t spr,
+                uint32_t md, uint64_t *words, uint32_t *slot_nt, uint32_t *slot_cnt, uint32_t *flags)
+{
+    const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
+    if (ng == 0) return;
+    const uint32_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
+    hipLaunchKernelGGL(k_sync_nodes, dim3(chunks), dim3(kNodesThreads), 0, s, gm, ng, corr, n_corr,
+                       md / GS, spr / GS, words, slot_nt, slot_cnt, flags);
+}
+
+void sync_orbit(hipStream_t s, const uint64_t *words, const uint32_t *slot_nt,
+                const uint32_t *slot_cnt, uint32_t *flags, uint64_t n_corr, uint64_t work_len,
+                uint32_t spr, uint32_t md, uint32_t *peaks, uint32_t peaks_cap, Result *res,
+                bool force_walk)
+{
+    const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
+    const uint32_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
+    const size_t lds = static_cast<size_t>(kNtCap) * 4 + static_cast<size_t>(kNodeCap) * 2 * 2 +
+                       static_cast<size_t>(kCellCap + 2) * 2 + 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_orbit),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        attr_set = true;
+    }
+    OrbitGeom gq{n_corr, work_len, spr, md};
+    hipLaunchKernelGGL(k_sync_orbit, dim3(1), dim3(kOrbitThreads), lds, s, words, slot_nt, slot_cnt,
+                       chunks, flags, gq, peaks, peaks_cap, res, force_walk ? 1 : 0);
+}
+
+}  // namespace apt::gpu

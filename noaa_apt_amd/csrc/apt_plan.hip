@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace apt {
@@ -98,6 +99,7 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     plan->sync = sync;
     plan->max_samples = max_samples;
     plan->max_batch = max_batch;
+    if (const char *e = std::getenv("APTGPU_FORCE_WALK")) plan->force_walk = e[0] == '1';
 
     // decode.rs:55 — u32 arithmetic; the reference would panic on overflow
     const uint64_t spr64 = static_cast<uint64_t>(PX_PER_ROW) * settings.work_rate;
@@ -190,6 +192,16 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     upload(plan->d_taps_resample, plan->taps_resample);
     upload(plan->d_taps_lowpass, plan->taps_lowpass);
     upload(plan->d_one, Signal{1.f});
+    plan->fused = plan->mode == APTGPU_MODE_STRICT && plan->l > 1 &&
+                  gpu::fused_supported(plan->l, plan->m, static_cast<uint32_t>(plan->taps_resample.size()),
+                                       static_cast<uint32_t>(plan->taps_lowpass.size()), plan->pw) &&
+                  plan->work_is_multiple;
+    if (plan->fused) {
+        const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
+        Signal hs(static_cast<size_t>(gpu::fused_taps_per_branch(plan->l, t1)) * plan->l + 16, 0.f);
+        gpu::fused_branch_taps(plan->l, plan->m, plan->taps_resample.data(), t1, hs.data());
+        upload(plan->d_taps_branch, hs);
+    }
 
     plan->slots.resize(static_cast<size_t>(max_batch));
     const uint64_t w = plan->max_work_len;
@@ -201,6 +213,14 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
             sl.correlation.alloc(w + 64);
             sl.bits.alloc(w / 64 + plan->md / 64 + 4);
             sl.peaks.alloc(plan->max_rows + 2);
+            const uint64_t ng = w / gpu::sync_group_size() + 2;
+            const uint64_t chunks = ng / gpu::sync_chunk_groups() + 2;
+            sl.gm.alloc(ng + 64);
+            sl.words.alloc(ng + 64);
+            sl.slot_nt.alloc(chunks * gpu::sync_slot_cap());
+            sl.slot_cnt.alloc(chunks);
+            sl.flags.alloc(4);
+            hip_check(hipMemset(sl.flags.ptr, 0, 16), "hipMemset flags");
         }
     }
     plan->d_results.alloc(static_cast<size_t>(max_batch));
@@ -227,7 +247,7 @@ uint64_t aptgpu_plan::out_len_nosync(uint64_t work_len) const
 // ------------------------------------------------------------------ pipeline
 // The kernel sequence of decode() for one recording already in HBM.
 void aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows,
-                          uint64_t rows_cap_floats, bool /*keep_steps*/)
+                          uint64_t rows_cap_floats, bool keep_steps)
 {
     using namespace apt::gpu;
     Slot &sl = slots[static_cast<size_t>(i)];
@@ -246,6 +266,17 @@ void aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_row
         return;
     }
 
+    const bool use_fused = fused && !keep_steps;
+    if (use_fused) {
+        // 1-3 fused: resample -> envelope -> low-pass in one launch (apt_kernels_fused.hip)
+        timed("fused_front_end", [&] {
+            fused_front_end(stream, l, m, static_cast<uint32_t>(taps_resample.size()),
+                            static_cast<uint32_t>(taps_lowpass.size()), pw, d_signal, n,
+                            d_taps_branch.ptr, d_taps_lowpass.ptr, cosphi2, sinphi, sl.filtered.ptr,
+                            (sync && work_is_multiple) ? sl.correlation.ptr : nullptr,
+                            (sync && work_is_multiple) ? sl.gm.ptr : nullptr, w, w - n_sync_taps);
+        });
+    } else {
     // 1. resample to work_rate (dsp.rs:62-126)
     if (l > 1) {
         timed("resample_generic", [&] {
@@ -266,6 +297,7 @@ void aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_row
         fir_decimate(stream, sl.demodulated.ptr, w, d_taps_lowpass.ptr,
                      static_cast<uint32_t>(taps_lowpass.size()), 1, sl.filtered.ptr, w);
     });
+    }
 
     if (sync && !work_is_multiple) {
         // generate_sync_frame, decode.rs:172-176
@@ -273,12 +305,28 @@ void aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_row
     } else if (sync) {
         // 4. find_sync (decode.rs:204-263): correlation, terminal flags, orbit
         const uint64_t n_corr = w - n_sync_taps;  // w >= 10*spr > 38*pw
-        timed("correlate", [&] { correlate(stream, sl.filtered.ptr, n_corr, pw, sl.correlation.ptr); });
-        timed("terminals", [&] { terminals(stream, sl.correlation.ptr, n_corr, md, sl.bits.ptr); });
-        timed("orbit_walk", [&] {
-            orbit_walk(stream, sl.bits.ptr, n_corr, w, spr, md, sl.peaks.ptr,
-                       static_cast<uint32_t>(sl.peaks.count), res);
-        });
+        if (!use_fused)
+            timed("correlate", [&] { correlate(stream, sl.filtered.ptr, n_corr, pw, sl.correlation.ptr); });
+        if (mode == APTGPU_MODE_GENERIC) {
+            // reference-shaped picker: full sliding-window terminals + sequential orbit
+            timed("terminals", [&] { terminals(stream, sl.correlation.ptr, n_corr, md, sl.bits.ptr); });
+            timed("orbit_walk", [&] {
+                orbit_walk(stream, sl.bits.ptr, n_corr, w, spr, md, sl.peaks.ptr,
+                           static_cast<uint32_t>(sl.peaks.count), res);
+            });
+        } else {
+            if (!use_fused)
+                timed("group_max", [&] { group_max(stream, sl.correlation.ptr, n_corr, sl.gm.ptr); });
+            timed("sync_nodes", [&] {
+                sync_nodes(stream, sl.gm.ptr, sl.correlation.ptr, n_corr, spr, md, sl.words.ptr,
+                           sl.slot_nt.ptr, sl.slot_cnt.ptr, sl.flags.ptr);
+            });
+            timed("sync_orbit", [&] {
+                sync_orbit(stream, sl.words.ptr, sl.slot_nt.ptr, sl.slot_cnt.ptr, sl.flags.ptr, n_corr,
+                           w, spr, md, sl.peaks.ptr, static_cast<uint32_t>(sl.peaks.count), res,
+                           force_walk);
+            });
+        }
         // 5. aligned rows + final /pw (decode.rs:120-134,158-159)
         uint64_t rows_cap = rows_cap_floats / 2080u;
         if (rows_cap > max_rows) rows_cap = max_rows;

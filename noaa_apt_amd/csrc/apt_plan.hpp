@@ -104,12 +104,16 @@ struct aptgpu_plan {
     uint32_t max_rows = 0;
     int max_batch = 1;
     bool fused = false;
+    bool force_walk = false;  // APTGPU_FORCE_WALK=1: exercise the picker's fallback path
 
-    apt::DeviceBuffer<float> d_taps_resample, d_taps_lowpass, d_one;
+    apt::DeviceBuffer<float> d_taps_resample, d_taps_lowpass, d_one, d_taps_branch;
     struct Slot {
         apt::DeviceBuffer<float> resampled, demodulated, filtered, correlation;
-        apt::DeviceBuffer<uint64_t> bits;
+        apt::DeviceBuffer<uint64_t> bits;     // 64-bit terminal words (generic-mode picker)
         apt::DeviceBuffer<uint32_t> peaks;
+        apt::DeviceBuffer<float> gm;          // per-group maxima of the correlation
+        apt::DeviceBuffer<uint64_t> words;    // 52-bit terminal words
+        apt::DeviceBuffer<uint32_t> slot_nt, slot_cnt, flags;
     };
     std::vector<Slot> slots;
     apt::DeviceBuffer<apt::gpu::Result> d_results;

@@ -138,6 +138,18 @@ def test_find_sync_adversarial(ctx, oracle, name, work_rate):
     assert got_pos.tolist() == want_pos.tolist()
 
 
+@pytest.mark.parametrize("name", ["zeros", "noise", "ramp_up", "plateaus", "rising_sine"])
+def test_find_sync_alternate_pickers(oracle, name, monkeypatch):
+    """The same answers from the reference-shaped picker (MODE_GENERIC: full sliding-window
+    terminals + sequential orbit) and from the doubling picker's fallback walk."""
+    f = _fsm_cases()[name]
+    want = oracle.find_sync(f, 4160).tolist()
+    gen = apt.Context(device=0, mode=apt.MODE_GENERIC)
+    assert apt.find_sync(gen, f, apt.Rate.hz(4160)).tolist() == want
+    monkeypatch.setenv("APTGPU_FORCE_WALK", "1")
+    assert apt.find_sync(apt.Context(device=0), f, apt.Rate.hz(4160)).tolist() == want
+
+
 def test_find_sync_short_and_edges(ctx, oracle):
     rng = np.random.default_rng(3)
     for n in (38, 39, 100, 1664, 1665, 2080, 2081, 4160, 4161, 5000):
@@ -180,6 +192,21 @@ def test_decode_bitexact(ctx, oracle, rate, seconds, seed, profile, kw, sync):
         assert stats.n_sync == st["sync_pos"].size
     assert_bitexact(got, want, f"decode {rate} {profile} sync={sync}")
     assert got.size % 2080 == 0
+
+
+@pytest.mark.parametrize("mode", ["generic", "walk"])
+def test_decode_alternate_paths(oracle, mode, monkeypatch):
+    """decode() through the unfused generic kernels, and with the picker's fallback walk."""
+    x = synth_apt(48000, 14, 2)
+    want = oracle.decode(x, 48000, True)
+    if mode == "walk":
+        monkeypatch.setenv("APTGPU_FORCE_WALK", "1")
+        c = apt.Context(device=0)
+    else:
+        c = apt.Context(device=0, mode=apt.MODE_GENERIC)
+    got, st = apt.decode(c, apt.Settings(), x, apt.Rate.hz(48000), True, return_stats=True)
+    assert_bitexact(got, want, f"decode via {mode}")
+    assert st.fused == (1 if mode == "walk" else 0)
 
 
 def test_decode_noise_fixture_like(ctx, oracle):
