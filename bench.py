@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--profile", default="standard")
     ap.add_argument("--mode", default="strict", choices=["strict", "generic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="experiment: leave the per-kernel HIP events out of the timed region")
     args = ap.parse_args()
 
     import torch
@@ -85,7 +87,7 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        plan.enable_timing(True)
+        plan.enable_timing(not args.no_kernel_timing)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -97,17 +99,11 @@ def main():
         ktimes = plan.collect_timing()
         plan.enable_timing(False)
         res = plan.results(1)[0]
+        pflags = plan.read_internal("picker_flags", np.uint32, 32)
 
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(n)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_samples_per_step = float(tot.item())
-    else:
-        total_samples_per_step = float(n)
+    from noaa_apt_amd import shard
+    # whole-job figures: MAX elapsed over ranks, SUM of samples over ranks (no other collective)
+    elapsed, total_samples_per_step = shard.reduce_job(t1 - t0, float(n), device=dev)
 
     if res.status != 0:
         raise SystemExit(f"decode failed on rank {rank}: status {res.status} reason {res.reason}")
@@ -147,6 +143,8 @@ def main():
                 "rows": int(res.n_rows),
                 "n_sync": int(res.n_sync),
                 "input_resident_in_hbm": True,
+                "picker": {"fallback_walk": int(pflags[1]), "node_terminals": int(pflags[2]),
+                           "nodes": int(pflags[3]), "cycle_stamps": [int(v) for v in pflags[8:13]]},
             },
             "roofline": {
                 "bound": "hbm",

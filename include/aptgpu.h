@@ -187,6 +187,17 @@ int aptgpu_plan_enable_timing(aptgpu_plan *plan, int on);
 int aptgpu_plan_collect_timing(aptgpu_plan *plan, aptgpu_kernel_time *out, size_t cap,
                                size_t *n_out);
 
+/* Introspection: copies one of the plan's internal HBM buffers of recording slot i to the
+ * host after synchronising — the device-side counterpart of the intermediate signals the
+ * reference exports through Context::step (src/context.rs:132-211).  Names: "filtered"
+ * (f32, "filter_result"), "correlation" (f32, "sync_correlation"), "group_max" (f32, maxima
+ * of the correlation over groups of 52 positions), "terminal_words" (u64), "peaks" (u32,
+ * find_sync positions), "picker_flags" (u32[32]: [0] list overflow, [1] 1 = sequential
+ * fallback ran, [8..] cycle stamps of the picker kernels).  Writes min(bytes, size) bytes
+ * and returns the buffer's size in *size_out. */
+int aptgpu_plan_read_internal(aptgpu_plan *plan, int i, const char *name, void *host_out,
+                              size_t bytes, size_t *size_out);
+
 /* ====================================================================== */
 /* 3. the dsp.rs / filters.rs / decode.rs building blocks (host buffers)    */
 /* ====================================================================== */

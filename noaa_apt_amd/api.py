@@ -158,6 +158,7 @@ def lib():
     L.aptgpu_plan_results.argtypes = [vp, i32, C.POINTER(Result)]
     L.aptgpu_plan_sync_positions.argtypes = [vp, i32, _u64p, sz, C.POINTER(sz)]
     L.aptgpu_plan_synchronize.argtypes = [vp]
+    L.aptgpu_plan_read_internal.argtypes = [vp, i32, C.c_char_p, vp, sz, C.POINTER(sz)]
     L.aptgpu_plan_enable_timing.argtypes = [vp, i32]
     L.aptgpu_plan_collect_timing.argtypes = [vp, C.POINTER(KernelTime), sz, C.POINTER(sz)]
     L.aptgpu_filter_design.argtypes = [C.POINTER(_CFilter), C.POINTER(_f32p), C.POINTER(sz)]
@@ -466,6 +467,14 @@ class Plan:
         n = C.c_size_t()
         _check(lib().aptgpu_plan_sync_positions(self._p, i, buf, cap, C.byref(n)))
         return np.array(buf[:min(cap, n.value)], dtype=np.uint64)
+
+    def read_internal(self, name, dtype, count, i=0):
+        """Download `count` elements of an internal HBM buffer (see aptgpu_plan_read_internal)."""
+        out = np.zeros(int(count), dtype=dtype)
+        size = C.c_size_t()
+        _check(lib().aptgpu_plan_read_internal(self._p, i, name.encode(), out.ctypes.data_as(C.c_void_p),
+                                               out.nbytes, C.byref(size)))
+        return out
 
     def synchronize(self):
         _check(lib().aptgpu_plan_synchronize(self._p))

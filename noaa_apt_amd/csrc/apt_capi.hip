@@ -226,6 +226,31 @@ int aptgpu_plan_collect_timing(aptgpu_plan *plan, aptgpu_kernel_time *out, size_
     }
 }
 
+int aptgpu_plan_read_internal(aptgpu_plan *plan, int i, const char *name, void *host_out,
+                              size_t bytes, size_t *size_out)
+{
+    if (!plan || !name || i < 0 || i >= plan->max_batch) return APTGPU_ERR_INVALID;
+    aptgpu_plan::Slot &sl = plan->slots[static_cast<size_t>(i)];
+    const void *src = nullptr;
+    size_t size = 0;
+    const std::string n(name);
+    if (n == "filtered") { src = sl.filtered.ptr; size = sl.filtered.count * sizeof(float); }
+    else if (n == "correlation") { src = sl.correlation.ptr; size = sl.correlation.count * sizeof(float); }
+    else if (n == "group_max") { src = sl.gm.ptr; size = sl.gm.count * sizeof(float); }
+    else if (n == "terminal_words") { src = sl.words.ptr; size = sl.words.count * sizeof(uint64_t); }
+    else if (n == "peaks") { src = sl.peaks.ptr; size = sl.peaks.count * sizeof(uint32_t); }
+    else if (n == "picker_flags") { src = sl.flags.ptr; size = sl.flags.count * sizeof(uint32_t); }
+    else return APTGPU_ERR_INVALID;
+    if (size_out) *size_out = size;
+    (void)hipSetDevice(plan->device);
+    if (hipStreamSynchronize(plan->stream) != hipSuccess) return APTGPU_ERR_HIP;
+    const size_t take = bytes < size ? bytes : size;
+    if (take && host_out && src &&
+        hipMemcpy(host_out, src, take, hipMemcpyDeviceToHost) != hipSuccess)
+        return APTGPU_ERR_HIP;
+    return APTGPU_OK;
+}
+
 // ------------------------------------------------------------------ decode()
 int aptgpu_decode(const aptgpu_context *ctx_in, const aptgpu_settings *settings,
                   const float *signal, size_t n, uint32_t input_rate_hz, int sync,
@@ -622,8 +647,8 @@ int aptgpu_find_sync(const aptgpu_context *ctx, const float *signal, size_t n,
             apt::DeviceBuffer<uint32_t> d_slot, d_cnt, d_flags;
             d_slot.alloc(chunks * apt::gpu::sync_slot_cap());
             d_cnt.alloc(chunks);
-            d_flags.alloc(4);
-            apt::hip_check(hipMemsetAsync(d_flags.ptr, 0, 16, sc.stream), "hipMemsetAsync");
+            d_flags.alloc(32);
+            apt::hip_check(hipMemsetAsync(d_flags.ptr, 0, 32 * sizeof(uint32_t), sc.stream), "hipMemsetAsync");
             const char *fw = std::getenv("APTGPU_FORCE_WALK");
             apt::gpu::group_max(sc.stream, d_c.ptr, n_corr, d_gm.ptr);
             apt::gpu::sync_nodes(sc.stream, d_gm.ptr, d_c.ptr, n_corr, spr, md, d_words.ptr, d_slot.ptr,

@@ -32,6 +32,9 @@ namespace apt::gpu {
 
 namespace {
 
+#ifndef APT_FUSED_MIN_WAVES
+#define APT_FUSED_MIN_WAVES 3
+#endif
 constexpr int kFusedThreads = 256;
 constexpr int kPreThreads = 4;
 constexpr int kOwnThreads = 240;
@@ -89,7 +92,7 @@ __host__ __device__ constexpr bool sync_plus(int j)
 }
 
 template <int L, int M, int T1, int T2, int PW>
-__global__ void __launch_bounds__(kFusedThreads, 3)
+__global__ void __launch_bounds__(kFusedThreads, APT_FUSED_MIN_WAVES)
 k_fused(const float *__restrict__ x, uint64_t n, const float *__restrict__ hs /*[TP][L] step-major*/,
         const float *__restrict__ h2 /*[T2]*/, float cosphi2, float sinphi,
         float *__restrict__ f_out, float *__restrict__ c_out, float *__restrict__ gm_out,
@@ -104,23 +107,32 @@ k_fused(const float *__restrict__ x, uint64_t n, const float *__restrict__ hs /*
     const int tid = threadIdx.x;
     const int64_t tile = blockIdx.x;
     const int64_t o0 = tile * Gm::OWN_K;            // first owned work sample
-    const int64_t k0 = o0 - Gm::PRE_K;              // first work sample of the tile
-    const int64_t a0 = k0 / L;                      // may be negative (tile 0)
-    const int64_t xs0 = a0 * M;                     // first input sample of the tile
+    const int64_t k0 = o0 - Gm::PRE_K;              // first work sample of the tile (< 0 in tile 0)
+    const int64_t xs0 = (k0 / L) * M;               // first input sample of the tile
+    // everything below indexes relative to the tile with 32-bit integers; the global limits
+    // become wave-uniform scalars
+    auto rel = [](int64_t v) -> int { return v < -(1 << 30) ? -(1 << 30) : (v > (1 << 30) ? (1 << 30) : static_cast<int>(v)); };
+    const int x_lo = rel(-xs0);                                   // tile index of input sample 0
+    const int x_hi = rel(static_cast<int64_t>(n) - xs0);          // tile index of input sample n
+    const int k_lo = rel(-k0);                                    // tile index of work sample 0
+    const int k_hi = rel(static_cast<int64_t>(w) - k0);           // tile index of work sample w
+    const int c_hi = rel(static_cast<int64_t>(n_corr) - k0);      // tile index of position n_corr
 
     // ---- stage 0: input tile -> LDS (coalesced 16-byte loads, zero outside [0, n))
-    for (int q = tid * 4; q < Gm::XT_PAD; q += kFusedThreads * 4) {
-        const int64_t g = xs0 + q;
-        float4 v;
-        if (g >= 0 && g + 3 < static_cast<int64_t>(n)) {
-            v = *reinterpret_cast<const float4 *>(x + g);
-        } else {
-            v.x = (g >= 0 && g < static_cast<int64_t>(n)) ? x[g] : 0.f;
-            v.y = (g + 1 >= 0 && g + 1 < static_cast<int64_t>(n)) ? x[g + 1] : 0.f;
-            v.z = (g + 2 >= 0 && g + 2 < static_cast<int64_t>(n)) ? x[g + 2] : 0.f;
-            v.w = (g + 3 >= 0 && g + 3 < static_cast<int64_t>(n)) ? x[g + 3] : 0.f;
+    {
+        const float *xt = x + xs0;  // only dereferenced inside [x_lo, x_hi)
+        for (int q = tid * 4; q < Gm::XT_PAD; q += kFusedThreads * 4) {
+            float4 v;
+            if (q >= x_lo && q + 3 < x_hi) {
+                v = *reinterpret_cast<const float4 *>(xt + q);
+            } else {
+                v.x = (q >= x_lo && q < x_hi) ? xt[q] : 0.f;
+                v.y = (q + 1 >= x_lo && q + 1 < x_hi) ? xt[q + 1] : 0.f;
+                v.z = (q + 2 >= x_lo && q + 2 < x_hi) ? xt[q + 2] : 0.f;
+                v.w = (q + 3 >= x_lo && q + 3 < x_hi) ? xt[q + 3] : 0.f;
+            }
+            *reinterpret_cast<float4 *>(P + q) = v;
         }
-        *reinterpret_cast<float4 *>(P + q) = v;
     }
     __syncthreads();
 
@@ -128,7 +140,8 @@ k_fused(const float *__restrict__ x, uint64_t n, const float *__restrict__ hs /*
     // Tap step i of every branch b reads xw[c_b + i]: a window of CLAST+1 samples sliding
     // by one per step.  The loop is unrolled in chunks of CH steps fenced by scheduling
     // barriers so only ~CLAST+2*CH samples and one chunk of taps are live at a time.
-    const int64_t kt = k0 + static_cast<int64_t>(tid) * L;  // this thread's first work sample
+    const int kq = tid * L;        // this thread's first work sample, tile-relative
+    const int kt = kq - k_lo;      // ... and as a global work-sample index clamped to int
     float r[L];
     {
         constexpr int CH = 4;
@@ -171,10 +184,9 @@ k_fused(const float *__restrict__ x, uint64_t n, const float *__restrict__ hs /*
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-        const bool live = kt >= 0;
 #pragma unroll
         for (int b = 0; b < L; ++b)
-            if (!live || static_cast<uint64_t>(kt + b) >= w) r[b] = 0.f;
+            if (kq + b < k_lo || kq + b >= k_hi) r[b] = 0.f;
     }
     __syncthreads();  // everyone is done reading the x tile
 #pragma unroll
@@ -188,7 +200,7 @@ k_fused(const float *__restrict__ x, uint64_t n, const float *__restrict__ hs /*
         for (int b = 0; b < L; ++b) {
             const float curr = r[b];
             float d = 0.f;
-            if (kt + b >= 1) {
+            if (kq + b > k_lo) {  // global index >= 1
                 const float s = (prev * prev) + (curr * curr);
                 const float c = (prev * curr) * cosphi2;
                 d = __builtin_sqrtf(s - c) / sinphi;
@@ -229,13 +241,15 @@ k_fused(const float *__restrict__ x, uint64_t n, const float *__restrict__ hs /*
     __syncthreads();
 
     // owned F -> HBM, coalesced 16-byte stores
-    for (int q = tid * 4; q < Gm::OWN_K; q += kFusedThreads * 4) {
-        const int64_t g = o0 + q;
-        if (g + 3 < static_cast<int64_t>(w)) {
-            *reinterpret_cast<float4 *>(f_out + g) = *reinterpret_cast<const float4 *>(P + Gm::PRE_K + q);
-        } else {
-            for (int e = 0; e < 4; ++e)
-                if (g + e < static_cast<int64_t>(w)) f_out[g + e] = P[Gm::PRE_K + q + e];
+    {
+        float *ft = f_out + o0;
+        for (int q = tid * 4; q < Gm::OWN_K; q += kFusedThreads * 4) {
+            if (Gm::PRE_K + q + 3 < k_hi) {
+                *reinterpret_cast<float4 *>(ft + q) = *reinterpret_cast<const float4 *>(P + Gm::PRE_K + q);
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (Gm::PRE_K + q + e < k_hi) ft[q + e] = P[Gm::PRE_K + q + e];
+            }
         }
     }
 
@@ -275,28 +289,25 @@ k_fused(const float *__restrict__ x, uint64_t n, const float *__restrict__ hs /*
         float mx = kNegInfF;
 #pragma unroll
         for (int b = 0; b < L; ++b) {
-            const int64_t pos = kt + b;
+            const int pq = kq + b;
             float v = c[b];
-            if (pos == 0 && !(v > 0.f)) v = 0.f;  // the picker starts from the peak (0, 0.)
-            if (pos >= 0 && static_cast<uint64_t>(pos) < n_corr) mx = fmaxf(mx, v);
+            if (pq == k_lo && !(v > 0.f)) v = 0.f;  // the picker starts from the peak (0, 0.)
+            if (pq >= k_lo && pq < c_hi) mx = fmaxf(mx, v);
             CS[tid * L + b] = c[b];
         }
         mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-        if ((tid & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads) {
-            const int64_t grp = kt / Gm::GS;
-            if (static_cast<uint64_t>(kt) < n_corr) gm_out[grp] = mx;
-        }
+        if ((tid & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads && kq < c_hi)
+            gm_out[o0 / Gm::GS + (tid - kPreThreads) / 4] = mx;
         __syncthreads();
         // owned C -> HBM, coalesced 16-byte stores (read by the fine stage of the picker)
+        float *ct = c_out + o0;
         for (int q = tid * 4; q < Gm::OWN_K; q += kFusedThreads * 4) {
-            const int64_t g = o0 + q;
-            if (g + 3 < static_cast<int64_t>(n_corr)) {
-                *reinterpret_cast<float4 *>(c_out + g) =
-                    *reinterpret_cast<const float4 *>(CS + Gm::PRE_K + q);
+            if (Gm::PRE_K + q + 3 < c_hi) {
+                *reinterpret_cast<float4 *>(ct + q) = *reinterpret_cast<const float4 *>(CS + Gm::PRE_K + q);
             } else {
                 for (int e = 0; e < 4; ++e)
-                    if (g + e < static_cast<int64_t>(n_corr)) c_out[g + e] = CS[Gm::PRE_K + q + e];
+                    if (Gm::PRE_K + q + e < c_hi) ct[q + e] = CS[Gm::PRE_K + q + e];
             }
         }
     }

@@ -100,8 +100,17 @@ k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict_
     // coarse: WM[g] = max(GM[g+1 .. g+R-1]) — the full groups inside every window of group g
     for (int q = tid; q < nwin; q += kNodesThreads) {
         const int64_t g = gw0 + q;
-        float wm = kNegInf;
-        for (int d = 1; d < R; ++d) wm = fmaxf(wm, s_gm[q + d]);
+        float w0 = kNegInf, w1 = kNegInf, w2 = kNegInf, w3 = kNegInf;
+        int d = 1;
+#pragma unroll 4
+        for (; d + 3 < R; d += 4) {
+            w0 = fmaxf(w0, s_gm[q + d]);
+            w1 = fmaxf(w1, s_gm[q + d + 1]);
+            w2 = fmaxf(w2, s_gm[q + d + 2]);
+            w3 = fmaxf(w3, s_gm[q + d + 3]);
+        }
+        for (; d < R; ++d) w0 = fmaxf(w0, s_gm[q + d]);
+        const float wm = fmaxf(fmaxf(w0, w1), fmaxf(w2, w3));
         s_wm[q] = wm;
         s_words[q] = 0ull;
         const bool valid = g >= 0 && g < static_cast<int64_t>(ng);
@@ -109,38 +118,51 @@ k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict_
     }
     __syncthreads();
 
-    // fine: exact terminal test for the candidate groups, one wave per candidate
+    // fine: exact terminal test for the candidate groups; each wave takes four candidates at
+    // a time so their eight corr loads are in flight together
     const uint32_t ncand = s_ncand;
-    for (uint32_t ci = wave; ci < ncand; ci += kNodesThreads / 64) {
-        const int q = s_cand[ci];
-        const int64_t g = gw0 + q;
-        const uint64_t i = static_cast<uint64_t>(g) * GS + lane;
-        float c = kNegInf;
-        const bool in = lane < GS && i < n_corr;
-        if (in) {
-            c = corr[i];
-            if (i == 0 && !(c > 0.f)) c = 0.f;
+    constexpr int kBatch = 4;
+    for (uint32_t c0 = wave * kBatch; c0 < ncand; c0 += kBatch * (kNodesThreads / 64)) {
+        int qv[kBatch];
+        float cv[kBatch], c2v[kBatch];
+        bool inv[kBatch];
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            const uint32_t ci = c0 + e;
+            qv[e] = (ci < ncand) ? s_cand[ci] : -1;
+            const int64_t g = gw0 + (qv[e] < 0 ? 0 : qv[e]);
+            const uint64_t i = static_cast<uint64_t>(g) * GS + lane;
+            inv[e] = qv[e] >= 0 && lane < GS && i < n_corr;
+            cv[e] = kNegInf;
+            c2v[e] = kNegInf;
+            if (inv[e]) {
+                cv[e] = corr[i];
+                if (i == 0 && !(cv[e] > 0.f)) cv[e] = 0.f;
+                if (i + md < n_corr) c2v[e] = corr[i + md];
+            }
         }
-        float c2 = kNegInf;
-        if (lane < GS && i + md < n_corr) c2 = corr[i + md];
-        // suffix max over lanes > lane (rest of this group)
-        float sfx = c;
-        for (int d = 1; d < 64; d <<= 1) {
-            const float o = __shfl_down(sfx, d, 64);
-            if (lane + d < 64) sfx = fmaxf(sfx, o);
+#pragma unroll
+        for (int e = 0; e < kBatch; ++e) {
+            if (qv[e] < 0) continue;  // wave-uniform
+            // suffix max over lanes > lane (rest of this group)
+            float sfx = cv[e];
+            for (int d = 1; d < 64; d <<= 1) {
+                const float o = __shfl_down(sfx, d, 64);
+                if (lane + d < 64) sfx = fmaxf(sfx, o);
+            }
+            float sfx_ex = __shfl_down(sfx, 1, 64);
+            if (lane == 63) sfx_ex = kNegInf;
+            // prefix max over lanes <= lane of the group md positions ahead
+            float pfx = c2v[e];
+            for (int d = 1; d < 64; d <<= 1) {
+                const float o = __shfl_up(pfx, d, 64);
+                if (lane >= d) pfx = fmaxf(pfx, o);
+            }
+            const float wmax = fmaxf(fmaxf(sfx_ex, s_wm[qv[e]]), pfx);
+            const bool term = inv[e] && !(wmax > cv[e]);
+            const unsigned long long word = __ballot(term) & kGroupMask;
+            if (lane == 0) s_words[qv[e]] = word;
         }
-        float sfx_ex = __shfl_down(sfx, 1, 64);
-        if (lane == 63) sfx_ex = kNegInf;
-        // prefix max over lanes <= lane of the group md positions ahead
-        float pfx = c2;
-        for (int d = 1; d < 64; d <<= 1) {
-            const float o = __shfl_up(pfx, d, 64);
-            if (lane >= d) pfx = fmaxf(pfx, o);
-        }
-        const float wmax = fmaxf(fmaxf(sfx_ex, s_wm[q]), pfx);
-        const bool term = in && !(wmax > c);
-        const unsigned long long word = __ballot(term) & kGroupMask;
-        if (lane == 0) s_words[q] = word;
     }
     __syncthreads();
 
@@ -189,7 +211,7 @@ k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict_
 
 // ------------------------------------------------------------------ k_sync_orbit
 constexpr int kOrbitThreads = 1024;
-constexpr int kNtCap = 12288;   // node terminals held in LDS
+constexpr int kNtCap = 16384;   // node terminals held in LDS
 constexpr int kCellCap = 8192;  // image rows (grid cells) handled by the doubling path
 constexpr int kNodeCap = kNtCap + kCellCap + 2;
 constexpr int kMaxChunks = 16384;
@@ -282,8 +304,8 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
     extern __shared__ uint32_t lds_u32[];
     uint32_t *s_nt = lds_u32;                                         // [kNtCap]
     uint16_t *s_ja = reinterpret_cast<uint16_t *>(s_nt + kNtCap);     // [kNodeCap]
-    uint16_t *s_jb = s_ja + kNodeCap;                                 // [kNodeCap]
-    uint16_t *s_path = s_jb + kNodeCap;                               // [kCellCap + 2]
+    uint16_t *s_path = s_ja + kNodeCap;                               // [kCellCap + 2]
+    uint16_t *s_cell = s_path + (kCellCap + 2);                       // [kCellCap + 2]
     __shared__ uint32_t s_wave[kOrbitThreads / 64];
     __shared__ uint32_t s_total;
     __shared__ uint32_t s_plen;
@@ -292,12 +314,26 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const uint64_t spr = gq.spr, md = gq.md, n_corr = gq.n_corr;
+    const uint64_t n_corr = gq.n_corr;
+    const uint32_t spr = gq.spr, md = gq.md;
+    // s / spr for s < 2^32 by multiply-high with floor(2^32/spr) and two corrections
+    const uint32_t spr_magic = static_cast<uint32_t>((1ull << 32) / spr);
+    auto div_spr = [&](uint32_t s) -> uint32_t {
+        uint32_t q = __umulhi(s, spr_magic);
+        uint32_t r = s - q * spr;
+        if (r >= spr) { ++q; r -= spr; }
+        if (r >= spr) ++q;
+        return q;
+    };
+    const uint64_t t_begin = __builtin_readcyclecounter();
+    auto stamp = [&](int k) {
+        if (tid == 0) flags[8 + k] = static_cast<uint32_t>(__builtin_readcyclecounter() - t_begin);
+    };
 
     // number of grid cells that can hold a start: c in [2, kc]
     const uint64_t kc = n_corr ? (n_corr - 1) / spr : 0;
     bool walk = force_walk != 0 || flags[0] != 0 || kc + 2 > kCellCap || n_chunks > kMaxChunks ||
-                n_corr == 0;
+                n_corr == 0 || gq.work_len >= (1ull << 31);
 
     // ---- gather the per-chunk node-terminal lists into one sorted LDS array
     uint32_t total = 0;
@@ -328,14 +364,25 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
                 const uint32_t ch = c_lo + e;
                 if (ch >= n_chunks) break;
                 const uint32_t cnt = slot_cnt[ch];
-                for (uint32_t k = 0; k < cnt; ++k)
-                    s_nt[ofs + k] = slot_nt[static_cast<uint64_t>(ch) * kSlotCap + k];
+                const uint4 *src = reinterpret_cast<const uint4 *>(slot_nt + static_cast<uint64_t>(ch) * kSlotCap);
+                uint4 v[kSlotCap / 4];
+#pragma unroll
+                for (int j = 0; j < kSlotCap / 4; ++j)
+                    if (static_cast<uint32_t>(4 * j) < cnt) v[j] = src[j];
+#pragma unroll
+                for (int j = 0; j < kSlotCap / 4; ++j) {
+                    if (static_cast<uint32_t>(4 * j) < cnt) s_nt[ofs + 4 * j] = v[j].x;
+                    if (static_cast<uint32_t>(4 * j + 1) < cnt) s_nt[ofs + 4 * j + 1] = v[j].y;
+                    if (static_cast<uint32_t>(4 * j + 2) < cnt) s_nt[ofs + 4 * j + 2] = v[j].z;
+                    if (static_cast<uint32_t>(4 * j + 3) < cnt) s_nt[ofs + 4 * j + 3] = v[j].w;
+                }
                 ofs += cnt;
             }
         }
         __syncthreads();
     }
 
+    stamp(0);  // node terminals gathered
     if (walk) {
         if (wave == 0) orbit_walk52(words, gq, peaks, peaks_cap, res);
         if (tid == 0) {
@@ -351,46 +398,72 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
     const uint32_t n_nodes = base_d + total + 1;
     const uint32_t END = n_nodes - 1;
 
-    auto node_start = [&](uint32_t v, uint64_t *cell) -> uint64_t {
+    const uint32_t nc32 = static_cast<uint32_t>(n_corr);
+    const uint32_t wl32 = static_cast<uint32_t>(gq.work_len);
+    auto node_start = [&](uint32_t v, uint32_t *cell) -> uint32_t {
         // start position and the cell used for the "(cell+1)*spr" term
         if (v == 0) { *cell = 1; return 0; }
-        if (v < base_d) { *cell = v + 1; return static_cast<uint64_t>(v + 1) * spr; }
-        const uint64_t s = static_cast<uint64_t>(s_nt[v - base_d]) + md + 1;
-        *cell = s / spr;
+        if (v < base_d) { *cell = v + 1; return (v + 1) * spr; }
+        const uint32_t s = s_nt[v - base_d] + md + 1;
+        *cell = div_spr(s);
         return s;
+    };
+
+    // cell index: s_cell[c] = first node terminal at or after c*spr (c = 0 .. kc+1)
+    for (uint32_t c = tid; c <= static_cast<uint32_t>(kc) + 1; c += kOrbitThreads)
+        s_cell[c] = static_cast<uint16_t>(c > kc ? total : lower_bound_u32(s_nt, total, c * spr));
+    __syncthreads();
+    stamp(1);  // cell index
+    auto first_node_terminal = [&](uint32_t s, uint32_t c /* = s / spr */) -> uint32_t {
+        const uint32_t lo = s_cell[c], hi = s_cell[c + 1];
+        uint32_t ui = lo + lower_bound_u32(s_nt + lo, hi - lo, s);
+        if (ui >= total) ui = total - 1;  // cannot happen (fact 3); keeps reads in bounds
+        return ui;
     };
 
     for (uint32_t v = tid; v < n_nodes; v += kOrbitThreads) {
         uint32_t nx = END;
         if (v != END) {
-            uint64_t cell;
-            const uint64_t s = node_start(v, &cell);
-            if (s < n_corr) {
-                uint32_t ui = lower_bound_u32(s_nt, total, s);  // exists: see fact (3)
-                if (ui >= total) ui = total - 1;
-                const uint64_t u = s_nt[ui];
-                const uint64_t a = u + md + 1;
-                const uint64_t b = (cell + 1) * spr;
-                const uint64_t s2 = a > b ? a : b;
-                if (s2 < n_corr) nx = (a >= b) ? base_d + ui : static_cast<uint32_t>(cell);  // grid(cell+1) = id cell
+            uint32_t cell;
+            const uint32_t s = node_start(v, &cell);
+            if (s < nc32) {
+                const uint32_t ui = first_node_terminal(s, v == 0 ? 0u : cell);
+                const uint32_t u = s_nt[ui];
+                const uint32_t a = u + md + 1;
+                const uint32_t b = (cell + 1) * spr;
+                const uint32_t s2 = a > b ? a : b;
+                if (s2 < nc32) nx = (a >= b) ? base_d + ui : cell;  // grid(cell+1) has id `cell`
             }
         }
         s_ja[v] = static_cast<uint16_t>(nx);
     }
     if (tid == 0) s_path[0] = 0;
     __syncthreads();
+    stamp(2);  // functional graph built
 
     // ---- orbit of the root by pointer doubling: path[m + 2^r] = J_r[path[m]], J_{r+1} = J_r o J_r
     const uint32_t path_cap = static_cast<uint32_t>(kc) + 2;  // root + at most one start per cell
-    uint16_t *ja = s_ja, *jb = s_jb;
+    constexpr int kPerThread = (kNodeCap + kOrbitThreads - 1) / kOrbitThreads;
     for (uint32_t span = 1; span < path_cap; span <<= 1) {
         for (uint32_t mI = tid; mI < span && mI + span < path_cap; mI += kOrbitThreads)
-            s_path[mI + span] = ja[s_path[mI]];
-        for (uint32_t v = tid; v < n_nodes; v += kOrbitThreads) jb[v] = ja[ja[v]];
+            s_path[mI + span] = s_ja[s_path[mI]];
+        // J <- J o J in place: stage the new values in registers, then write them back
+        uint16_t nv[kPerThread];
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const uint32_t v = tid + j * kOrbitThreads;
+            nv[j] = (v < n_nodes) ? s_ja[s_ja[v]] : 0;
+        }
         __syncthreads();
-        uint16_t *t = ja; ja = jb; jb = t;
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const uint32_t v = tid + j * kOrbitThreads;
+            if (v < n_nodes) s_ja[v] = nv[j];
+        }
+        __syncthreads();
     }
 
+    stamp(3);  // orbit extracted
     // ---- peak list: path[k] (k >= 1) starts at s in cell c; pushes fill
     // peaks[cell(prev) .. c-2] with s and peaks[c-1] with u = firstT(s)
     if (tid == 0) { s_plen = 1; s_fit = 0ull; }
@@ -399,29 +472,27 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
     for (uint32_t k = tid; k < path_cap; k += kOrbitThreads) {
         const uint32_t v = s_path[k];
         if (v == END) continue;
-        uint64_t cell;
-        const uint64_t s = node_start(v, &cell);
-        uint32_t ui = (v == 0) ? 0u : lower_bound_u32(s_nt, total, s);
-        if (ui >= total) ui = total - 1;
-        const uint64_t u = s_nt[ui];
+        uint32_t cell;
+        const uint32_t s = node_start(v, &cell);
+        const uint32_t ui = (v == 0) ? 0u : first_node_terminal(s, cell);
+        const uint32_t u = s_nt[ui];
         const bool is_last = (k + 1 >= path_cap) || s_path[k + 1] == END;
         if (k == 0) {
-            if (peaks_cap > 0) peaks[0] = static_cast<uint32_t>(u);
-            if (!is_last && u + spr < gq.work_len) ++fit_local;
+            if (peaks_cap > 0) peaks[0] = u;
+            if (!is_last && u + spr < wl32) ++fit_local;
             if (is_last) s_plen = 1;
             continue;
         }
-        uint64_t pcell;
+        uint32_t pcell;
         (void)node_start(s_path[k - 1], &pcell);
-        // cell of the previous start: for the root the list holds 1 entry
-        const uint64_t c_prev = (k - 1 == 0) ? 1 : pcell;
-        const uint64_t c = s / spr;
-        for (uint64_t qv = c_prev; qv + 1 < c; ++qv)
-            if (qv < peaks_cap) peaks[qv] = static_cast<uint32_t>(s);
-        if (c - 1 < peaks_cap) peaks[c - 1] = static_cast<uint32_t>(u);
-        if (s + spr < gq.work_len) fit_local += c - c_prev - 1;
-        if (!is_last && u + spr < gq.work_len) ++fit_local;  // the last peak is dropped
-        if (is_last) s_plen = static_cast<uint32_t>(c);
+        const uint32_t c_prev = (k - 1 == 0) ? 1u : pcell;  // the root leaves one entry
+        const uint32_t c = cell;                             // = s / spr for k >= 1
+        for (uint32_t qv = c_prev; qv + 1 < c; ++qv)
+            if (qv < peaks_cap) peaks[qv] = s;
+        if (c - 1 < peaks_cap) peaks[c - 1] = u;
+        if (s + spr < wl32) fit_local += c - c_prev - 1;
+        if (!is_last && u + spr < wl32) ++fit_local;  // the last peak is dropped
+        if (is_last) s_plen = c;
     }
     atomicAdd(&s_fit, fit_local);
     __syncthreads();
@@ -437,7 +508,10 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
         res->n_out = few ? 0 : rows * 2080u;
         flags[1] = 0u;
         flags[0] = 0u;
+        flags[2] = total;
+        flags[3] = n_nodes;
     }
+    stamp(4);  // peaks written
 }
 
 }  // namespace
@@ -470,8 +544,8 @@ void sync_orbit(hipStream_t s, const uint64_t *words, const uint32_t *slot_nt,
 {
     const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
     const uint32_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
-    const size_t lds = static_cast<size_t>(kNtCap) * 4 + static_cast<size_t>(kNodeCap) * 2 * 2 +
-                       static_cast<size_t>(kCellCap + 2) * 2 + 64;
+    const size_t lds = static_cast<size_t>(kNtCap) * 4 + static_cast<size_t>(kNodeCap) * 2 +
+                       static_cast<size_t>(kCellCap + 2) * 2 * 2 + 64;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_orbit),

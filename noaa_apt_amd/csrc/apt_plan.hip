@@ -219,8 +219,8 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
             sl.words.alloc(ng + 64);
             sl.slot_nt.alloc(chunks * gpu::sync_slot_cap());
             sl.slot_cnt.alloc(chunks);
-            sl.flags.alloc(4);
-            hip_check(hipMemset(sl.flags.ptr, 0, 16), "hipMemset flags");
+            sl.flags.alloc(32);
+            hip_check(hipMemset(sl.flags.ptr, 0, 32 * sizeof(uint32_t)), "hipMemset flags");
         }
     }
     plan->d_results.alloc(static_cast<size_t>(max_batch));
