@@ -175,9 +175,10 @@ int aptgpu_plan_sync_positions(aptgpu_plan *plan, int i, uint64_t *pos, size_t c
                                size_t *n_sync);
 int aptgpu_plan_synchronize(aptgpu_plan *plan);
 
-/* Per-kernel timing with HIP events recorded on the plan's stream around
- * every kernel launch.  Enable, run decodes, then collect: averages are over
- * all launches since the last enable/collect. */
+/* Kernel timing with HIP events recorded on the plan's stream.  on = 0: off;
+ * 1: only the dominant (first-stage) kernel of each decode is bracketed; 2: every
+ * kernel launch is.  Enable, run decodes, then collect: averages are over all
+ * bracketed launches since the last collect. */
 typedef struct aptgpu_kernel_time {
     char name[48];
     double avg_ms;

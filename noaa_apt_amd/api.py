@@ -479,8 +479,10 @@ class Plan:
     def synchronize(self):
         _check(lib().aptgpu_plan_synchronize(self._p))
 
-    def enable_timing(self, on=True):
-        _check(lib().aptgpu_plan_enable_timing(self._p, 1 if on else 0))
+    def enable_timing(self, mode=2):
+        """0/False off, 1 dominant kernel only, 2/True every kernel launch."""
+        mode = 2 if mode is True else (0 if mode is False else int(mode))
+        _check(lib().aptgpu_plan_enable_timing(self._p, mode))
 
     def collect_timing(self):
         arr = (KernelTime * 32)()

@@ -208,7 +208,7 @@ int aptgpu_plan_sync_positions(aptgpu_plan *plan, int i, uint64_t *pos, size_t c
 int aptgpu_plan_enable_timing(aptgpu_plan *plan, int on)
 {
     if (!plan) return APTGPU_ERR_INVALID;
-    plan->timer.enable(on != 0);
+    plan->timer.enable(on < 0 ? 0 : (on > 2 ? 2 : on));
     return APTGPU_OK;
 }
 

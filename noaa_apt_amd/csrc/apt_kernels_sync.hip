@@ -215,6 +215,8 @@ constexpr int kNtCap = 16384;   // node terminals held in LDS
 constexpr int kCellCap = 8192;  // image rows (grid cells) handled by the doubling path
 constexpr int kNodeCap = kNtCap + kCellCap + 2;
 constexpr int kMaxChunks = 16384;
+constexpr int kListCap = 8192;    // nodes the marked (reachable) set may hold
+constexpr int kMaxLevels = 48;    // breadth-first levels before giving up on the fast path
 
 struct OrbitGeom {
     uint64_t n_corr, work_len;
@@ -302,13 +304,13 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
              uint32_t peaks_cap, Result *__restrict__ res, int force_walk)
 {
     extern __shared__ uint32_t lds_u32[];
-    uint32_t *s_nt = lds_u32;                                         // [kNtCap]
-    uint16_t *s_ja = reinterpret_cast<uint16_t *>(s_nt + kNtCap);     // [kNodeCap]
-    uint16_t *s_path = s_ja + kNodeCap;                               // [kCellCap + 2]
-    uint16_t *s_cell = s_path + (kCellCap + 2);                       // [kCellCap + 2]
+    uint32_t *s_nt = lds_u32;                                         // [kNtCap] node terminals
+    uint32_t *s_mark = s_nt + kNtCap;                                 // [kNodeCap/32 + 1] visited bits
+    uint16_t *s_ja = reinterpret_cast<uint16_t *>(s_mark + (kNodeCap / 32 + 1));  // [kNodeCap] next / jump
+    uint16_t *s_list = s_ja + kNodeCap;                               // [kListCap] visited node ids
+    uint16_t *s_path = s_list + kListCap;                             // [kCellCap + 2]
     __shared__ uint32_t s_wave[kOrbitThreads / 64];
-    __shared__ uint32_t s_total;
-    __shared__ uint32_t s_plen;
+    __shared__ uint32_t s_total, s_count, s_plen, s_bad;
     __shared__ unsigned long long s_fit;
 
     const int tid = threadIdx.x;
@@ -338,7 +340,6 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
     // ---- gather the per-chunk node-terminal lists into one sorted LDS array
     uint32_t total = 0;
     if (!walk) {
-        // exclusive scan of slot_cnt in strips of `per`
         const uint32_t per = (n_chunks + kOrbitThreads - 1) / kOrbitThreads;
         const uint32_t c_lo = tid * per;
         uint32_t mine = 0;
@@ -363,7 +364,7 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
             for (uint32_t e = 0; e < per; ++e) {
                 const uint32_t ch = c_lo + e;
                 if (ch >= n_chunks) break;
-                const uint32_t cnt = slot_cnt[ch];
+                const uint32_t cnt = (per == 1) ? mine : slot_cnt[ch];
                 const uint4 *src = reinterpret_cast<const uint4 *>(slot_nt + static_cast<uint64_t>(ch) * kSlotCap);
                 uint4 v[kSlotCap / 4];
 #pragma unroll
@@ -381,25 +382,16 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
         }
         __syncthreads();
     }
-
     stamp(0);  // node terminals gathered
-    if (walk) {
-        if (wave == 0) orbit_walk52(words, gq, peaks, peaks_cap, res);
-        if (tid == 0) {
-            flags[1] = 1u;  // report which path ran
-            flags[0] = 0u;  // re-arm the overflow flag for the next decode
-        }
-        return;
-    }
 
-    // ---- nodes: 0 = root, 1 .. ng = grid cells 2 .. kc, then one per node terminal, END
+    // ---- nodes: 0 = root, 1 .. n_grid = grid cells 2 .. kc, then one per node terminal, END
     const uint32_t n_grid = kc >= 2 ? static_cast<uint32_t>(kc - 1) : 0;
     const uint32_t base_d = 1 + n_grid;
     const uint32_t n_nodes = base_d + total + 1;
     const uint32_t END = n_nodes - 1;
-
     const uint32_t nc32 = static_cast<uint32_t>(n_corr);
     const uint32_t wl32 = static_cast<uint32_t>(gq.work_len);
+
     auto node_start = [&](uint32_t v, uint32_t *cell) -> uint32_t {
         // start position and the cell used for the "(cell+1)*spr" term
         if (v == 0) { *cell = 1; return 0; }
@@ -408,62 +400,97 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
         *cell = div_spr(s);
         return s;
     };
-
-    // cell index: s_cell[c] = first node terminal at or after c*spr (c = 0 .. kc+1)
-    for (uint32_t c = tid; c <= static_cast<uint32_t>(kc) + 1; c += kOrbitThreads)
-        s_cell[c] = static_cast<uint16_t>(c > kc ? total : lower_bound_u32(s_nt, total, c * spr));
-    __syncthreads();
-    stamp(1);  // cell index
-    auto first_node_terminal = [&](uint32_t s, uint32_t c /* = s / spr */) -> uint32_t {
-        const uint32_t lo = s_cell[c], hi = s_cell[c + 1];
-        uint32_t ui = lo + lower_bound_u32(s_nt + lo, hi - lo, s);
+    auto first_node_terminal = [&](uint32_t s) -> uint32_t {
+        uint32_t ui = lower_bound_u32(s_nt, total, s);
         if (ui >= total) ui = total - 1;  // cannot happen (fact 3); keeps reads in bounds
         return ui;
     };
+    auto next_of = [&](uint32_t v) -> uint32_t {
+        uint32_t cell;
+        const uint32_t s = node_start(v, &cell);
+        if (s >= nc32) return END;
+        const uint32_t ui = first_node_terminal(v == 0 ? 0u : s);
+        const uint32_t a = s_nt[ui] + md + 1;
+        const uint32_t b = (cell + 1) * spr;
+        const uint32_t s2 = a > b ? a : b;
+        if (s2 >= nc32) return END;
+        return (a >= b) ? base_d + ui : cell;  // grid(cell+1) has id `cell`
+    };
 
-    for (uint32_t v = tid; v < n_nodes; v += kOrbitThreads) {
-        uint32_t nx = END;
-        if (v != END) {
-            uint32_t cell;
-            const uint32_t s = node_start(v, &cell);
-            if (s < nc32) {
-                const uint32_t ui = first_node_terminal(s, v == 0 ? 0u : cell);
-                const uint32_t u = s_nt[ui];
-                const uint32_t a = u + md + 1;
-                const uint32_t b = (cell + 1) * spr;
-                const uint32_t s2 = a > b ? a : b;
-                if (s2 < nc32) nx = (a >= b) ? base_d + ui : cell;  // grid(cell+1) has id `cell`
-            }
+    // ---- reachable set by breadth-first marking from the root and every grid node: on real
+    // recordings all chains merge within a step or two, so a handful of levels closes it.
+    uint32_t count = 0;
+    if (!walk) {
+        for (uint32_t wq = tid; wq < kNodeCap / 32 + 1; wq += kOrbitThreads) s_mark[wq] = 0u;
+        if (tid == 0) { s_bad = 0; }
+        __syncthreads();
+        for (uint32_t v = tid; v < base_d; v += kOrbitThreads) {
+            if (v < kListCap) s_list[v] = static_cast<uint16_t>(v);
+            atomicOr(&s_mark[v >> 5], 1u << (v & 31));
         }
-        s_ja[v] = static_cast<uint16_t>(nx);
+        if (tid == 0) {
+            s_count = base_d;
+            if (base_d > kListCap) s_bad = 1;
+        }
+        __syncthreads();
+        uint32_t lo = 0, hi = base_d;
+        for (int level = 0; level < kMaxLevels && lo < hi && !s_bad; ++level) {
+            for (uint32_t idx = lo + tid; idx < hi; idx += kOrbitThreads) {
+                const uint32_t v = s_list[idx];
+                const uint32_t nx = next_of(v);
+                s_ja[v] = static_cast<uint16_t>(nx);
+                if (nx != END) {
+                    const uint32_t bit = 1u << (nx & 31);
+                    if (!(atomicOr(&s_mark[nx >> 5], bit) & bit)) {
+                        const uint32_t pos = atomicAdd(&s_count, 1u);
+                        if (pos < kListCap) s_list[pos] = static_cast<uint16_t>(nx); else s_bad = 1;
+                    }
+                }
+            }
+            __syncthreads();
+            lo = hi;
+            hi = s_count < kListCap ? s_count : kListCap;
+            __syncthreads();
+        }
+        if (lo < hi || s_bad) walk = true;  // not closed within the budget: take the general path
+        count = hi;
     }
-    if (tid == 0) s_path[0] = 0;
-    __syncthreads();
-    stamp(2);  // functional graph built
+    stamp(1);  // reachable set closed
 
-    // ---- orbit of the root by pointer doubling: path[m + 2^r] = J_r[path[m]], J_{r+1} = J_r o J_r
+    if (walk) {
+        if (wave == 0) orbit_walk52(words, gq, peaks, peaks_cap, res);
+        if (tid == 0) {
+            flags[1] = 1u;  // report which path ran
+            flags[0] = 0u;  // re-arm the overflow flag for the next decode
+        }
+        return;
+    }
+    if (tid == 0) { s_ja[END] = static_cast<uint16_t>(END); s_path[0] = 0; }
+    __syncthreads();
+
+    // ---- orbit of the root by pointer doubling over the visited nodes only:
+    // path[m + 2^r] = J_r[path[m]],  J_{r+1} = J_r o J_r  (staged in registers, in place)
     const uint32_t path_cap = static_cast<uint32_t>(kc) + 2;  // root + at most one start per cell
-    constexpr int kPerThread = (kNodeCap + kOrbitThreads - 1) / kOrbitThreads;
+    constexpr int kPerThread = (kListCap + kOrbitThreads - 1) / kOrbitThreads;
     for (uint32_t span = 1; span < path_cap; span <<= 1) {
         for (uint32_t mI = tid; mI < span && mI + span < path_cap; mI += kOrbitThreads)
             s_path[mI + span] = s_ja[s_path[mI]];
-        // J <- J o J in place: stage the new values in registers, then write them back
         uint16_t nv[kPerThread];
 #pragma unroll
         for (int j = 0; j < kPerThread; ++j) {
-            const uint32_t v = tid + j * kOrbitThreads;
-            nv[j] = (v < n_nodes) ? s_ja[s_ja[v]] : 0;
+            const uint32_t idx = tid + j * kOrbitThreads;
+            nv[j] = (idx < count) ? s_ja[s_ja[s_list[idx]]] : 0;
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < kPerThread; ++j) {
-            const uint32_t v = tid + j * kOrbitThreads;
-            if (v < n_nodes) s_ja[v] = nv[j];
+            const uint32_t idx = tid + j * kOrbitThreads;
+            if (idx < count) s_ja[s_list[idx]] = nv[j];
         }
         __syncthreads();
     }
+    stamp(2);  // orbit extracted
 
-    stamp(3);  // orbit extracted
     // ---- peak list: path[k] (k >= 1) starts at s in cell c; pushes fill
     // peaks[cell(prev) .. c-2] with s and peaks[c-1] with u = firstT(s)
     if (tid == 0) { s_plen = 1; s_fit = 0ull; }
@@ -474,8 +501,7 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
         if (v == END) continue;
         uint32_t cell;
         const uint32_t s = node_start(v, &cell);
-        const uint32_t ui = (v == 0) ? 0u : first_node_terminal(s, cell);
-        const uint32_t u = s_nt[ui];
+        const uint32_t u = s_nt[first_node_terminal(v == 0 ? 0u : s)];
         const bool is_last = (k + 1 >= path_cap) || s_path[k + 1] == END;
         if (k == 0) {
             if (peaks_cap > 0) peaks[0] = u;
@@ -510,8 +536,9 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
         flags[0] = 0u;
         flags[2] = total;
         flags[3] = n_nodes;
+        flags[4] = count;
     }
-    stamp(4);  // peaks written
+    stamp(3);  // peaks written
 }
 
 }  // namespace
@@ -544,8 +571,9 @@ void sync_orbit(hipStream_t s, const uint64_t *words, const uint32_t *slot_nt,
 {
     const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
     const uint32_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
-    const size_t lds = static_cast<size_t>(kNtCap) * 4 + static_cast<size_t>(kNodeCap) * 2 +
-                       static_cast<size_t>(kCellCap + 2) * 2 * 2 + 64;
+    const size_t lds = static_cast<size_t>(kNtCap) * 4 + static_cast<size_t>(kNodeCap / 32 + 1) * 4 +
+                       static_cast<size_t>(kNodeCap) * 2 + static_cast<size_t>(kListCap) * 2 +
+                       static_cast<size_t>(kCellCap + 2) * 2 + 64;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_orbit),

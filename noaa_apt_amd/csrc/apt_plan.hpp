@@ -55,9 +55,10 @@ struct DeviceBuffer {
 class KernelTimer {
 public:
     ~KernelTimer();
-    void enable(bool on);
-    bool enabled() const { return on_; }
-    void begin(hipStream_t s, const char *name);
+    // 0 = off, 1 = only launches flagged `dominant`, 2 = every launch
+    void enable(int mode);
+    int mode() const { return mode_; }
+    void begin(hipStream_t s, const char *name, bool dominant);
     void end(hipStream_t s);
     // synchronises the stream, folds all recorded pairs into per-name averages
     std::vector<aptgpu_kernel_time> collect(hipStream_t s);
@@ -67,7 +68,8 @@ private:
         const char *name;
         hipEvent_t a, b;
     };
-    bool on_ = false;
+    int mode_ = 0;
+    bool open_ = false;
     std::vector<Pair> pairs_;
     std::vector<hipEvent_t> pool_;
     hipEvent_t take();
