@@ -47,15 +47,17 @@ void gather_rows(hipStream_t s, const float *f, const uint32_t *peaks, const Res
 // true when a <L, M, T1, T2, PW> specialisation exists
 bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
 uint32_t fused_group_size(uint32_t l);
-uint32_t fused_taps_per_branch(uint32_t l, uint32_t t1);
-// host: reorder the T1 taps step-major [TP][L] (hs[i*L+b] = coeff[p_b + i*L], 0 past T1)
+// host: stage-1 tap-pair table [WIN][PS][2] (see apt_kernels_fused.hip) and its size in floats
+uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1);
 void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, float *hs);
+// host: stage-3 tap pairs h2p[k] = (h2[k-1], h2[k]), k = 0 .. t2  (2*(t2+1) floats)
+void fused_lowpass_pairs(const float *h2, uint32_t t2, float *h2p);
 // x -> F (filtered work-rate signal) and, if gm_out != nullptr, the per-group maxima of
 // the sync cross-correlation.  Returns false if no specialisation matches.
 bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
-                     const float *x, uint64_t n, const float *hs, const float *h2, float cosphi2,
-                     float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w,
-                     uint64_t n_corr);
+                     const float *x, uint64_t n, const float *hs, const float *h2, const float *h2p,
+                     float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out,
+                     uint64_t w, uint64_t n_corr);
 
 // ---- parallel peak picker (apt_kernels_sync.hip) ------------------------------------
 uint32_t sync_group_size();    // correlation positions per group (52)

@@ -77,10 +77,23 @@ struct FusedGeom {
     static constexpr int C_OFF = D_OFF + TILE_K;
     static constexpr int LDS_FLOATS = XT_PAD > (C_OFF + TILE_K) ? XT_PAD : (C_OFF + TILE_K);
     static constexpr int GS = 4 * L;                                  // correlation group size
+    static constexpr int NP = L / 2;                                  // accumulator pairs (+1 single if L odd)
+    static constexpr int PS = NP + (L & 1);                           // f2 tap entries per window sample
+    static constexpr int DW = L + T2 - 1;                             // envelope window per thread
     static_assert(PRE_K >= T2 + 1, "pre-halo too small for the low-pass");
     static_assert((kFusedThreads - kPreThreads - kOwnThreads) * L >= G - 1, "post-halo too small");
     static_assert(OWN_K % 4 == 0, "owned range must be float4-aligned");
 };
+
+// does polyphase branch b use window sample q?  (tap index i = q - c_b, p_b + i*L < T1)
+template <int L, int M, int T1>
+__host__ __device__ constexpr bool branch_uses(int b, int q)
+{
+    const int i = q - branch_first<L, M>(b);
+    return i >= 0 && branch_phase<L, M>(b) + i * L < T1;
+}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // sign of the sync template at index j (decode.rs:188-198): + inside the seven high pulses
 template <int PW>
@@ -93,8 +106,9 @@ __host__ __device__ constexpr bool sync_plus(int j)
 
 template <int L, int M, int T1, int T2, int PW>
 __global__ void __launch_bounds__(kFusedThreads, APT_FUSED_MIN_WAVES)
-k_fused(const float *__restrict__ x, uint64_t n, const float *__restrict__ hs /*[TP][L] step-major*/,
-        const float *__restrict__ h2 /*[T2]*/, float cosphi2, float sinphi,
+k_fused(const float *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][PS] tap pairs*/,
+        const float *__restrict__ h2 /*[T2]*/, const f2 *__restrict__ h2p /*[T2+1] (h2[m-1], h2[m])*/,
+        float cosphi2, float sinphi,
         float *__restrict__ f_out, float *__restrict__ c_out, float *__restrict__ gm_out,
         uint64_t w, uint64_t n_corr)
 {
@@ -137,53 +151,53 @@ k_fused(const float *__restrict__ x, uint64_t n, const float *__restrict__ hs /*
     __syncthreads();
 
     // ---- stage 1: polyphase resampler, L outputs per thread (dsp.rs:252-263)
-    // Tap step i of every branch b reads xw[c_b + i]: a window of CLAST+1 samples sliding
-    // by one per step.  The loop is unrolled in chunks of CH steps fenced by scheduling
-    // barriers so only ~CLAST+2*CH samples and one chunk of taps are live at a time.
+    // Sample-stationary form: window sample q is broadcast (op_sel) against a PAIR of taps
+    // (one scalar-loaded SGPR pair) feeding a pair of accumulators, so every tap costs half
+    // a v_pk_mul_f32 + half a v_pk_add_f32 and no register shuffling.  Each branch still
+    // accumulates its own taps in ascending order, products and sums rounded separately.
     const int kq = tid * L;        // this thread's first work sample, tile-relative
     const int kt = kq - k_lo;      // ... and as a global work-sample index clamped to int
     float r[L];
     {
         constexpr int CH = 4;
-        float xw[Gm::WIN + 1];
         const float *src = P + tid * M;
-        constexpr bool kPairs = (M % 2) == 0;  // 8-byte aligned window -> ds_read_b64
-        auto load_range = [&](auto lo_c, auto hi_c) {
-            constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
-            if constexpr (kPairs) {
+        f2 acc[Gm::NP > 0 ? Gm::NP : 1];
+        float accl = 0.f;
 #pragma unroll
-                for (int q = lo; q < hi; q += 2) {
-                    const float2 v = *reinterpret_cast<const float2 *>(src + q);
-                    xw[q] = v.x;
-                    xw[q + 1] = v.y;
+        for (int pp = 0; pp < Gm::NP; ++pp) acc[pp] = (f2){0.f, 0.f};
+        static_for<0, (Gm::WIN + CH - 1) / CH>([&](auto cc) {
+            constexpr int q0 = decltype(cc)::value * CH;
+            float xv[CH];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) xv[e] = (q0 + e < Gm::WIN) ? src[q0 + e] : 0.f;
+            static_for<0, CH>([&](auto ee) {
+                constexpr int q = q0 + decltype(ee)::value;
+                if constexpr (q < Gm::WIN) {
+                    const float xq = xv[decltype(ee)::value];
+                    static_for<0, Gm::NP>([&](auto pc) {
+                        constexpr int pp = decltype(pc)::value;
+                        constexpr bool va = branch_uses<L, M, T1>(2 * pp, q);
+                        constexpr bool vb = branch_uses<L, M, T1>(2 * pp + 1, q);
+                        if constexpr (va && vb) {
+                            acc[pp] = acc[pp] + hs[q * Gm::PS + pp] * (f2){xq, xq};
+                        } else if constexpr (va) {
+                            acc[pp].x = acc[pp].x + hs[q * Gm::PS + pp].x * xq;
+                        } else if constexpr (vb) {
+                            acc[pp].y = acc[pp].y + hs[q * Gm::PS + pp].y * xq;
+                        }
+                    });
+                    if constexpr ((L & 1) && branch_uses<L, M, T1>(L - 1, q))
+                        accl = accl + hs[q * Gm::PS + Gm::NP].x * xq;
                 }
-            } else {
-#pragma unroll
-                for (int q = lo; q < hi; ++q) xw[q] = src[q];
-            }
-        };
-        constexpr int kFirst = (Gm::CLAST + CH + 1) & ~1;
-        load_range(std::integral_constant<int, 0>{}, std::integral_constant<int, kFirst>{});
-#pragma unroll
-        for (int b = 0; b < L; ++b) r[b] = 0.f;
-        static_for<0, (Gm::TP + CH - 1) / CH>([&](auto cc) {
-            constexpr int c0 = decltype(cc)::value * CH;
-            constexpr int lo = (Gm::CLAST + c0 + CH + 1) & ~1;
-            constexpr int hi_raw = (Gm::CLAST + c0 + 2 * CH + 1) & ~1;
-            constexpr int hi = hi_raw < ((Gm::WIN + 1) & ~1) ? hi_raw : ((Gm::WIN + 1) & ~1);
-            if constexpr (lo < hi) load_range(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{});
-#pragma unroll
-            for (int i = c0; i < c0 + CH; ++i) {
-                if (i < Gm::TP) {
-#pragma unroll
-                    for (int b = 0; b < L; ++b) {
-                        if (branch_phase<L, M>(b) + i * L < T1)
-                            r[b] = r[b] + hs[i * L + b] * xw[branch_first<L, M>(b) + i];
-                    }
-                }
-            }
+            });
             __builtin_amdgcn_sched_barrier(0);
         });
+#pragma unroll
+        for (int pp = 0; pp < Gm::NP; ++pp) {
+            r[2 * pp] = acc[pp].x;
+            r[2 * pp + 1] = acc[pp].y;
+        }
+        if constexpr (L & 1) r[L - 1] = accl;
 #pragma unroll
         for (int b = 0; b < L; ++b)
             if (kq + b < k_lo || kq + b >= k_hi) r[b] = 0.f;
@@ -212,27 +226,66 @@ k_fused(const float *__restrict__ x, uint64_t n, const float *__restrict__ hs /*
     __syncthreads();
 
     // ---- stage 3: causal low-pass with the `i > j` guard (dsp.rs:396-404)
+    // Same sample-stationary pairing: envelope sample d = D[kt-(T2-1)+qq] meets output b at
+    // tap j = (T2-1)+b-qq, so outputs (b, b+1) take the tap pair (h2[m], h2[m+1]); walking qq
+    // downwards gives every output its taps in ascending j.
     float f[L];
     {
-        constexpr int DW = L + T2 - 1;
-        float dw[DW];  // D[kt - (T2-1) .. kt + L - 1]
         const int base = tid * L - (T2 - 1);
-#pragma unroll
-        for (int q = 0; q < DW; ++q) dw[q] = (base + q >= 0) ? Q[base + q] : 0.f;
-#pragma unroll
-        for (int b = 0; b < L; ++b) f[b] = 0.f;
         if (kt >= T2) {
+            f2 fa[Gm::NP > 0 ? Gm::NP : 1];
+            float fl = 0.f;
 #pragma unroll
-            for (int j = 0; j < T2; ++j) {
+            for (int pp = 0; pp < Gm::NP; ++pp) fa[pp] = (f2){0.f, 0.f};
+            constexpr int CH3 = 7;
+            static_for<0, (Gm::DW + CH3 - 1) / CH3>([&](auto cc) {
+                constexpr int hi = Gm::DW - 1 - decltype(cc)::value * CH3;  // walk qq downwards
+                float dv[CH3];
 #pragma unroll
-                for (int b = 0; b < L; ++b) f[b] = f[b] + dw[(T2 - 1) + b - j] * h2[j];
+                for (int e = 0; e < CH3; ++e) dv[e] = (hi - e >= 0) ? Q[base + hi - e] : 0.f;
+                static_for<0, CH3>([&](auto ee) {
+                    constexpr int qq = hi - decltype(ee)::value;
+                    if constexpr (qq >= 0) {
+                        const float d = dv[decltype(ee)::value];
+                        static_for<0, Gm::NP>([&](auto pc) {
+                            constexpr int pp = decltype(pc)::value;
+                            constexpr int m = (T2 - 1) + 2 * pp - qq;       // tap of lane x; lane y: m+1
+                            constexpr bool va = m >= 0 && m < T2;
+                            constexpr bool vb = m + 1 >= 0 && m + 1 < T2;
+                            if constexpr (va && vb) {
+                                fa[pp] = fa[pp] + h2p[m + 1] * (f2){d, d};
+                            } else if constexpr (va) {
+                                fa[pp].x = fa[pp].x + h2[m] * d;
+                            } else if constexpr (vb) {
+                                fa[pp].y = fa[pp].y + h2[m + 1] * d;
+                            }
+                        });
+                        if constexpr (L & 1) {
+                            constexpr int ml = (T2 - 1) + (L - 1) - qq;
+                            if constexpr (ml >= 0 && ml < T2) fl = fl + h2[ml] * d;
+                        }
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int pp = 0; pp < Gm::NP; ++pp) {
+                f[2 * pp] = fa[pp].x;
+                f[2 * pp + 1] = fa[pp].y;
             }
+            if constexpr (L & 1) f[L - 1] = fl;
         } else {
+            // first samples of the recording (tile 0 only): the reference's `i > j` guard
 #pragma unroll
+            for (int b = 0; b < L; ++b) f[b] = 0.f;
+#pragma unroll 1
             for (int j = 0; j < T2; ++j) {
+                const float hj = h2[j];
 #pragma unroll
-                for (int b = 0; b < L; ++b)
-                    if (kt + b > j) f[b] = f[b] + dw[(T2 - 1) + b - j] * h2[j];
+                for (int b = 0; b < L; ++b) {
+                    const int qi = base + (T2 - 1) + b - j;
+                    if (kt + b > j && qi >= 0) f[b] = f[b] + Q[qi] * hj;
+                }
             }
         }
     }
@@ -255,37 +308,51 @@ k_fused(const float *__restrict__ x, uint64_t n, const float *__restrict__ hs /*
 
     // ---- stage 4: sync cross-correlation (decode.rs:225-233), its group maxima, and C
     if (gm_out != nullptr) {
-        constexpr int CJ = 2 * PW;  // one template pulse per chunk
-        float fw[Gm::FWIN + CJ];
+        // F sample q meets output b at template index j = q - b: outputs (b, b+1) add the
+        // same sample with the signs of T[j] and T[j-1] (neg_lo / neg_hi modifiers).
+        constexpr int CH4 = 6;
         const float *src = P + tid * L;
-        auto load_f = [&](auto lo_c, auto hi_c) {
-            constexpr int lo = decltype(lo_c)::value, hi = decltype(hi_c)::value;
+        f2 ca[Gm::NP > 0 ? Gm::NP : 1];
+        float cl = 0.f;
 #pragma unroll
-            for (int q = lo; q < hi; ++q) fw[q] = src[q];
-        };
-        load_f(std::integral_constant<int, 0>{}, std::integral_constant<int, L + CJ>{});
-        float c[L];
+        for (int pp = 0; pp < Gm::NP; ++pp) ca[pp] = (f2){0.f, 0.f};
+        static_for<0, (Gm::FWIN + CH4 - 1) / CH4>([&](auto cc) {
+            constexpr int q0 = decltype(cc)::value * CH4;
+            float fv[CH4];
 #pragma unroll
-        for (int b = 0; b < L; ++b) c[b] = 0.f;
-        static_for<0, (Gm::G + CJ - 1) / CJ>([&](auto cc) {
-            constexpr int j0 = decltype(cc)::value * CJ;
-            constexpr int lo = L + j0 + CJ;
-            constexpr int hi = (lo + CJ) < Gm::FWIN ? (lo + CJ) : Gm::FWIN;
-            if constexpr (lo < hi) load_f(std::integral_constant<int, lo>{}, std::integral_constant<int, hi>{});
-#pragma unroll
-            for (int j = j0; j < j0 + CJ; ++j) {
-                if (j < Gm::G) {
-#pragma unroll
-                    for (int b = 0; b < L; ++b) {
-                        if (sync_plus<PW>(j))
-                            c[b] = c[b] + fw[b + j];
-                        else
-                            c[b] = c[b] - fw[b + j];
+            for (int e = 0; e < CH4; ++e) fv[e] = (q0 + e < Gm::FWIN) ? src[q0 + e] : 0.f;
+            static_for<0, CH4>([&](auto ee) {
+                constexpr int q = q0 + decltype(ee)::value;
+                if constexpr (q < Gm::FWIN) {
+                    const float v = fv[decltype(ee)::value];
+                    static_for<0, Gm::NP>([&](auto pc) {
+                        constexpr int pp = decltype(pc)::value;
+                        constexpr int jx = q - 2 * pp, jy = q - 2 * pp - 1;
+                        constexpr bool va = jx >= 0 && jx < Gm::G;
+                        constexpr bool vb = jy >= 0 && jy < Gm::G;
+                        if constexpr (va && vb) {
+                            ca[pp] = ca[pp] + (f2){sync_plus<PW>(jx) ? v : -v, sync_plus<PW>(jy) ? v : -v};
+                        } else if constexpr (va) {
+                            ca[pp].x = sync_plus<PW>(jx) ? ca[pp].x + v : ca[pp].x - v;
+                        } else if constexpr (vb) {
+                            ca[pp].y = sync_plus<PW>(jy) ? ca[pp].y + v : ca[pp].y - v;
+                        }
+                    });
+                    if constexpr (L & 1) {
+                        constexpr int jl = q - (L - 1);
+                        if constexpr (jl >= 0 && jl < Gm::G) cl = sync_plus<PW>(jl) ? cl + v : cl - v;
                     }
                 }
-            }
+            });
             __builtin_amdgcn_sched_barrier(0);
         });
+        float c[L];
+#pragma unroll
+        for (int pp = 0; pp < Gm::NP; ++pp) {
+            c[2 * pp] = ca[pp].x;
+            c[2 * pp + 1] = ca[pp].y;
+        }
+        if constexpr (L & 1) c[L - 1] = cl;
         float mx = kNegInfF;
 #pragma unroll
         for (int b = 0; b < L; ++b) {
@@ -315,7 +382,7 @@ k_fused(const float *__restrict__ x, uint64_t n, const float *__restrict__ hs /*
 
 template <int L, int M, int T1, int T2, int PW>
 void launch_fused(hipStream_t s, const float *x, uint64_t n, const float *hb, const float *h2,
-                  float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w,
+                  const float *h2p, float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w,
                   uint64_t n_corr)
 {
     using Gm = FusedGeom<L, M, T1, T2, PW>;
@@ -328,7 +395,8 @@ void launch_fused(hipStream_t s, const float *x, uint64_t n, const float *hb, co
         attr_set = true;
     }
     const unsigned tiles = static_cast<unsigned>((w + Gm::OWN_K - 1) / Gm::OWN_K);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(kFusedThreads), lds, s, x, n, hb, h2, cosphi2, sinphi,
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(kFusedThreads), lds, s, x, n, reinterpret_cast<const f2 *>(hb), h2,
+                       reinterpret_cast<const f2 *>(h2p), cosphi2, sinphi,
                        f_out, c_out, gm_out, w, n_corr);
 }
 
@@ -341,29 +409,60 @@ bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t 
 
 uint32_t fused_group_size(uint32_t l) { return 4 * l; }
 
-uint32_t fused_taps_per_branch(uint32_t l, uint32_t t1) { return (t1 + l - 1) / l; }
-
-void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, float *hb)
+// floats in the stage-1 tap-pair table: [WIN][PS] pairs
+uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1)
 {
     const uint32_t tp = (t1 + l - 1) / l;
-    for (uint32_t b = 0; b < l; ++b) {
+    const uint32_t clast = ((l - 1) * m + l - 1) / l;
+    const uint32_t win = clast + tp;
+    const uint32_t ps = l / 2 + (l & 1);
+    return win * ps * 2;
+}
+
+// host: stage-1 table hs[q][pp] = (tap of branch 2pp at window sample q, tap of branch 2pp+1),
+// 0 where a branch does not use q; last entry of a row = (tap of the odd branch L-1, 0)
+void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, float *hs)
+{
+    const uint32_t tp = (t1 + l - 1) / l;
+    const uint32_t clast = ((l - 1) * m + l - 1) / l;
+    const uint32_t win = clast + tp;
+    const uint32_t np = l / 2, ps = np + (l & 1);
+    auto tap = [&](uint32_t b, uint32_t q) -> float {
         const uint32_t cb = (b * m + l - 1) / l;
         const uint32_t pb = cb * l - b * m;
-        for (uint32_t i = 0; i < tp; ++i) {
-            const uint32_t j = pb + i * l;
-            hb[i * l + b] = j < t1 ? coeff[j] : 0.f;  // step-major [TP][L]
+        if (q < cb) return 0.f;
+        const uint64_t j = pb + static_cast<uint64_t>(q - cb) * l;
+        return j < t1 ? coeff[j] : 0.f;
+    };
+    for (uint32_t q = 0; q < win; ++q) {
+        for (uint32_t pp = 0; pp < np; ++pp) {
+            hs[(q * ps + pp) * 2] = tap(2 * pp, q);
+            hs[(q * ps + pp) * 2 + 1] = tap(2 * pp + 1, q);
+        }
+        if (l & 1) {
+            hs[(q * ps + np) * 2] = tap(l - 1, q);
+            hs[(q * ps + np) * 2 + 1] = 0.f;
         }
     }
 }
 
+// host: stage-3 table h2p[k] = (h2[k-1], h2[k]) for k = 0 .. t2 (0 outside the filter)
+void fused_lowpass_pairs(const float *h2, uint32_t t2, float *h2p)
+{
+    for (uint32_t k = 0; k <= t2; ++k) {
+        h2p[2 * k] = k >= 1 ? h2[k - 1] : 0.f;
+        h2p[2 * k + 1] = k < t2 ? h2[k] : 0.f;
+    }
+}
+
 bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
-                     const float *x, uint64_t n, const float *hb, const float *h2, float cosphi2,
-                     float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w,
-                     uint64_t n_corr)
+                     const float *x, uint64_t n, const float *hb, const float *h2, const float *h2p,
+                     float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out,
+                     uint64_t w, uint64_t n_corr)
 {
     if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
-        launch_fused<13, 50, 959, 37, 3>(s, x, n, hb, h2, cosphi2, sinphi, f_out, c_out, gm_out, w,
-                                         n_corr);
+        launch_fused<13, 50, 959, 37, 3>(s, x, n, hb, h2, h2p, cosphi2, sinphi, f_out, c_out, gm_out,
+                                         w, n_corr);
         return true;
     }
     return false;

@@ -200,9 +200,13 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
                   plan->work_is_multiple;
     if (plan->fused) {
         const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
-        Signal hs(static_cast<size_t>(gpu::fused_taps_per_branch(plan->l, t1)) * plan->l + 16, 0.f);
+        Signal hs(static_cast<size_t>(gpu::fused_tap_table_floats(plan->l, plan->m, t1)) + 16, 0.f);
         gpu::fused_branch_taps(plan->l, plan->m, plan->taps_resample.data(), t1, hs.data());
         upload(plan->d_taps_branch, hs);
+        Signal h2p(2 * (plan->taps_lowpass.size() + 1) + 16, 0.f);
+        gpu::fused_lowpass_pairs(plan->taps_lowpass.data(), static_cast<uint32_t>(plan->taps_lowpass.size()),
+                                 h2p.data());
+        upload(plan->d_taps_lowpass_pairs, h2p);
     }
 
     plan->slots.resize(static_cast<size_t>(max_batch));
@@ -277,7 +281,8 @@ void aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_row
         timed("fused_front_end", [&] {
             fused_front_end(stream, l, m, static_cast<uint32_t>(taps_resample.size()),
                             static_cast<uint32_t>(taps_lowpass.size()), pw, d_signal, n,
-                            d_taps_branch.ptr, d_taps_lowpass.ptr, cosphi2, sinphi, sl.filtered.ptr,
+                            d_taps_branch.ptr, d_taps_lowpass.ptr, d_taps_lowpass_pairs.ptr, cosphi2, sinphi,
+                            sl.filtered.ptr,
                             (sync && work_is_multiple) ? sl.correlation.ptr : nullptr,
                             (sync && work_is_multiple) ? sl.gm.ptr : nullptr, w, w - n_sync_taps);
         });

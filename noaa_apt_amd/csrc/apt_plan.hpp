@@ -108,7 +108,7 @@ struct aptgpu_plan {
     bool fused = false;
     bool force_walk = false;  // APTGPU_FORCE_WALK=1: exercise the picker's fallback path
 
-    apt::DeviceBuffer<float> d_taps_resample, d_taps_lowpass, d_one, d_taps_branch;
+    apt::DeviceBuffer<float> d_taps_resample, d_taps_lowpass, d_one, d_taps_branch, d_taps_lowpass_pairs;
     struct Slot {
         apt::DeviceBuffer<float> resampled, demodulated, filtered, correlation;
         apt::DeviceBuffer<uint64_t> bits;     // 64-bit terminal words (generic-mode picker)
