@@ -150,8 +150,9 @@ def main():
                 "rows": int(res.n_rows),
                 "n_sync": int(res.n_sync),
                 "input_resident_in_hbm": True,
-                "picker": {"fallback_walk": int(pflags[1]), "node_terminals": int(pflags[2]),
-                           "nodes": int(pflags[3]), "visited_nodes": int(pflags[4]), "cycle_stamps": [int(v) for v in pflags[8:12]]},
+                "picker": {"path": {0: "lds", 1: "sequential-walk", 2: "global"}.get(int(pflags[1]), "?"),
+                           "node_capacity": int(pflags[3]), "visited_nodes": int(pflags[4]),
+                           "cycle_stamps": [int(v) for v in pflags[8:11]]},
             },
             "roofline": {
                 "bound": "hbm",

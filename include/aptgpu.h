@@ -160,10 +160,14 @@ int aptgpu_plan_get_info(const aptgpu_plan *plan, aptgpu_plan_info *info);
 
 /* Enqueue decode() of `count` independent recordings already resident in HBM.
  * d_signals[i] points to n[i] device floats; d_rows[i] receives up to
- * rows_cap[i]*2080 device floats.  Asynchronous on the plan's stream (or
- * ctx.stream given at plan creation): no host synchronisation, so it can be
- * captured in a hipGraph.  Outcome per recording lands in the plan's result
- * records. */
+ * rows_cap[i]*2080 device floats.  Asynchronous, no host synchronisation.
+ * The plan runs a two-stream software pipeline: the front end of recording
+ * i+1 (also across consecutive calls) overlaps the peak picker and row gather
+ * of recording i, handing max_batch+1 workspace slots over with events.  If
+ * ctx.stream was given at plan creation the work is ordered AFTER what is
+ * already enqueued on ctx.stream (inputs may be produced there); to order
+ * ctx.stream after the decode, call aptgpu_plan_join().  Outcome per recording
+ * lands in the plan's result records. */
 int aptgpu_plan_decode_device(aptgpu_plan *plan, int count, const float *const *d_signals,
                               const size_t *n, float *const *d_rows, const size_t *rows_cap,
                               char *err, size_t err_cap);
@@ -174,6 +178,9 @@ int aptgpu_plan_results(aptgpu_plan *plan, int count, aptgpu_result *results);
 int aptgpu_plan_sync_positions(aptgpu_plan *plan, int i, uint64_t *pos, size_t cap,
                                size_t *n_sync);
 int aptgpu_plan_synchronize(aptgpu_plan *plan);
+/* Makes ctx.stream wait, on the device, for everything the plan has enqueued
+ * so far (host does not block).  Without a ctx.stream: same as synchronize. */
+int aptgpu_plan_join(aptgpu_plan *plan);
 
 /* Kernel timing with HIP events recorded on the plan's stream.  on = 0: off;
  * 1: only the dominant (first-stage) kernel of each decode is bracketed; 2: every

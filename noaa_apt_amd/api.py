@@ -158,6 +158,7 @@ def lib():
     L.aptgpu_plan_results.argtypes = [vp, i32, C.POINTER(Result)]
     L.aptgpu_plan_sync_positions.argtypes = [vp, i32, _u64p, sz, C.POINTER(sz)]
     L.aptgpu_plan_synchronize.argtypes = [vp]
+    L.aptgpu_plan_join.argtypes = [vp]
     L.aptgpu_plan_read_internal.argtypes = [vp, i32, C.c_char_p, vp, sz, C.POINTER(sz)]
     L.aptgpu_plan_enable_timing.argtypes = [vp, i32]
     L.aptgpu_plan_collect_timing.argtypes = [vp, C.POINTER(KernelTime), sz, C.POINTER(sz)]
@@ -478,6 +479,10 @@ class Plan:
 
     def synchronize(self):
         _check(lib().aptgpu_plan_synchronize(self._p))
+
+    def join(self):
+        """Order the caller's stream (given at creation) after everything enqueued so far."""
+        _check(lib().aptgpu_plan_join(self._p))
 
     def enable_timing(self, mode=2):
         """0/False off, 1 dominant kernel only, 2/True every kernel launch."""

@@ -123,7 +123,15 @@ void aptgpu_plan_destroy(aptgpu_plan *plan)
     if (!plan) return;
     (void)hipSetDevice(plan->device);
     if (plan->stream) (void)hipStreamSynchronize(plan->stream);
-    if (plan->own_stream && plan->stream) (void)hipStreamDestroy(plan->stream);
+    if (plan->stream2) (void)hipStreamSynchronize(plan->stream2);
+    for (auto &sl : plan->slots) {
+        if (sl.ev_front) (void)hipEventDestroy(sl.ev_front);
+        if (sl.ev_free) (void)hipEventDestroy(sl.ev_free);
+    }
+    if (plan->ev_user) (void)hipEventDestroy(plan->ev_user);
+    if (plan->ev_nodes) (void)hipEventDestroy(plan->ev_nodes);
+    if (plan->stream) (void)hipStreamDestroy(plan->stream);
+    if (plan->stream2) (void)hipStreamDestroy(plan->stream2);
     delete plan;
 }
 
@@ -156,11 +164,12 @@ int aptgpu_plan_decode_device(aptgpu_plan *plan, int count, const float *const *
     }
     return guarded(err, err_cap, [&] {
         apt::hip_check(hipSetDevice(plan->device), "hipSetDevice");
-        for (int i = 0; i < count; ++i) {
+        for (int i = 0; i < count; ++i)
             if (n[i] > plan->max_samples)
                 throw Error{ErrorKind::Invalid, "recording longer than the plan's max_samples"};
+        plan->begin_call(count);
+        for (int i = 0; i < count; ++i)
             plan->enqueue(i, d_signals[i], n[i], d_rows[i], rows_cap[i] * 2080u, false);
-        }
         return APTGPU_OK;
     });
 }
@@ -169,37 +178,66 @@ int aptgpu_plan_synchronize(aptgpu_plan *plan)
 {
     if (!plan) return APTGPU_ERR_INVALID;
     (void)hipSetDevice(plan->device);
-    return hipStreamSynchronize(plan->stream) == hipSuccess ? APTGPU_OK : APTGPU_ERR_HIP;
+    try {
+        plan->sync_all();
+    } catch (const Error &) {
+        return APTGPU_ERR_HIP;
+    }
+    return APTGPU_OK;
+}
+
+int aptgpu_plan_join(aptgpu_plan *plan)
+{
+    if (!plan) return APTGPU_ERR_INVALID;
+    if (!plan->user_stream) return aptgpu_plan_synchronize(plan);
+    (void)hipSetDevice(plan->device);
+    // ctx.stream waits (on the device) for everything enqueued so far on both internal streams
+    for (hipStream_t st : {plan->stream, plan->stream2}) {
+        if (hipEventRecord(plan->ev_user, st) != hipSuccess ||
+            hipStreamWaitEvent(plan->user_stream, plan->ev_user, 0) != hipSuccess)
+            return APTGPU_ERR_HIP;
+    }
+    return APTGPU_OK;
 }
 
 int aptgpu_plan_results(aptgpu_plan *plan, int count, aptgpu_result *results)
 {
-    if (!plan || !results || count < 0 || count > plan->max_batch) return APTGPU_ERR_INVALID;
+    if (!plan || !results || count < 0 || static_cast<size_t>(count) > plan->last_slots.size())
+        return APTGPU_ERR_INVALID;
     static_assert(sizeof(aptgpu_result) == sizeof(apt::gpu::Result), "result layout");
     (void)hipSetDevice(plan->device);
-    if (hipMemcpyAsync(results, plan->d_results.ptr, sizeof(aptgpu_result) * count,
-                       hipMemcpyDeviceToHost, plan->stream) != hipSuccess)
+    try {
+        plan->sync_all();
+    } catch (const Error &) {
         return APTGPU_ERR_HIP;
-    return hipStreamSynchronize(plan->stream) == hipSuccess ? APTGPU_OK : APTGPU_ERR_HIP;
+    }
+    for (int i = 0; i < count; ++i)
+        if (hipMemcpy(results + i, plan->result_of(i), sizeof(aptgpu_result), hipMemcpyDeviceToHost) !=
+            hipSuccess)
+            return APTGPU_ERR_HIP;
+    return APTGPU_OK;
 }
 
 int aptgpu_plan_sync_positions(aptgpu_plan *plan, int i, uint64_t *pos, size_t cap, size_t *n_sync)
 {
-    if (!plan || i < 0 || i >= plan->max_batch || !n_sync) return APTGPU_ERR_INVALID;
+    if (!plan || i < 0 || static_cast<size_t>(i) >= plan->last_slots.size() || !n_sync)
+        return APTGPU_ERR_INVALID;
     aptgpu_result r{};
     (void)hipSetDevice(plan->device);
-    if (hipMemcpyAsync(&r, plan->d_results.ptr + i, sizeof r, hipMemcpyDeviceToHost,
-                       plan->stream) != hipSuccess ||
-        hipStreamSynchronize(plan->stream) != hipSuccess)
+    try {
+        plan->sync_all();
+    } catch (const Error &) {
+        return APTGPU_ERR_HIP;
+    }
+    if (hipMemcpy(&r, plan->result_of(i), sizeof r, hipMemcpyDeviceToHost) != hipSuccess)
         return APTGPU_ERR_HIP;
     *n_sync = r.n_sync;
     size_t take = r.n_sync < cap ? r.n_sync : cap;
     if (!plan->sync || !pos || take == 0) return APTGPU_OK;
-    if (take > plan->slots[i].peaks.count) take = plan->slots[i].peaks.count;
+    if (take > plan->slot_of(i).peaks.count) take = plan->slot_of(i).peaks.count;
     std::vector<uint32_t> tmp(take);
-    if (hipMemcpyAsync(tmp.data(), plan->slots[i].peaks.ptr, take * sizeof(uint32_t),
-                       hipMemcpyDeviceToHost, plan->stream) != hipSuccess ||
-        hipStreamSynchronize(plan->stream) != hipSuccess)
+    if (hipMemcpy(tmp.data(), plan->slot_of(i).peaks.ptr, take * sizeof(uint32_t),
+                  hipMemcpyDeviceToHost) != hipSuccess)
         return APTGPU_ERR_HIP;
     for (size_t k = 0; k < take; ++k) pos[k] = tmp[k];
     return APTGPU_OK;
@@ -217,6 +255,7 @@ int aptgpu_plan_collect_timing(aptgpu_plan *plan, aptgpu_kernel_time *out, size_
     if (!plan || !n_out) return APTGPU_ERR_INVALID;
     try {
         (void)hipSetDevice(plan->device);
+        plan->sync_all();
         auto v = plan->timer.collect(plan->stream);
         *n_out = v.size();
         for (size_t i = 0; i < v.size() && i < cap && out; ++i) out[i] = v[i];
@@ -229,8 +268,9 @@ int aptgpu_plan_collect_timing(aptgpu_plan *plan, aptgpu_kernel_time *out, size_
 int aptgpu_plan_read_internal(aptgpu_plan *plan, int i, const char *name, void *host_out,
                               size_t bytes, size_t *size_out)
 {
-    if (!plan || !name || i < 0 || i >= plan->max_batch) return APTGPU_ERR_INVALID;
-    aptgpu_plan::Slot &sl = plan->slots[static_cast<size_t>(i)];
+    if (!plan || !name || i < 0 || static_cast<size_t>(i) >= plan->last_slots.size())
+        return APTGPU_ERR_INVALID;
+    aptgpu_plan::Slot &sl = plan->slot_of(i);
     const void *src = nullptr;
     size_t size = 0;
     const std::string n(name);
@@ -243,7 +283,11 @@ int aptgpu_plan_read_internal(aptgpu_plan *plan, int i, const char *name, void *
     else return APTGPU_ERR_INVALID;
     if (size_out) *size_out = size;
     (void)hipSetDevice(plan->device);
-    if (hipStreamSynchronize(plan->stream) != hipSuccess) return APTGPU_ERR_HIP;
+    try {
+        plan->sync_all();
+    } catch (const Error &) {
+        return APTGPU_ERR_HIP;
+    }
     const size_t take = bytes < size ? bytes : size;
     if (take && host_out && src &&
         hipMemcpy(host_out, src, take, hipMemcpyDeviceToHost) != hipSuccess)
@@ -276,7 +320,6 @@ int aptgpu_decode(const aptgpu_context *ctx_in, const aptgpu_settings *settings,
         if (plan->spr == 0) throw Error{ErrorKind::Invalid, "work_rate too small"};
         hipStream_t s = plan->stream;
         const uint64_t w = plan->work_len_for(n);
-        aptgpu_plan::Slot &sl = plan->slots[0];
 
         apt::DeviceBuffer<float> d_in, d_rows;
         d_in.alloc(n + 16);
@@ -286,7 +329,10 @@ int aptgpu_decode(const aptgpu_context *ctx_in, const aptgpu_settings *settings,
             sync ? static_cast<uint64_t>(plan->max_rows) * 2080u : plan->out_len_nosync(w) + 16;
         d_rows.alloc(out_cap);
 
+        plan->begin_call(1);
         plan->enqueue(0, d_in.ptr, n, d_rows.ptr, out_cap, steps);
+        aptgpu_plan::Slot &sl = plan->slot_of(0);
+        if (steps) plan->sync_all();  // the step exports below read the slot's buffers
 
         // dsp.rs:96 / :106 — the resample filter, then the resample steps
         step(&ctx, steps, "resample_filter", 1, plan->taps_resample.data(),
@@ -330,7 +376,7 @@ int aptgpu_decode(const aptgpu_context *ctx_in, const aptgpu_settings *settings,
                 // "sync_result": the aligned rows at work_rate (decode.rs:150)
                 apt::DeviceBuffer<float> d_al;
                 d_al.alloc(static_cast<uint64_t>(res.n_rows) * plan->spr + 16);
-                apt::gpu::gather_rows(s, sl.filtered.ptr, sl.peaks.ptr, plan->d_results.ptr, plan->spr,
+                apt::gpu::gather_rows(s, sl.filtered.ptr, sl.peaks.ptr, plan->result_of(0), plan->spr,
                                       1, true, d_al.ptr, res.n_rows);
                 apt::Signal al = download(d_al.ptr, static_cast<uint64_t>(res.n_rows) * plan->spr, s);
                 step(&ctx, steps, "sync_result", 0, al.data(), al.size(), work);
@@ -338,7 +384,7 @@ int aptgpu_decode(const aptgpu_context *ctx_in, const aptgpu_settings *settings,
                 // final resample_with_filter(NoFilter), l == 1 branch (dsp.rs:106-122)
                 const float one = 1.f;
                 step(&ctx, steps, "resample_filter", 1, &one, 1, 0);
-                apt::gpu::gather_rows(s, sl.filtered.ptr, sl.peaks.ptr, plan->d_results.ptr, plan->spr,
+                apt::gpu::gather_rows(s, sl.filtered.ptr, sl.peaks.ptr, plan->result_of(0), plan->spr,
                                       1, false, d_al.ptr, res.n_rows);
                 al = download(d_al.ptr, static_cast<uint64_t>(res.n_rows) * plan->spr, s);
                 step(&ctx, steps, "filter_filter", 1, &one, 1, 0);
@@ -650,11 +696,15 @@ int aptgpu_find_sync(const aptgpu_context *ctx, const float *signal, size_t n,
             d_flags.alloc(32);
             apt::hip_check(hipMemsetAsync(d_flags.ptr, 0, 32 * sizeof(uint32_t), sc.stream), "hipMemsetAsync");
             const char *fw = std::getenv("APTGPU_FORCE_WALK");
+            const char *fg = std::getenv("APTGPU_PICKER_LDS");
             apt::gpu::group_max(sc.stream, d_c.ptr, n_corr, d_gm.ptr);
             apt::gpu::sync_nodes(sc.stream, d_gm.ptr, d_c.ptr, n_corr, spr, md, d_words.ptr, d_slot.ptr,
                                  d_cnt.ptr, d_flags.ptr);
+            apt::DeviceBuffer<uint32_t> d_ws;
+            d_ws.alloc(apt::gpu::sync_orbit_ws_words(n_corr, spr));
             apt::gpu::sync_orbit(sc.stream, d_words.ptr, d_slot.ptr, d_cnt.ptr, d_flags.ptr, n_corr, n,
-                                 spr, md, d_peaks.ptr, cap, d_res.ptr, fw && fw[0] == '1');
+                                 spr, md, d_ws.ptr, d_peaks.ptr, cap, d_res.ptr,
+                                 (fw && fw[0] == '1') ? 1 : ((fg && fg[0] == '1') ? 4 : 0));
             apt::hip_check(hipStreamSynchronize(sc.stream), "hipStreamSynchronize");
         }
         apt::gpu::Result r{};

@@ -69,10 +69,11 @@ void group_max(hipStream_t s, const float *corr, uint64_t n_corr, float *gm);
 void sync_nodes(hipStream_t s, const float *gm, const float *corr, uint64_t n_corr, uint32_t spr,
                 uint32_t md, uint64_t *words, uint32_t *slot_nt, uint32_t *slot_cnt, uint32_t *flags);
 // orbit of the picker (LDS pointer doubling, or the sequential walk as fallback)
+size_t sync_orbit_ws_words(uint64_t n_corr, uint32_t spr);  // uint32 words of scratch it needs
 void sync_orbit(hipStream_t s, const uint64_t *words, const uint32_t *slot_nt,
                 const uint32_t *slot_cnt, uint32_t *flags, uint64_t n_corr, uint64_t work_len,
-                uint32_t spr, uint32_t md, uint32_t *peaks, uint32_t peaks_cap, Result *res,
-                bool force_walk);
+                uint32_t spr, uint32_t md, uint32_t *ws, uint32_t *peaks, uint32_t peaks_cap,
+                Result *res, int force /* 0 global-memory kernel, 1 sequential walk, 4 LDS kernel first */);
 
 // writes a result record from the host's knowledge (too-short recording, no-sync path)
 void set_result(hipStream_t s, Result *res, Result value);

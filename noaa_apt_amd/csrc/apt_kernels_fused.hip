@@ -78,7 +78,8 @@ struct FusedGeom {
     static constexpr int LDS_FLOATS = XT_PAD > (C_OFF + TILE_K) ? XT_PAD : (C_OFF + TILE_K);
     static constexpr int GS = 4 * L;                                  // correlation group size
     static constexpr int NP = L / 2;                                  // accumulator pairs (+1 single if L odd)
-    static constexpr int PS = NP + (L & 1);                           // f2 tap entries per window sample
+    static constexpr int PS = NP;                                     // f2 tap entries per window sample
+    static constexpr int HL_OFF = 2 * ((CLAST + (T1 + L - 1) / L) * NP);  // float offset of the odd branch's taps
     static constexpr int DW = L + T2 - 1;                             // envelope window per thread
     static_assert(PRE_K >= T2 + 1, "pre-halo too small for the low-pass");
     static_assert((kFusedThreads - kPreThreads - kOwnThreads) * L >= G - 1, "post-halo too small");
@@ -159,36 +160,67 @@ k_fused(const float *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WI
     const int kt = kq - k_lo;      // ... and as a global work-sample index clamped to int
     float r[L];
     {
-        constexpr int CH = 4;
+        // Software pipeline over chunks of CH window samples: SMEM returns out of order, so the
+        // only usable wait is lgkmcnt(0).  Each chunk therefore (1) consumes its first tap —
+        // which makes the compiler wait for exactly the loads issued one chunk ago — (2) issues
+        // the loads of the NEXT chunk, (3) computes the rest under their latency.
+        constexpr int CH = 2;
+        constexpr int NCH = (Gm::WIN + CH - 1) / CH;
         const float *src = P + tid * M;
         f2 acc[Gm::NP > 0 ? Gm::NP : 1];
         float accl = 0.f;
 #pragma unroll
         for (int pp = 0; pp < Gm::NP; ++pp) acc[pp] = (f2){0.f, 0.f};
-        static_for<0, (Gm::WIN + CH - 1) / CH>([&](auto cc) {
-            constexpr int q0 = decltype(cc)::value * CH;
-            float xv[CH];
+        f2 tb[2][CH * Gm::PS];   // tap pairs of the chunk in use / in flight (SGPRs)
+        float tl[2][CH];         // taps of the odd branch L-1 (contiguous per sample: aligned pairs)
+        float xb[2][CH];         // window samples of the chunk in use / in flight
+        const float *hl = reinterpret_cast<const float *>(hs) + Gm::HL_OFF;
+        auto issue = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int buf = c & 1;
 #pragma unroll
-            for (int e = 0; e < CH; ++e) xv[e] = (q0 + e < Gm::WIN) ? src[q0 + e] : 0.f;
-            static_for<0, CH>([&](auto ee) {
-                constexpr int q = q0 + decltype(ee)::value;
-                if constexpr (q < Gm::WIN) {
-                    const float xq = xv[decltype(ee)::value];
-                    static_for<0, Gm::NP>([&](auto pc) {
-                        constexpr int pp = decltype(pc)::value;
-                        constexpr bool va = branch_uses<L, M, T1>(2 * pp, q);
-                        constexpr bool vb = branch_uses<L, M, T1>(2 * pp + 1, q);
-                        if constexpr (va && vb) {
-                            acc[pp] = acc[pp] + hs[q * Gm::PS + pp] * (f2){xq, xq};
-                        } else if constexpr (va) {
-                            acc[pp].x = acc[pp].x + hs[q * Gm::PS + pp].x * xq;
-                        } else if constexpr (vb) {
-                            acc[pp].y = acc[pp].y + hs[q * Gm::PS + pp].y * xq;
-                        }
-                    });
-                    if constexpr ((L & 1) && branch_uses<L, M, T1>(L - 1, q))
-                        accl = accl + hs[q * Gm::PS + Gm::NP].x * xq;
+            for (int e = 0; e < CH; ++e) {
+                const int q = c * CH + e;
+                xb[buf][e] = (q < Gm::WIN) ? src[q] : 0.f;
+                if constexpr (L & 1) tl[buf][e] = (q < Gm::WIN) ? hl[q] : 0.f;
+#pragma unroll
+                for (int k = 0; k < Gm::PS; ++k)
+                    tb[buf][e * Gm::PS + k] = (q < Gm::WIN) ? hs[q * Gm::PS + k] : (f2){0.f, 0.f};
+            }
+        };
+        auto mac = [&](auto cc, auto ee, auto kk) {
+            constexpr int c = decltype(cc)::value, e = decltype(ee)::value, k = decltype(kk)::value;
+            constexpr int buf = c & 1;
+            constexpr int q = c * CH + e;
+            if constexpr (q < Gm::WIN) {
+                const float xq = xb[buf][e];
+                if constexpr (k < Gm::NP) {
+                    const f2 t = tb[buf][e * Gm::PS + k];
+                    constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
+                    constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
+                    if constexpr (va && vb) {
+                        acc[k] = acc[k] + t * (f2){xq, xq};
+                    } else if constexpr (va) {
+                        acc[k].x = acc[k].x + t.x * xq;
+                    } else if constexpr (vb) {
+                        acc[k].y = acc[k].y + t.y * xq;
+                    }
+                } else if constexpr (branch_uses<L, M, T1>(L - 1, q)) {
+                    accl = accl + tl[buf][e] * xq;
                 }
+            }
+        };
+        issue(std::integral_constant<int, 0>{});
+        static_for<0, NCH>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            mac(cc, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (c + 1 < NCH) issue(std::integral_constant<int, c + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, CH>([&](auto ee) {
+                static_for<0, Gm::PS + (L & 1)>([&](auto kk) {
+                    if constexpr (!(decltype(ee)::value == 0 && decltype(kk)::value == 0)) mac(cc, ee, kk);
+                });
             });
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -409,24 +441,23 @@ bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t 
 
 uint32_t fused_group_size(uint32_t l) { return 4 * l; }
 
-// floats in the stage-1 tap-pair table: [WIN][PS] pairs
+// floats in the stage-1 tap tables: [WIN][NP] pairs, then [WIN] taps of the odd branch L-1
 uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1)
 {
     const uint32_t tp = (t1 + l - 1) / l;
     const uint32_t clast = ((l - 1) * m + l - 1) / l;
     const uint32_t win = clast + tp;
-    const uint32_t ps = l / 2 + (l & 1);
-    return win * ps * 2;
+    return win * (l / 2) * 2 + win + 2;
 }
 
-// host: stage-1 table hs[q][pp] = (tap of branch 2pp at window sample q, tap of branch 2pp+1),
-// 0 where a branch does not use q; last entry of a row = (tap of the odd branch L-1, 0)
+// host: hs[q][pp] = (tap of branch 2pp at window sample q, tap of branch 2pp+1), 0 where a branch
+// does not use q; after the pairs, hl[q] = tap of the odd branch L-1 at q
 void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, float *hs)
 {
     const uint32_t tp = (t1 + l - 1) / l;
     const uint32_t clast = ((l - 1) * m + l - 1) / l;
     const uint32_t win = clast + tp;
-    const uint32_t np = l / 2, ps = np + (l & 1);
+    const uint32_t np = l / 2;
     auto tap = [&](uint32_t b, uint32_t q) -> float {
         const uint32_t cb = (b * m + l - 1) / l;
         const uint32_t pb = cb * l - b * m;
@@ -434,15 +465,13 @@ void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, 
         const uint64_t j = pb + static_cast<uint64_t>(q - cb) * l;
         return j < t1 ? coeff[j] : 0.f;
     };
+    float *hl = hs + static_cast<size_t>(win) * np * 2;
     for (uint32_t q = 0; q < win; ++q) {
         for (uint32_t pp = 0; pp < np; ++pp) {
-            hs[(q * ps + pp) * 2] = tap(2 * pp, q);
-            hs[(q * ps + pp) * 2 + 1] = tap(2 * pp + 1, q);
+            hs[(q * np + pp) * 2] = tap(2 * pp, q);
+            hs[(q * np + pp) * 2 + 1] = tap(2 * pp + 1, q);
         }
-        if (l & 1) {
-            hs[(q * ps + np) * 2] = tap(l - 1, q);
-            hs[(q * ps + np) * 2 + 1] = 0.f;
-        }
+        hl[q] = (l & 1) ? tap(l - 1, q) : 0.f;
     }
 }
 

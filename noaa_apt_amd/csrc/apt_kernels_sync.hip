@@ -62,10 +62,10 @@ k_group_max(const float *__restrict__ corr, uint64_t n_corr, float *__restrict__
 }
 
 // ------------------------------------------------------------------ k_sync_nodes
-constexpr int kNodesThreads = 256;
-constexpr int kChunkGroups = 256;  // own groups per workgroup
+constexpr int kNodesThreads = 128;
+constexpr int kChunkGroups = 128;  // own groups per workgroup
 constexpr int kRMax = 416;         // md/GS <= 416  (work_rate <= 54080)
-constexpr int kSlotCap = 96;       // node terminals kept per chunk before "overflow"
+constexpr int kSlotCap = 64;       // node terminals kept per chunk before "overflow"
 
 __global__ void __launch_bounds__(kNodesThreads)
 k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict__ corr,
@@ -73,18 +73,21 @@ k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict_
              uint64_t *__restrict__ words_out, uint32_t *__restrict__ slot_nt,
              uint32_t *__restrict__ slot_cnt, uint32_t *__restrict__ flags)
 {
-    // window of groups [gw0, gw0 + nwin): gw0 = g0 - R - 1, nwin = CG + R + 1
-    __shared__ float s_gm[kChunkGroups + 2 * kRMax + 2];
-    __shared__ float s_wm[kChunkGroups + kRMax + 1];
-    __shared__ uint64_t s_words[kChunkGroups + kRMax + 1];
-    __shared__ uint16_t s_cand[kChunkGroups + kRMax + 1];
+    // window of groups [gw0, gw0 + nwin): gw0 = g0 - R - 1, nwin = CG + R + 1.  LDS is sized
+    // at launch for the actual R (4.4 KB at R = 96) so these workgroups fit beside the front
+    // end of the next recording, which leaves only ~5 KB of LDS free per CU.
+    extern __shared__ uint64_t lds_nodes[];
+    const int R = static_cast<int>(r_groups);
+    uint64_t *s_words = lds_nodes;                                           // [CG + R + 1]
+    float *s_gm = reinterpret_cast<float *>(s_words + (kChunkGroups + R + 1));  // [CG + 2R + 2]
+    float *s_wm = s_gm + (kChunkGroups + 2 * R + 2);                         // [CG + R + 1]
+    uint16_t *s_cand = reinterpret_cast<uint16_t *>(s_wm + (kChunkGroups + R + 1));  // [CG + R + 1]
     __shared__ uint32_t s_ncand;
     __shared__ uint32_t s_scan[kNodesThreads / 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int R = static_cast<int>(r_groups);
     const int64_t g0 = static_cast<int64_t>(blockIdx.x) * kChunkGroups;
     const int64_t gw0 = g0 - R - 1;
     const int nwin = kChunkGroups + R + 1;
@@ -211,12 +214,12 @@ k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict_
 
 // ------------------------------------------------------------------ k_sync_orbit
 constexpr int kOrbitThreads = 1024;
-constexpr int kNtCap = 16384;   // node terminals held in LDS
-constexpr int kCellCap = 8192;  // image rows (grid cells) handled by the doubling path
+constexpr int kMaxLevels = 64;    // breadth-first levels before giving up on the fast path
+// capacities of the LDS-resident kernel (the global-memory kernel has none)
+constexpr int kNtCap = 16384;     // node terminals held in LDS
+constexpr int kCellCap = 8192;    // image rows (grid cells)
 constexpr int kNodeCap = kNtCap + kCellCap + 2;
-constexpr int kMaxChunks = 16384;
 constexpr int kListCap = 8192;    // nodes the marked (reachable) set may hold
-constexpr int kMaxLevels = 48;    // breadth-first levels before giving up on the fast path
 
 struct OrbitGeom {
     uint64_t n_corr, work_len;
@@ -297,8 +300,9 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t 
     return lo;
 }
 
+// ---- LDS-resident picker: fastest, bounded capacity (147 KB of LDS, one workgroup)
 __global__ void __launch_bounds__(kOrbitThreads)
-k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ slot_nt,
+k_sync_orbit_lds(const uint64_t *__restrict__ words, const uint32_t *__restrict__ slot_nt,
              const uint32_t *__restrict__ slot_cnt, uint32_t n_chunks,
              uint32_t *__restrict__ flags, OrbitGeom gq, uint32_t *__restrict__ peaks,
              uint32_t peaks_cap, Result *__restrict__ res, int force_walk)
@@ -334,12 +338,13 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
 
     // number of grid cells that can hold a start: c in [2, kc]
     const uint64_t kc = n_corr ? (n_corr - 1) / spr : 0;
-    bool walk = force_walk != 0 || flags[0] != 0 || kc + 2 > kCellCap || n_chunks > kMaxChunks ||
-                n_corr == 0 || gq.work_len >= (1ull << 31);
+    bool walk = force_walk == 1 || flags[0] != 0 || n_corr == 0 || gq.work_len >= (1ull << 31);
+    // beyond the LDS capacities the global-memory kernel (launched next) takes over
+    bool defer = !walk && (force_walk == 2 || kc + 2 > kCellCap || n_chunks > kOrbitThreads * 16);
 
     // ---- gather the per-chunk node-terminal lists into one sorted LDS array
     uint32_t total = 0;
-    if (!walk) {
+    if (!walk && !defer) {
         const uint32_t per = (n_chunks + kOrbitThreads - 1) / kOrbitThreads;
         const uint32_t c_lo = tid * per;
         uint32_t mine = 0;
@@ -357,8 +362,10 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
         if (tid == kOrbitThreads - 1) s_total = base + inc;
         __syncthreads();
         total = s_total;
-        if (total > kNtCap || total == 0) {
-            walk = true;  // uniform: s_total is shared
+        if (total > kNtCap) {
+            defer = true;  // uniform: s_total is shared
+        } else if (total == 0) {
+            walk = true;
         } else {
             uint32_t ofs = base + inc - mine;
             for (uint32_t e = 0; e < per; ++e) {
@@ -383,6 +390,10 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
         __syncthreads();
     }
     stamp(0);  // node terminals gathered
+    if (defer) {
+        if (tid == 0) flags[5] = 1u;  // k_sync_orbit_global runs the picker for this recording
+        return;
+    }
 
     // ---- nodes: 0 = root, 1 .. n_grid = grid cells 2 .. kc, then one per node terminal, END
     const uint32_t n_grid = kc >= 2 ? static_cast<uint32_t>(kc - 1) : 0;
@@ -452,7 +463,10 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
             hi = s_count < kListCap ? s_count : kListCap;
             __syncthreads();
         }
-        if (lo < hi || s_bad) walk = true;  // not closed within the budget: take the general path
+        if (lo < hi || s_bad) {  // not closed within the LDS budget: the global kernel takes over
+            if (tid == 0) flags[5] = 1u;
+            return;
+        }
         count = hi;
     }
     stamp(1);  // reachable set closed
@@ -541,6 +555,253 @@ k_sync_orbit(const uint64_t *__restrict__ words, const uint32_t *__restrict__ sl
     stamp(3);  // peaks written
 }
 
+
+// Relaxed agent-scope accesses: the tables below live in global memory (L2) and are written
+// and re-read inside one launch; these bypass the CU's L1 so a __syncthreads() is enough to
+// hand data between the threads of the (single) workgroup.
+__device__ __forceinline__ uint32_t gld(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gst(uint32_t *p, uint32_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t lower_bound_g(const uint32_t *a, uint32_t lo, uint32_t hi, uint32_t key)
+{
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (gld(a + mid) < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// One workgroup; every table in the global scratch `ws` (sized by sync_orbit_ws_words()), so
+// the kernel needs almost no LDS and can run beside the next recording's front end.  Node
+// terminals are looked up straight in the per-chunk slots k_sync_nodes wrote (no gather pass):
+// chunk = position / (128*52), then the first entry >= s of that slot or of the next
+// non-empty one.  Node ids: 0 root, 1..n_grid grid cells 2..kc, base_d + slot entry, END.
+__global__ void __launch_bounds__(kOrbitThreads, 8)
+k_sync_orbit_global(const uint64_t *__restrict__ words, const uint32_t *__restrict__ slot_nt,
+             const uint32_t *__restrict__ slot_cnt, uint32_t n_chunks, uint32_t *__restrict__ flags,
+             OrbitGeom gq, uint32_t *__restrict__ ws, uint32_t nt_cap, uint32_t *__restrict__ peaks,
+             uint32_t peaks_cap, Result *__restrict__ res, int force_walk)
+{
+    // after the LDS-resident kernel (force_walk == 3) it runs only if that kernel handed the
+    // recording over (flags[5]); on its own it is the default picker
+    if (force_walk == 3) {
+        if (flags[5] == 0) return;
+        force_walk = 0;
+    }
+    __shared__ uint32_t s_count, s_plen;
+    __shared__ unsigned long long s_fit;
+    // this latency-bound workgroup shares its CU with VALU-saturated front-end waves of the next
+    // recording: let its few instructions issue first
+    __builtin_amdgcn_s_setprio(3);
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const uint64_t n_corr = gq.n_corr;
+    const uint32_t spr = gq.spr, md = gq.md;
+    const uint32_t spr_magic = static_cast<uint32_t>((1ull << 32) / spr);
+    auto div_spr = [&](uint32_t sv) -> uint32_t {  // sv / spr by multiply-high + two corrections
+        uint32_t q = __umulhi(sv, spr_magic);
+        uint32_t r = sv - q * spr;
+        if (r >= spr) { ++q; r -= spr; }
+        if (r >= spr) ++q;
+        return q;
+    };
+    const uint64_t t_begin = __builtin_readcyclecounter();
+    auto stamp = [&](int k) {
+        if (tid == 0) flags[8 + k] = static_cast<uint32_t>(__builtin_readcyclecounter() - t_begin);
+    };
+
+    const uint64_t kc64 = n_corr ? (n_corr - 1) / spr : 0;  // cells that can hold a start: 2 .. kc
+    bool walk = force_walk == 1 || flags[0] != 0 || n_corr == 0 || gq.work_len >= (1ull << 31);
+    const uint32_t kc = static_cast<uint32_t>(kc64);
+
+    // ---- workspace carve-up (uint32 words)
+    const uint32_t n_grid = kc >= 2 ? kc - 1 : 0;
+    const uint32_t base_d = 1 + n_grid;
+    const uint32_t END = base_d + nt_cap;
+    const uint32_t n_nodes = END + 1;
+    uint32_t *w_ja = ws;                      // [n_nodes] next / jump table
+    uint32_t *w_jb = w_ja + n_nodes;          // [n_nodes] double buffer
+    uint32_t *w_u = w_jb + n_nodes;           // [n_nodes] terminal reached from the node's start
+    uint32_t *w_list = w_u + n_nodes;         // [n_nodes] visited nodes
+    uint32_t *w_mark = w_list + n_nodes;      // [n_nodes/32 + 1]
+    uint32_t *w_path = w_mark + (n_nodes / 32 + 1);  // [kc + 2]
+    const uint32_t nc32 = static_cast<uint32_t>(n_corr);
+    const uint32_t wl32 = static_cast<uint32_t>(gq.work_len);
+    constexpr uint32_t kChunkSpan = kChunkGroups * GS;  // positions per chunk
+
+    // first node terminal at or after sv: (slot entry index, value); slots were written by the
+    // previous kernel, so plain (cached) loads are fine
+    auto first_node_terminal = [&](uint32_t sv, uint32_t *uval) -> uint32_t {
+        uint32_t ch = sv / kChunkSpan;
+        for (; ch < n_chunks; ++ch) {
+            const uint32_t cnt = slot_cnt[ch];
+            if (cnt == 0) continue;
+            const uint4 *src = reinterpret_cast<const uint4 *>(slot_nt + static_cast<uint64_t>(ch) * kSlotCap);
+            const uint32_t lim = cnt < kSlotCap ? cnt : kSlotCap;
+            for (uint32_t j = 0; 4 * j < lim; j += 4) {  // 16 entries per round trip
+                uint4 v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (4 * (j + e) < lim) ? src[j + e] : make_uint4(~0u, ~0u, ~0u, ~0u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t k0 = 4 * (j + e);
+                    const uint32_t vals[4] = {v[e].x, v[e].y, v[e].z, v[e].w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (k0 + t < lim && vals[t] >= sv) { *uval = vals[t]; return ch * kSlotCap + k0 + t; }
+                }
+            }
+        }
+        *uval = nc32 - 1;  // cannot happen (fact 3)
+        return nt_cap - 1;
+    };
+    auto node_start = [&](uint32_t v, uint32_t *cell) -> uint32_t {
+        if (v == 0) { *cell = 1; return 0; }
+        if (v < base_d) { *cell = v + 1; return (v + 1) * spr; }
+        const uint32_t sv = slot_nt[v - base_d] + md + 1;
+        *cell = div_spr(sv);
+        return sv;
+    };
+
+    // ---- reachable set by breadth-first marking from the root and every grid node
+    uint32_t count = 0;
+    if (!walk) {
+        for (uint32_t wq = tid; wq < n_nodes / 32 + 1; wq += kOrbitThreads) gst(w_mark + wq, 0u);
+        if (tid == 0) s_count = base_d;
+        __syncthreads();
+        for (uint32_t v = tid; v < base_d; v += kOrbitThreads) {
+            gst(w_list + v, v);
+            atomicOr(w_mark + (v >> 5), 1u << (v & 31));
+        }
+        __syncthreads();
+        uint32_t lo = 0, hi = base_d;
+        for (int level = 0; level < kMaxLevels && lo < hi; ++level) {
+            for (uint32_t idx = lo + tid; idx < hi; idx += kOrbitThreads) {
+                const uint32_t v = gld(w_list + idx);
+                uint32_t cell, u = 0, nx = END;
+                const uint32_t sv = node_start(v, &cell);
+                if (sv < nc32) {
+                    const uint32_t e = first_node_terminal(sv, &u);
+                    const uint32_t a = u + md + 1;
+                    const uint32_t b = (cell + 1) * spr;
+                    const uint32_t s2 = a > b ? a : b;
+                    if (s2 < nc32) nx = (a >= b) ? base_d + e : cell;  // grid(cell+1) has id `cell`
+                }
+                gst(w_ja + v, nx);
+                gst(w_u + v, u);
+                if (nx != END) {
+                    const uint32_t bit = 1u << (nx & 31);
+                    if (!(atomicOr(w_mark + (nx >> 5), bit) & bit)) gst(w_list + atomicAdd(&s_count, 1u), nx);
+                }
+            }
+            __syncthreads();
+            lo = hi;
+            hi = s_count;
+            __syncthreads();
+        }
+        if (lo < hi) walk = true;  // not closed within the level budget: take the general path
+        count = hi;
+    }
+    stamp(0);  // reachable set closed
+
+    if (walk) {
+        if (wave == 0) orbit_walk52(words, gq, peaks, peaks_cap, res);
+        if (tid == 0) {
+            flags[1] = 1u;  // report which path ran
+            flags[0] = 0u;  // re-arm the overflow flag for the next decode
+            flags[5] = 0u;
+        }
+        return;
+    }
+    if (tid == 0) { gst(w_ja + END, END); gst(w_jb + END, END); gst(w_path, 0u); }
+    __syncthreads();
+
+    // ---- orbit of the root by pointer doubling over the visited nodes:
+    // path[m + 2^r] = J_r[path[m]],  J_{r+1} = J_r o J_r (double-buffered)
+    const uint32_t path_cap = kc + 2;  // root + at most one start per cell
+    uint32_t *ja = w_ja, *jb = w_jb;
+    constexpr int kKeep = 4;  // visited ids (and their current jump) kept in registers
+    uint32_t vk[kKeep], jk[kKeep];
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j) {
+        const uint32_t idx = tid + j * kOrbitThreads;
+        vk[j] = (idx < count) ? gld(w_list + idx) : END;
+    }
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j) jk[j] = gld(ja + vk[j]);
+    for (uint32_t span = 1; span < path_cap; span <<= 1) {
+        for (uint32_t mI = tid; mI < span && mI + span < path_cap; mI += kOrbitThreads)
+            gst(w_path + mI + span, gld(ja + gld(w_path + mI)));
+#pragma unroll
+        for (int j = 0; j < kKeep; ++j) jk[j] = gld(ja + jk[j]);  // J[J[v]], one round trip
+#pragma unroll
+        for (int j = 0; j < kKeep; ++j) gst(jb + vk[j], jk[j]);
+        for (uint32_t idx = tid + kKeep * kOrbitThreads; idx < count; idx += kOrbitThreads) {
+            const uint32_t v = gld(w_list + idx);
+            gst(jb + v, gld(ja + gld(ja + v)));
+        }
+        __syncthreads();
+        uint32_t *t = ja; ja = jb; jb = t;
+    }
+    stamp(1);  // orbit extracted
+
+    // ---- peak list: path[k] (k >= 1) starts at s in cell c; pushes fill
+    // peaks[cell(prev) .. c-2] with s and peaks[c-1] with u = firstT(s)
+    if (tid == 0) { s_plen = 1; s_fit = 0ull; }
+    __syncthreads();
+    unsigned long long fit_local = 0;
+    for (uint32_t k = tid; k < path_cap; k += kOrbitThreads) {
+        const uint32_t v = gld(w_path + k);
+        if (v == END) continue;
+        uint32_t cell;
+        const uint32_t sv = node_start(v, &cell);
+        const uint32_t u = gld(w_u + v);
+        const bool is_last = (k + 1 >= path_cap) || gld(w_path + k + 1) == END;
+        if (k == 0) {
+            if (peaks_cap > 0) peaks[0] = u;
+            if (!is_last && u + spr < wl32) ++fit_local;
+            if (is_last) s_plen = 1;
+            continue;
+        }
+        uint32_t pcell;
+        (void)node_start(gld(w_path + k - 1), &pcell);
+        const uint32_t c_prev = (k - 1 == 0) ? 1u : pcell;  // the root leaves one entry
+        const uint32_t c = cell;                             // = s / spr for k >= 1
+        for (uint32_t qv = c_prev; qv + 1 < c; ++qv)
+            if (qv < peaks_cap) peaks[qv] = sv;
+        if (c - 1 < peaks_cap) peaks[c - 1] = u;
+        if (sv + spr < wl32) fit_local += c - c_prev - 1;
+        if (!is_last && u + spr < wl32) ++fit_local;  // the last peak is dropped
+        if (is_last) s_plen = c;
+    }
+    atomicAdd(&s_fit, fit_local);
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t len = s_plen;
+        const bool few = len < 5;  // decode.rs:112-118
+        const uint64_t rows = s_fit;
+        res->status = few ? 1 : 0;
+        res->reason = few ? 2 : 0;
+        res->n_sync = len;
+        res->n_rows = few ? 0 : static_cast<uint32_t>(rows);
+        res->work_len = gq.work_len;
+        res->n_out = few ? 0 : rows * 2080u;
+        flags[1] = 2u;  // the global-memory kernel ran
+        flags[0] = 0u;
+        flags[5] = 0u;
+        flags[2] = nt_cap;
+        flags[3] = n_nodes;
+        flags[4] = count;
+    }
+    stamp(2);  // peaks written
+}
+
 }  // namespace
 
 uint32_t sync_group_size() { return GS; }
@@ -560,29 +821,54 @@ void sync_nodes(hipStream_t s, const float *gm, const float *corr, uint64_t n_co
     const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
     if (ng == 0) return;
     const uint32_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
-    hipLaunchKernelGGL(k_sync_nodes, dim3(chunks), dim3(kNodesThreads), 0, s, gm, ng, corr, n_corr,
-                       md / GS, spr / GS, words, slot_nt, slot_cnt, flags);
+    const uint32_t r = md / GS;
+    const size_t lds = static_cast<size_t>(kChunkGroups + r + 1) * 8 + static_cast<size_t>(kChunkGroups + 2 * r + 2) * 4 +
+                       static_cast<size_t>(kChunkGroups + r + 1) * 4 + static_cast<size_t>(kChunkGroups + r + 1) * 2 + 16;
+    hipLaunchKernelGGL(k_sync_nodes, dim3(chunks), dim3(kNodesThreads), lds, s, gm, ng, corr, n_corr,
+                       r, spr / GS, words, slot_nt, slot_cnt, flags);
+}
+
+// uint32 words of scratch k_sync_orbit needs for a correlation of n_corr positions
+size_t sync_orbit_ws_words(uint64_t n_corr, uint32_t spr)
+{
+    const uint64_t ng = (n_corr + GS - 1) / GS;
+    const uint64_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
+    const uint64_t nt_cap = chunks * kSlotCap;
+    const uint64_t kc = (spr ? n_corr / spr : 0) + 2;
+    const uint64_t node_cap = 1 + kc + nt_cap + 1;
+    return 4 * node_cap + (node_cap / 32 + 1) + (kc + 2) + 64;
 }
 
 void sync_orbit(hipStream_t s, const uint64_t *words, const uint32_t *slot_nt,
                 const uint32_t *slot_cnt, uint32_t *flags, uint64_t n_corr, uint64_t work_len,
-                uint32_t spr, uint32_t md, uint32_t *peaks, uint32_t peaks_cap, Result *res,
-                bool force_walk)
+                uint32_t spr, uint32_t md, uint32_t *ws, uint32_t *peaks, uint32_t peaks_cap,
+                Result *res, int force)
 {
     const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
     const uint32_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
+    OrbitGeom gq{n_corr, work_len, spr, md};
     const size_t lds = static_cast<size_t>(kNtCap) * 4 + static_cast<size_t>(kNodeCap / 32 + 1) * 4 +
                        static_cast<size_t>(kNodeCap) * 2 + static_cast<size_t>(kListCap) * 2 +
                        static_cast<size_t>(kCellCap + 2) * 2 + 64;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_orbit),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_orbit_lds),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         attr_set = true;
     }
-    OrbitGeom gq{n_corr, work_len, spr, md};
-    hipLaunchKernelGGL(k_sync_orbit, dim3(1), dim3(kOrbitThreads), lds, s, words, slot_nt, slot_cnt,
-                       chunks, flags, gq, peaks, peaks_cap, res, force_walk ? 1 : 0);
+    // force: 0 = global-memory kernel (default: tiny LDS, co-runs with the next front end, no
+    // capacity limits), 1 = sequential walk, 2 = same as 0, 4 = LDS-resident kernel first (lowest
+    // stand-alone latency) with the global-memory kernel as its overflow path
+    if (force == 4) {
+        hipLaunchKernelGGL(k_sync_orbit_lds, dim3(1), dim3(kOrbitThreads), lds, s, words, slot_nt, slot_cnt,
+                           chunks, flags, gq, peaks, peaks_cap, res, 0);
+        hipLaunchKernelGGL(k_sync_orbit_global, dim3(1), dim3(kOrbitThreads), 0, s, words, slot_nt,
+                           slot_cnt, chunks, flags, gq, ws, chunks * kSlotCap, peaks, peaks_cap, res, 3);
+    } else {
+        hipLaunchKernelGGL(k_sync_orbit_global, dim3(1), dim3(kOrbitThreads), 0, s, words, slot_nt,
+                           slot_cnt, chunks, flags, gq, ws, chunks * kSlotCap, peaks, peaks_cap, res,
+                           force == 1 ? 1 : 0);
+    }
 }
 
 }  // namespace apt::gpu

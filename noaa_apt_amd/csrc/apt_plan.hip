@@ -101,7 +101,8 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     plan->sync = sync;
     plan->max_samples = max_samples;
     plan->max_batch = max_batch;
-    if (const char *e = std::getenv("APTGPU_FORCE_WALK")) plan->force_walk = e[0] == '1';
+    if (const char *e = std::getenv("APTGPU_FORCE_WALK")) plan->picker_force = e[0] == '1' ? 1 : 0;
+    if (const char *e = std::getenv("APTGPU_PICKER_LDS")) if (e[0] == '1') plan->picker_force = 4;
 
     // decode.rs:55 — u32 arithmetic; the reference would panic on overflow
     const uint64_t spr64 = static_cast<uint64_t>(PX_PER_ROW) * settings.work_rate;
@@ -172,13 +173,17 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
 
     // ---- device side
     hip_check(hipSetDevice(plan->device), "hipSetDevice");
+    hip_check(hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking), "hipStreamCreate");
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
+        hip_check(hipStreamCreateWithPriority(&plan->stream2, hipStreamNonBlocking, hi), "hipStreamCreate");
+    }
+    hip_check(hipEventCreateWithFlags(&plan->ev_nodes, hipEventDisableTiming), "hipEventCreate");
+    if (const char *e = std::getenv("APTGPU_HOLD_FRONT")) plan->hold_front = e[0] == '1';
     if (ctx && ctx->stream) {
-        plan->stream = static_cast<hipStream_t>(ctx->stream);
-        plan->own_stream = false;
-    } else {
-        hip_check(hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking),
-                  "hipStreamCreate");
-        plan->own_stream = true;
+        plan->user_stream = static_cast<hipStream_t>(ctx->stream);
+        hip_check(hipEventCreateWithFlags(&plan->ev_user, hipEventDisableTiming), "hipEventCreate");
     }
 
     plan->max_work_len = plan->work_len_for(max_samples);
@@ -209,7 +214,8 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         upload(plan->d_taps_lowpass_pairs, h2p);
     }
 
-    plan->slots.resize(static_cast<size_t>(max_batch));
+    // one extra slot so that consecutive calls (and consecutive recordings of a call) overlap
+    plan->slots.resize(static_cast<size_t>(max_batch) + 1);
     const uint64_t w = plan->max_work_len;
     for (auto &sl : plan->slots) {
         sl.resampled.alloc(w + 64);
@@ -225,12 +231,17 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
             sl.words.alloc(ng + 64);
             sl.slot_nt.alloc(chunks * gpu::sync_slot_cap());
             sl.slot_cnt.alloc(chunks);
+            sl.orbit_ws.alloc(gpu::sync_orbit_ws_words(w, plan->spr));
             sl.flags.alloc(32);
             hip_check(hipMemset(sl.flags.ptr, 0, 32 * sizeof(uint32_t)), "hipMemset flags");
         }
     }
-    plan->d_results.alloc(static_cast<size_t>(max_batch));
-    hip_check(hipMemset(plan->d_results.ptr, 0, sizeof(gpu::Result) * max_batch), "hipMemset");
+    for (auto &sl : plan->slots) {
+        hip_check(hipEventCreateWithFlags(&sl.ev_front, hipEventDisableTiming), "hipEventCreate");
+        hip_check(hipEventCreateWithFlags(&sl.ev_free, hipEventDisableTiming), "hipEventCreate");
+    }
+    plan->d_results.alloc(plan->slots.size());
+    hip_check(hipMemset(plan->d_results.ptr, 0, sizeof(gpu::Result) * plan->slots.size()), "hipMemset");
     return plan.release();
 }
 
@@ -252,34 +263,70 @@ uint64_t aptgpu_plan::out_len_nosync(uint64_t work_len) const
 
 // ------------------------------------------------------------------ pipeline
 // The kernel sequence of decode() for one recording already in HBM.
-void aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows,
-                          uint64_t rows_cap_floats, bool keep_steps)
+void aptgpu_plan::begin_call(int count)
+{
+    last_slots.assign(static_cast<size_t>(count), 0);
+    if (user_stream) {
+        apt::hip_check(hipEventRecord(ev_user, user_stream), "hipEventRecord");
+        apt::hip_check(hipStreamWaitEvent(stream, ev_user, 0), "hipStreamWaitEvent");
+    }
+}
+
+void aptgpu_plan::sync_all()
+{
+    apt::hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    apt::hip_check(hipStreamSynchronize(stream2), "hipStreamSynchronize");
+}
+
+int aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows,
+                         uint64_t rows_cap_floats, bool keep_steps)
 {
     using namespace apt::gpu;
-    Slot &sl = slots[static_cast<size_t>(i)];
-    Result *res = d_results.ptr + i;
+    const int slot = static_cast<int>(seq++ % slots.size());
+    if (static_cast<size_t>(i) < last_slots.size()) last_slots[static_cast<size_t>(i)] = slot;
+    Slot &sl = slots[static_cast<size_t>(slot)];
+    Result *res = d_results.ptr + slot;
     const uint64_t w = work_len_for(n);
+    // the previous user of this slot must have finished its picker/gather
+    if (sl.used) apt::hip_check(hipStreamWaitEvent(stream, sl.ev_free, 0), "hipStreamWaitEvent");
+    sl.used = true;
+    if (hold_front && ev_nodes_armed)
+        apt::hip_check(hipStreamWaitEvent(stream, ev_nodes, 0), "hipStreamWaitEvent");
+    hipStream_t front = stream, back = stream2;
+    bool handed_over = false;
+    auto hand_over = [&] {  // front end done -> picker stream may start
+        if (handed_over) return;
+        apt::hip_check(hipEventRecord(sl.ev_front, front), "hipEventRecord");
+        apt::hip_check(hipStreamWaitEvent(back, sl.ev_front, 0), "hipStreamWaitEvent");
+        handed_over = true;
+    };
+    auto release = [&] {  // everything of this recording is enqueued: mark the slot's end
+        hand_over();
+        apt::hip_check(hipEventRecord(sl.ev_free, back), "hipEventRecord");
+    };
 
     // the first-stage kernels carry the bulk of the work: they are the "dominant" launches
     // that timing mode 1 brackets with events (mode 2 brackets every launch)
+    hipStream_t cur = front;  // stream the next launch goes to
     auto timed = [&](const char *name, auto &&launch) {
         const bool dominant = !std::strcmp(name, "fused_front_end") || !std::strcmp(name, "resample_generic");
-        timer.begin(stream, name, dominant);
+        timer.begin(cur, name, dominant);
         launch();
-        timer.end(stream);
+        timer.end(cur);
     };
 
     // decode.rs:79-83 — fewer than 10 rows of samples
     if (w < 10ull * spr) {
-        set_result(stream, res, Result{APTGPU_ERR_INTERNAL, 1, 0, 0, w, 0});
-        return;
+        set_result(front, res, Result{APTGPU_ERR_INTERNAL, 1, 0, 0, w, 0});
+        release();
+        return slot;
     }
 
     const bool use_fused = fused && !keep_steps;
     if (use_fused) {
         // 1-3 fused: resample -> envelope -> low-pass in one launch (apt_kernels_fused.hip)
         timed("fused_front_end", [&] {
-            fused_front_end(stream, l, m, static_cast<uint32_t>(taps_resample.size()),
+            fused_front_end(cur, l, m, static_cast<uint32_t>(taps_resample.size()),
                             static_cast<uint32_t>(taps_lowpass.size()), pw, d_signal, n,
                             d_taps_branch.ptr, d_taps_lowpass.ptr, d_taps_lowpass_pairs.ptr, cosphi2, sinphi,
                             sl.filtered.ptr,
@@ -290,58 +337,64 @@ void aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_row
     // 1. resample to work_rate (dsp.rs:62-126)
     if (l > 1) {
         timed("resample_generic", [&] {
-            resample_generic(stream, d_signal, n, d_taps_resample.ptr,
+            resample_generic(cur, d_signal, n, d_taps_resample.ptr,
                              static_cast<uint32_t>(taps_resample.size()), l, m, sl.resampled.ptr, w);
         });
     } else {
         timed("fir_decimate", [&] {
-            fir_decimate(stream, d_signal, n, d_taps_resample.ptr,
+            fir_decimate(cur, d_signal, n, d_taps_resample.ptr,
                          static_cast<uint32_t>(taps_resample.size()), m, sl.resampled.ptr, w);
         });
     }
     // 2. AM envelope (dsp.rs:350-383)
     timed("demodulate",
-          [&] { demodulate(stream, sl.resampled.ptr, w, cosphi2, sinphi, sl.demodulated.ptr); });
+          [&] { demodulate(cur, sl.resampled.ptr, w, cosphi2, sinphi, sl.demodulated.ptr); });
     // 3. low-pass (dsp.rs:386-410)
     timed("lowpass", [&] {
-        fir_decimate(stream, sl.demodulated.ptr, w, d_taps_lowpass.ptr,
+        fir_decimate(cur, sl.demodulated.ptr, w, d_taps_lowpass.ptr,
                      static_cast<uint32_t>(taps_lowpass.size()), 1, sl.filtered.ptr, w);
     });
     }
 
     if (sync && !work_is_multiple) {
         // generate_sync_frame, decode.rs:172-176
-        set_result(stream, res, Result{APTGPU_ERR_INTERNAL, 3, 0, 0, w, 0});
+        set_result(cur, res, Result{APTGPU_ERR_INTERNAL, 3, 0, 0, w, 0});
     } else if (sync) {
         // 4. find_sync (decode.rs:204-263): correlation, terminal flags, orbit
         const uint64_t n_corr = w - n_sync_taps;  // w >= 10*spr > 38*pw
         if (!use_fused)
-            timed("correlate", [&] { correlate(stream, sl.filtered.ptr, n_corr, pw, sl.correlation.ptr); });
+            timed("correlate", [&] { correlate(cur, sl.filtered.ptr, n_corr, pw, sl.correlation.ptr); });
+        hand_over();
+        cur = back;
         if (mode == APTGPU_MODE_GENERIC) {
             // reference-shaped picker: full sliding-window terminals + sequential orbit
-            timed("terminals", [&] { terminals(stream, sl.correlation.ptr, n_corr, md, sl.bits.ptr); });
+            timed("terminals", [&] { terminals(cur, sl.correlation.ptr, n_corr, md, sl.bits.ptr); });
             timed("orbit_walk", [&] {
-                orbit_walk(stream, sl.bits.ptr, n_corr, w, spr, md, sl.peaks.ptr,
+                orbit_walk(cur, sl.bits.ptr, n_corr, w, spr, md, sl.peaks.ptr,
                            static_cast<uint32_t>(sl.peaks.count), res);
             });
         } else {
             if (!use_fused)
-                timed("group_max", [&] { group_max(stream, sl.correlation.ptr, n_corr, sl.gm.ptr); });
+                timed("group_max", [&] { group_max(cur, sl.correlation.ptr, n_corr, sl.gm.ptr); });
             timed("sync_nodes", [&] {
-                sync_nodes(stream, sl.gm.ptr, sl.correlation.ptr, n_corr, spr, md, sl.words.ptr,
+                sync_nodes(cur, sl.gm.ptr, sl.correlation.ptr, n_corr, spr, md, sl.words.ptr,
                            sl.slot_nt.ptr, sl.slot_cnt.ptr, sl.flags.ptr);
             });
+            if (hold_front) {
+                apt::hip_check(hipEventRecord(ev_nodes, back), "hipEventRecord");
+                ev_nodes_armed = true;
+            }
             timed("sync_orbit", [&] {
-                sync_orbit(stream, sl.words.ptr, sl.slot_nt.ptr, sl.slot_cnt.ptr, sl.flags.ptr, n_corr,
-                           w, spr, md, sl.peaks.ptr, static_cast<uint32_t>(sl.peaks.count), res,
-                           force_walk);
+                sync_orbit(cur, sl.words.ptr, sl.slot_nt.ptr, sl.slot_cnt.ptr, sl.flags.ptr, n_corr,
+                           w, spr, md, sl.orbit_ws.ptr, sl.peaks.ptr,
+                           static_cast<uint32_t>(sl.peaks.count), res, picker_force);
             });
         }
         // 5. aligned rows + final /pw (decode.rs:120-134,158-159)
         uint64_t rows_cap = rows_cap_floats / 2080u;
         if (rows_cap > max_rows) rows_cap = max_rows;
         timed("gather_rows", [&] {
-            gather_rows(stream, sl.filtered.ptr, sl.peaks.ptr, res, spr, pw, false, d_rows,
+            gather_rows(cur, sl.filtered.ptr, sl.peaks.ptr, res, spr, pw, false, d_rows,
                         static_cast<uint32_t>(rows_cap));
         });
     } else {
@@ -351,14 +404,16 @@ void aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_row
         if (n_out > rows_cap_floats) n_out = rows_cap_floats;
         if (l2 > 1) {
             timed("final_resample", [&] {
-                resample_generic(stream, sl.filtered.ptr, aligned, d_one.ptr, 1, l2, m2, d_rows, n_out);
+                resample_generic(cur, sl.filtered.ptr, aligned, d_one.ptr, 1, l2, m2, d_rows, n_out);
             });
         } else {
             timed("final_decimate", [&] {
-                fir_decimate(stream, sl.filtered.ptr, aligned, d_one.ptr, 1, m2, d_rows, n_out);
+                fir_decimate(cur, sl.filtered.ptr, aligned, d_one.ptr, 1, m2, d_rows, n_out);
             });
         }
-        set_result(stream, res,
+        set_result(cur, res,
                    Result{APTGPU_OK, 0, static_cast<uint32_t>(n_out / 2080u), 0, w, n_out});
     }
+    release();
+    return slot;
 }

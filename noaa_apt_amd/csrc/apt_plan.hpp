@@ -81,8 +81,15 @@ private:
 struct aptgpu_plan {
     int device = 0;
     int mode = APTGPU_MODE_STRICT;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
+    // Two internal streams form a software pipeline over consecutive recordings: the front
+    // end (resample .. correlation) of recording i+1 runs on `stream` while the peak picker
+    // and row gather of recording i run on `stream2`; events hand the workspace slots over.
+    hipStream_t stream = nullptr;   // front end
+    hipStream_t stream2 = nullptr;  // picker + gather
+    hipStream_t user_stream = nullptr;  // ctx.stream: inputs are ordered after it (may be null)
+    hipEvent_t ev_user = nullptr;
+    uint64_t seq = 0;               // recordings enqueued so far (slot = seq % slots.size())
+    std::vector<int> last_slots;    // slot of recording i of the most recent decode_device call
 
     aptgpu_settings settings{};
     uint32_t input_rate = 0;
@@ -106,7 +113,16 @@ struct aptgpu_plan {
     uint32_t max_rows = 0;
     int max_batch = 1;
     bool fused = false;
-    bool force_walk = false;  // APTGPU_FORCE_WALK=1: exercise the picker's fallback path
+    // the front end is launched as this many consecutive tile ranges: each kernel boundary lets
+    // the previous recording's single-workgroup orbit kernel (147 KB of LDS) grab a CU
+    // event recorded on stream2 after the most recent recording's sync_nodes: the next front
+    // end waits for it, so the single-workgroup orbit kernel (147 KB LDS) is already queued on
+    // the high-priority stream when the front end's workgroups start to fill the CUs
+    hipEvent_t ev_nodes = nullptr;
+    bool ev_nodes_armed = false;
+    bool hold_front = false;  // APTGPU_HOLD_FRONT=1 enables (experiment; off: event waits cost more)
+    int picker_force = 0;  // 0 global-memory picker; APTGPU_FORCE_WALK=1 -> 1; APTGPU_PICKER_LDS=1 -> 4
+  // APTGPU_FORCE_WALK=1: exercise the picker's fallback path
 
     apt::DeviceBuffer<float> d_taps_resample, d_taps_lowpass, d_one, d_taps_branch, d_taps_lowpass_pairs;
     struct Slot {
@@ -115,7 +131,10 @@ struct aptgpu_plan {
         apt::DeviceBuffer<uint32_t> peaks;
         apt::DeviceBuffer<float> gm;          // per-group maxima of the correlation
         apt::DeviceBuffer<uint64_t> words;    // 52-bit terminal words
-        apt::DeviceBuffer<uint32_t> slot_nt, slot_cnt, flags;
+        apt::DeviceBuffer<uint32_t> slot_nt, slot_cnt, flags, orbit_ws;
+        hipEvent_t ev_front = nullptr;  // front end of this slot finished (stream -> stream2)
+        hipEvent_t ev_free = nullptr;   // picker/gather finished with this slot (stream2 -> stream)
+        bool used = false;
     };
     std::vector<Slot> slots;
     apt::DeviceBuffer<apt::gpu::Result> d_results;
@@ -126,9 +145,14 @@ struct aptgpu_plan {
     uint64_t work_len_for(uint64_t n) const;
     uint64_t out_len_nosync(uint64_t work_len) const;
 
-    // enqueue the whole decode() of one device-resident recording into slot `i`
-    void enqueue(int i, const float *d_signal, uint64_t n, float *d_rows, uint64_t rows_cap_floats,
-                 bool keep_steps);
+    // enqueue the whole decode() of one device-resident recording (recording `i` of the
+    // current call) into the next pipeline slot; returns the slot used
+    int enqueue(int i, const float *d_signal, uint64_t n, float *d_rows, uint64_t rows_cap_floats,
+                bool keep_steps);
+    void begin_call(int count);     // orders the front-end stream after ctx.stream
+    void sync_all();                // waits for both internal streams
+    Slot &slot_of(int i) { return slots[static_cast<size_t>(last_slots[static_cast<size_t>(i)])]; }
+    apt::gpu::Result *result_of(int i) { return d_results.ptr + last_slots[static_cast<size_t>(i)]; }
 };
 
 namespace apt {

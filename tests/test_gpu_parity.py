@@ -148,6 +148,9 @@ def test_find_sync_alternate_pickers(oracle, name, monkeypatch):
     assert apt.find_sync(gen, f, apt.Rate.hz(4160)).tolist() == want
     monkeypatch.setenv("APTGPU_FORCE_WALK", "1")
     assert apt.find_sync(apt.Context(device=0), f, apt.Rate.hz(4160)).tolist() == want
+    monkeypatch.delenv("APTGPU_FORCE_WALK")
+    monkeypatch.setenv("APTGPU_PICKER_LDS", "1")  # the LDS-resident picker (with the global kernel as overflow)
+    assert apt.find_sync(apt.Context(device=0), f, apt.Rate.hz(4160)).tolist() == want
 
 
 def test_find_sync_short_and_edges(ctx, oracle):
@@ -194,7 +197,7 @@ def test_decode_bitexact(ctx, oracle, rate, seconds, seed, profile, kw, sync):
     assert got.size % 2080 == 0
 
 
-@pytest.mark.parametrize("mode", ["generic", "walk"])
+@pytest.mark.parametrize("mode", ["generic", "walk", "lds"])
 def test_decode_alternate_paths(oracle, mode, monkeypatch):
     """decode() through the unfused generic kernels, and with the picker's fallback walk."""
     x = synth_apt(48000, 14, 2)
@@ -202,11 +205,14 @@ def test_decode_alternate_paths(oracle, mode, monkeypatch):
     if mode == "walk":
         monkeypatch.setenv("APTGPU_FORCE_WALK", "1")
         c = apt.Context(device=0)
+    elif mode == "lds":
+        monkeypatch.setenv("APTGPU_PICKER_LDS", "1")
+        c = apt.Context(device=0)
     else:
         c = apt.Context(device=0, mode=apt.MODE_GENERIC)
     got, st = apt.decode(c, apt.Settings(), x, apt.Rate.hz(48000), True, return_stats=True)
     assert_bitexact(got, want, f"decode via {mode}")
-    assert st.fused == (1 if mode == "walk" else 0)
+    assert st.fused == (0 if mode == "generic" else 1)
 
 
 def test_decode_noise_fixture_like(ctx, oracle):
