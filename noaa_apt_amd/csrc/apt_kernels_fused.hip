@@ -35,9 +35,8 @@ namespace {
 #ifndef APT_FUSED_MIN_WAVES
 #define APT_FUSED_MIN_WAVES 3
 #endif
-constexpr int kFusedThreads = 256;
-constexpr int kPreThreads = 4;
-constexpr int kOwnThreads = 240;
+constexpr int kPreThreads = 4;    // pre-halo threads (low-pass + envelope history)
+constexpr int kPostThreads = 12;  // post-halo threads (correlation look-ahead)
 constexpr float kNegInfF = -__builtin_huge_valf();
 
 template <int I, int N, typename F>
@@ -60,8 +59,10 @@ __host__ __device__ constexpr int branch_phase(int b)  // p_b = c_b*L - b*M
     return branch_first<L, M>(b) * L - b * M;
 }
 
-template <int L, int M, int T1, int T2, int PW>
+template <int L, int M, int T1, int T2, int PW, int NTHR>
 struct FusedGeom {
+    static constexpr int kFusedThreads = NTHR;
+    static constexpr int kOwnThreads = NTHR - kPreThreads - kPostThreads;
     static constexpr int TP = (T1 + L - 1) / L;                       // taps per branch (max)
     static constexpr int CLAST = branch_first<L, M>(L - 1);           // last branch's first sample
     static constexpr int WIN = CLAST + TP;                            // input window per thread
@@ -105,15 +106,17 @@ __host__ __device__ constexpr bool sync_plus(int j)
     return (((j - pulse) / pulse) & 1) == 1;
 }
 
-template <int L, int M, int T1, int T2, int PW>
-__global__ void __launch_bounds__(kFusedThreads, APT_FUSED_MIN_WAVES)
+template <int L, int M, int T1, int T2, int PW, int NTHR>
+__global__ void __launch_bounds__(NTHR, (APT_FUSED_MIN_WAVES * NTHR + 255) / 256)
 k_fused(const float *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][PS] tap pairs*/,
         const float *__restrict__ h2 /*[T2]*/, const f2 *__restrict__ h2p /*[T2+1] (h2[m-1], h2[m])*/,
         float cosphi2, float sinphi,
         float *__restrict__ f_out, float *__restrict__ c_out, float *__restrict__ gm_out,
         uint64_t w, uint64_t n_corr)
 {
-    using Gm = FusedGeom<L, M, T1, T2, PW>;
+    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR>;
+    constexpr int kFusedThreads = NTHR;
+    constexpr int kOwnThreads = Gm::kOwnThreads;
     extern __shared__ float lds[];
     float *P = lds;                  // x tile -> R -> F
     float *Q = lds + Gm::D_OFF;      // D (inside the dead part of the x tile)
@@ -412,14 +415,15 @@ k_fused(const float *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WI
     }
 }
 
-template <int L, int M, int T1, int T2, int PW>
+template <int L, int M, int T1, int T2, int PW, int NTHR>
 void launch_fused(hipStream_t s, const float *x, uint64_t n, const float *hb, const float *h2,
                   const float *h2p, float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w,
                   uint64_t n_corr)
 {
-    using Gm = FusedGeom<L, M, T1, T2, PW>;
+    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR>;
+    constexpr int kFusedThreads = NTHR;
     const size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
-    auto kern = k_fused<L, M, T1, T2, PW>;
+    auto kern = k_fused<L, M, T1, T2, PW, NTHR>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -436,7 +440,9 @@ void launch_fused(hipStream_t s, const float *x, uint64_t n, const float *hb, co
 
 bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
 {
-    return l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3;
+    if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) return true;    // 48 kHz, standard
+    if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3) return true;  // 96 kHz, standard
+    return false;
 }
 
 uint32_t fused_group_size(uint32_t l) { return 4 * l; }
@@ -490,8 +496,14 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
                      uint64_t w, uint64_t n_corr)
 {
     if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
-        launch_fused<13, 50, 959, 37, 3>(s, x, n, hb, h2, h2p, cosphi2, sinphi, f_out, c_out, gm_out,
-                                         w, n_corr);
+        launch_fused<13, 50, 959, 37, 3, 256>(s, x, n, hb, h2, h2p, cosphi2, sinphi, f_out, c_out,
+                                              gm_out, w, n_corr);
+        return true;
+    }
+    if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3) {
+        // twice the input per work sample: 128-thread workgroups keep the x tile at 51.8 KB
+        launch_fused<13, 100, 1915, 37, 3, 128>(s, x, n, hb, h2, h2p, cosphi2, sinphi, f_out, c_out,
+                                                gm_out, w, n_corr);
         return true;
     }
     return false;

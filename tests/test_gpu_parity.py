@@ -215,6 +215,25 @@ def test_decode_alternate_paths(oracle, mode, monkeypatch):
     assert st.fused == (0 if mode == "generic" else 1)
 
 
+def test_fused_specialisations_are_used(ctx):
+    """48 kHz and 96 kHz (standard profile) run the fused front end; other rates the generic one."""
+    for rate, want in ((48000, 1), (96000, 1), (44100, 0), (11025, 0)):
+        _, st = apt.decode(ctx, apt.Settings(), synth_apt(rate, 11, 3), apt.Rate.hz(rate), True,
+                           return_stats=True)
+        assert st.fused == want, rate
+
+
+def test_decode_long_recordings(ctx, oracle):
+    """Sizes past the LDS picker's capacity (15 min @ 48 kHz, 5 min @ 96 kHz): the
+    global-memory picker has no size limit and stays bit-exact."""
+    for rate, seconds, seed in ((48000, 900, 41), (96000, 300, 42)):
+        x = synth_apt(rate, seconds, seed)
+        want = oracle.decode(x, rate, True)
+        got, st = apt.decode(ctx, apt.Settings(), x, apt.Rate.hz(rate), True, return_stats=True)
+        assert st.fused == 1
+        assert_bitexact(got, want, f"long {rate} Hz {seconds} s")
+
+
 def test_decode_noise_fixture_like(ctx, oracle):
     """Stand-in for test/noise_48000hz.wav (really 11025 Hz, 30 s of noise)."""
     x = synth_noise(11025, 30.0, 77)
