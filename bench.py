@@ -126,6 +126,17 @@ def main():
         achieved = b_alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         kernel_sum_ms = sum(v[0] for v in ktimes.values())
         pipe_achieved = b_alg / (ms_per_step * 1e-3) / 1e9
+        # HBM bytes per launch of the dominant kernel as measured with rocprofv3 PMC counters
+        # (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 2x read correction applied by
+        # tools/summarize_pmc.py) for THIS workload; null when no matching profile is committed
+        traffic = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            if (args.rate, args.seconds, args.profile, args.mode) == (48000, 600.0, "standard", "strict") \
+                    and dom[0] == "fused_front_end":
+                traffic = prof["per_launch"]["k_fused"]["hbm_total_MB"] * 1e6
+        except Exception:
+            traffic = None
         line = {
             "metric": "Msamples/sec WAV->APT-line decode",
             "value": round(value, 3),
@@ -162,7 +173,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                                  if traffic else None,
                 "algorithmic_bytes_per_launch": b_alg,
             },
             "pipeline": {
