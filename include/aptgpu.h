@@ -86,6 +86,10 @@ typedef struct aptgpu_context {
 #define APTGPU_MODE_STRICT 0 /* bit-exact with the reference's f32 loops; fused kernels when
                                 the (L, M, taps) combination has a specialisation          */
 #define APTGPU_MODE_GENERIC 1 /* force the unfused generic kernels (any rate combination)   */
+#define APTGPU_MODE_FP16_TAPS 2 /* first resample with fp16 taps + fp16 samples through
+                                   v_dot2_f32_f16, f32 accumulate (BASELINE.json config 5).  NOT
+                                   bit-exact: pixels within ~2e-3 of the row peak, sync positions
+                                   unchanged on APT data; every other stage as in STRICT        */
 
 /* What find_sync()/decode() learned; the reference only logs it
  * (`info!("Found {} sync frames")` src/decode.rs:260). */

@@ -24,5 +24,5 @@ from .api import (  # noqa: F401
     decode, resample_with_filter, resample, demodulate, filter, find_sync, generate_sync_frame,
     Plan, PlanInfo, Result, KernelTime,
     lib, lib_path, build, device_count, version,
-    MODE_STRICT, MODE_GENERIC,
+    MODE_STRICT, MODE_GENERIC, MODE_FP16_TAPS,
 )

@@ -13,6 +13,7 @@ CARRIER_FREQ = 2400  # decode.rs:38
 
 MODE_STRICT = 0
 MODE_GENERIC = 1
+MODE_FP16_TAPS = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libaptgpu.so")

@@ -129,7 +129,6 @@ void aptgpu_plan_destroy(aptgpu_plan *plan)
         if (sl.ev_free) (void)hipEventDestroy(sl.ev_free);
     }
     if (plan->ev_user) (void)hipEventDestroy(plan->ev_user);
-    if (plan->ev_nodes) (void)hipEventDestroy(plan->ev_nodes);
     if (plan->stream) (void)hipStreamDestroy(plan->stream);
     if (plan->stream2) (void)hipStreamDestroy(plan->stream2);
     delete plan;

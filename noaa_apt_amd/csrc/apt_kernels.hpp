@@ -23,6 +23,11 @@ struct Result {
 // fast_resampling, dsp.rs:186-289: out[k], k < w
 void resample_generic(hipStream_t s, const float *x, uint64_t n, const float *coeff,
                       uint32_t ntaps, uint32_t l, uint32_t m, float *out, uint64_t w);
+// fp16-tap variant (APTGPU_MODE_FP16_TAPS, BASELINE config 5): tolerance-based, not bit-exact
+uint32_t f16taps_pairs_per_phase(uint32_t l, uint32_t ntaps);
+float f16taps_pack(uint32_t l, const float *coeff, uint32_t ntaps, uint16_t *table);  // returns 2^-s
+void resample_f16taps(hipStream_t s, const float *x, uint64_t n, const uint16_t *table, uint32_t ntaps,
+                      uint32_t l, uint32_t m, float unscale, float *out, uint64_t w);
 // filter() followed by decimate(m), dsp.rs:386-410 + 294-307: out[k] = filter(x)[k*m]
 void fir_decimate(hipStream_t s, const float *x, uint64_t n, const float *coeff, uint32_t ntaps,
                   uint32_t m, float *out, uint64_t n_out);

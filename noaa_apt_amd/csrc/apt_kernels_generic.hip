@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 // never fuse a*b+c: the reference rounds the product and the sum separately
 #pragma clang fp contract(off)
 
@@ -47,6 +49,39 @@ k_resample_generic(const float *__restrict__ x, uint64_t n, const float *__restr
             if (xi < n) sum = __fadd_rn(sum, __fmul_rn(coeff[j], x[xi]));
         }
         out[k] = sum;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// fp16-tap variant of the polyphase resampler (BASELINE config 5; NOT bit-exact).
+// Taps are stored phase-major as fp16 pre-scaled by 2^s (so the 1/L-sized taps use the
+// fp16 normal range), samples are rounded to fp16 on the fly, and two taps at a time go
+// through v_dot2_f32_f16 with f32 accumulation; the sum is scaled back by 2^-s (exact).
+// Error sources: 11-bit taps and 11-bit samples -> about 1e-3 of the signal's peak.
+// ---------------------------------------------------------------------------------
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+__global__ void __launch_bounds__(kBlock)
+k_resample_f16taps(const float *__restrict__ x, uint64_t n, const h2 *__restrict__ hp /*[l][tp2]*/,
+                   uint32_t tp2 /* tap pairs per phase */, uint32_t l, uint32_t m, float unscale,
+                   float *__restrict__ out, uint64_t w)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t k = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < w;
+         k += stride) {
+        const uint64_t km = k * m;
+        const uint64_t x0 = (km + l - 1) / l;
+        const uint32_t p = static_cast<uint32_t>(x0 * l - km);
+        const h2 *row = hp + static_cast<uint64_t>(p) * tp2;
+        float acc = 0.f;
+        for (uint32_t i = 0; i < tp2; ++i) {
+            const uint64_t xi = x0 + 2ull * i;
+            const float a = xi < n ? x[xi] : 0.f;
+            const float b = xi + 1 < n ? x[xi + 1] : 0.f;
+            const h2 xv = {static_cast<_Float16>(a), static_cast<_Float16>(b)};
+            acc = __builtin_amdgcn_fdot2(xv, row[i], acc, false);
+        }
+        out[k] = acc * unscale;
     }
 }
 
@@ -337,6 +372,39 @@ void resample_generic(hipStream_t s, const float *x, uint64_t n, const float *co
     const uint32_t jlim = 2 * ((ntaps - 1) / 2) + 1;  // n <= t + offset  <=>  j <= 2*offset
     hipLaunchKernelGGL(k_resample_generic, dim3(grid_for(w, kBlock)), dim3(kBlock), 0, s, x, n,
                        coeff, jlim, l, m, out, w);
+}
+
+uint32_t f16taps_pairs_per_phase(uint32_t l, uint32_t ntaps) { return ((ntaps + l - 1) / l + 1) / 2; }
+
+// host: phase-major fp16 table [l][tp2][2] (as raw uint16 pairs) and the power-of-two scale
+float f16taps_pack(uint32_t l, const float *coeff, uint32_t ntaps, uint16_t *table)
+{
+    const uint32_t jlim = 2 * ((ntaps - 1) / 2) + 1;  // taps the reference actually uses
+    const uint32_t tp2 = f16taps_pairs_per_phase(l, ntaps);
+    float mx = 0.f;
+    for (uint32_t j = 0; j < jlim; ++j) mx = fmaxf(mx, fabsf(coeff[j]));
+    int e = 0;
+    if (mx > 0.f) (void)frexpf(mx, &e);       // mx = f * 2^e, f in [0.5, 1)
+    const int sh = -e + 1;                     // scaled max in [1, 2): well inside fp16 range
+    const float scale = ldexpf(1.f, sh);
+    for (uint32_t p = 0; p < l; ++p)
+        for (uint32_t i = 0; i < 2 * tp2; ++i) {
+            const uint64_t j = p + static_cast<uint64_t>(i) * l;
+            const _Float16 h = static_cast<_Float16>(j < jlim ? coeff[j] * scale : 0.f);
+            uint16_t bits;
+            __builtin_memcpy(&bits, &h, 2);
+            table[(static_cast<size_t>(p) * tp2 * 2) + i] = bits;
+        }
+    return ldexpf(1.f, -sh);
+}
+
+void resample_f16taps(hipStream_t s, const float *x, uint64_t n, const uint16_t *table, uint32_t ntaps,
+                      uint32_t l, uint32_t m, float unscale, float *out, uint64_t w)
+{
+    if (w == 0) return;
+    hipLaunchKernelGGL(k_resample_f16taps, dim3(grid_for(w, kBlock)), dim3(kBlock), 0, s, x, n,
+                       reinterpret_cast<const h2 *>(table), f16taps_pairs_per_phase(l, ntaps), l, m, unscale,
+                       out, w);
 }
 
 void fir_decimate(hipStream_t s, const float *x, uint64_t /*n*/, const float *coeff,

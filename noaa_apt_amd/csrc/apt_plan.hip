@@ -179,8 +179,6 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
         hip_check(hipStreamCreateWithPriority(&plan->stream2, hipStreamNonBlocking, hi), "hipStreamCreate");
     }
-    hip_check(hipEventCreateWithFlags(&plan->ev_nodes, hipEventDisableTiming), "hipEventCreate");
-    if (const char *e = std::getenv("APTGPU_HOLD_FRONT")) plan->hold_front = e[0] == '1';
     if (ctx && ctx->stream) {
         plan->user_stream = static_cast<hipStream_t>(ctx->stream);
         hip_check(hipEventCreateWithFlags(&plan->ev_user, hipEventDisableTiming), "hipEventCreate");
@@ -203,6 +201,13 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
                   gpu::fused_supported(plan->l, plan->m, static_cast<uint32_t>(plan->taps_resample.size()),
                                        static_cast<uint32_t>(plan->taps_lowpass.size()), plan->pw) &&
                   plan->work_is_multiple;
+    if (plan->mode == APTGPU_MODE_FP16_TAPS && plan->l > 1) {
+        const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
+        std::vector<uint16_t> tab(static_cast<size_t>(plan->l) * gpu::f16taps_pairs_per_phase(plan->l, t1) * 2 + 8, 0);
+        plan->f16_unscale = gpu::f16taps_pack(plan->l, plan->taps_resample.data(), t1, tab.data());
+        plan->d_taps_f16.alloc(tab.size());
+        hip_check(hipMemcpy(plan->d_taps_f16.ptr, tab.data(), tab.size() * 2, hipMemcpyHostToDevice), "hipMemcpy f16 taps");
+    }
     if (plan->fused) {
         const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
         Signal hs(static_cast<size_t>(gpu::fused_tap_table_floats(plan->l, plan->m, t1)) + 16, 0.f);
@@ -290,8 +295,6 @@ int aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows
     // the previous user of this slot must have finished its picker/gather
     if (sl.used) apt::hip_check(hipStreamWaitEvent(stream, sl.ev_free, 0), "hipStreamWaitEvent");
     sl.used = true;
-    if (hold_front && ev_nodes_armed)
-        apt::hip_check(hipStreamWaitEvent(stream, ev_nodes, 0), "hipStreamWaitEvent");
     hipStream_t front = stream, back = stream2;
     bool handed_over = false;
     auto hand_over = [&] {  // front end done -> picker stream may start
@@ -309,7 +312,8 @@ int aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows
     // that timing mode 1 brackets with events (mode 2 brackets every launch)
     hipStream_t cur = front;  // stream the next launch goes to
     auto timed = [&](const char *name, auto &&launch) {
-        const bool dominant = !std::strcmp(name, "fused_front_end") || !std::strcmp(name, "resample_generic");
+        const bool dominant = !std::strcmp(name, "fused_front_end") || !std::strcmp(name, "resample_generic") ||
+                              !std::strcmp(name, "resample_f16taps");
         timer.begin(cur, name, dominant);
         launch();
         timer.end(cur);
@@ -335,7 +339,12 @@ int aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows
         });
     } else {
     // 1. resample to work_rate (dsp.rs:62-126)
-    if (l > 1) {
+    if (l > 1 && mode == APTGPU_MODE_FP16_TAPS) {
+        timed("resample_f16taps", [&] {
+            resample_f16taps(cur, d_signal, n, d_taps_f16.ptr, static_cast<uint32_t>(taps_resample.size()),
+                             l, m, f16_unscale, sl.resampled.ptr, w);
+        });
+    } else if (l > 1) {
         timed("resample_generic", [&] {
             resample_generic(cur, d_signal, n, d_taps_resample.ptr,
                              static_cast<uint32_t>(taps_resample.size()), l, m, sl.resampled.ptr, w);
@@ -380,10 +389,6 @@ int aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows
                 sync_nodes(cur, sl.gm.ptr, sl.correlation.ptr, n_corr, spr, md, sl.words.ptr,
                            sl.slot_nt.ptr, sl.slot_cnt.ptr, sl.flags.ptr);
             });
-            if (hold_front) {
-                apt::hip_check(hipEventRecord(ev_nodes, back), "hipEventRecord");
-                ev_nodes_armed = true;
-            }
             timed("sync_orbit", [&] {
                 sync_orbit(cur, sl.words.ptr, sl.slot_nt.ptr, sl.slot_cnt.ptr, sl.flags.ptr, n_corr,
                            w, spr, md, sl.orbit_ws.ptr, sl.peaks.ptr,

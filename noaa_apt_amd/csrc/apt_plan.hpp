@@ -115,16 +115,12 @@ struct aptgpu_plan {
     bool fused = false;
     // the front end is launched as this many consecutive tile ranges: each kernel boundary lets
     // the previous recording's single-workgroup orbit kernel (147 KB of LDS) grab a CU
-    // event recorded on stream2 after the most recent recording's sync_nodes: the next front
-    // end waits for it, so the single-workgroup orbit kernel (147 KB LDS) is already queued on
-    // the high-priority stream when the front end's workgroups start to fill the CUs
-    hipEvent_t ev_nodes = nullptr;
-    bool ev_nodes_armed = false;
-    bool hold_front = false;  // APTGPU_HOLD_FRONT=1 enables (experiment; off: event waits cost more)
     int picker_force = 0;  // 0 global-memory picker; APTGPU_FORCE_WALK=1 -> 1; APTGPU_PICKER_LDS=1 -> 4
   // APTGPU_FORCE_WALK=1: exercise the picker's fallback path
 
     apt::DeviceBuffer<float> d_taps_resample, d_taps_lowpass, d_one, d_taps_branch, d_taps_lowpass_pairs;
+    apt::DeviceBuffer<uint16_t> d_taps_f16;  // APTGPU_MODE_FP16_TAPS
+    float f16_unscale = 1.f;
     struct Slot {
         apt::DeviceBuffer<float> resampled, demodulated, filtered, correlation;
         apt::DeviceBuffer<uint64_t> bits;     // 64-bit terminal words (generic-mode picker)

@@ -234,6 +234,21 @@ def test_decode_long_recordings(ctx, oracle):
         assert_bitexact(got, want, f"long {rate} Hz {seconds} s")
 
 
+@pytest.mark.parametrize("rate,seed", [(48000, 2), (96000, 3), (11025, 1)])
+def test_decode_fp16_taps_mode(oracle, rate, seed):
+    """BASELINE config 5: fp16 taps + fp16 samples, f32 accumulate.  Tolerance (stated):
+    identical sync positions and row count, |px - ref| <= 2e-3 * max|ref| (measured ~5e-4)."""
+    x = synth_apt(rate, 14, seed)
+    want, st = oracle.decode(x, rate, True, want_steps=True)
+    c = apt.Context(device=0, mode=apt.MODE_FP16_TAPS)
+    got, stats = apt.decode(c, apt.Settings(), x, apt.Rate.hz(rate), True, return_stats=True)
+    assert stats.fused == 0 and stats.n_sync == st["sync_pos"].size
+    assert got.shape == want.shape
+    err = np.max(np.abs(got - want)) / np.max(np.abs(want))
+    assert err <= 2e-3, err
+    assert err > 0  # it really is the reduced-precision path
+
+
 def test_decode_noise_fixture_like(ctx, oracle):
     """Stand-in for test/noise_48000hz.wav (really 11025 Hz, 30 s of noise)."""
     x = synth_noise(11025, 30.0, 77)
