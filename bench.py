@@ -35,8 +35,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rate", type=int, default=48000)
     ap.add_argument("--seconds", type=float, default=600.0)
     ap.add_argument("--profile", default="standard")
@@ -58,9 +58,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with 1 rank)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     settings = apt.Settings.profile(args.profile)
@@ -163,7 +164,7 @@ def main():
                 "n_sync": int(res.n_sync),
                 "input_resident_in_hbm": True,
                 "picker": {"path": {0: "lds", 1: "sequential-walk", 2: "global"}.get(int(pflags[1]), "?"),
-                           "node_capacity": int(pflags[3]), "visited_nodes": int(pflags[4]),
+                           "node_capacity": int(pflags[3]), "visited_nodes": int(pflags[4]), "orbit": "direct" if int(pflags[6]) else "doubling",
                            "cycle_stamps": [int(v) for v in pflags[8:11]]},
             },
             "roofline": {
@@ -220,6 +221,7 @@ def main():
         print(json.dumps(line), flush=True)
     plan.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

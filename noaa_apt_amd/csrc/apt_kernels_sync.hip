@@ -567,15 +567,6 @@ __device__ __forceinline__ void gst(uint32_t *p, uint32_t v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ uint32_t lower_bound_g(const uint32_t *a, uint32_t lo, uint32_t hi, uint32_t key)
-{
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (gld(a + mid) < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
 // One workgroup; every table in the global scratch `ws` (sized by sync_orbit_ws_words()), so
 // the kernel needs almost no LDS and can run beside the next recording's front end.  Node
 // terminals are looked up straight in the per-chunk slots k_sync_nodes wrote (no gather pass):
@@ -593,7 +584,7 @@ k_sync_orbit_global(const uint64_t *__restrict__ words, const uint32_t *__restri
         if (flags[5] == 0) return;
         force_walk = 0;
     }
-    __shared__ uint32_t s_count, s_plen;
+    __shared__ uint32_t s_count, s_plen, s_conflict, s_endcell;
     __shared__ unsigned long long s_fit;
     // this latency-bound workgroup shares its CU with VALU-saturated front-end waves of the next
     // recording: let its few instructions issue first
@@ -631,6 +622,7 @@ k_sync_orbit_global(const uint64_t *__restrict__ words, const uint32_t *__restri
     uint32_t *w_list = w_u + n_nodes;         // [n_nodes] visited nodes
     uint32_t *w_mark = w_list + n_nodes;      // [n_nodes/32 + 1]
     uint32_t *w_path = w_mark + (n_nodes / 32 + 1);  // [kc + 2]
+    uint32_t *w_succ = w_path + (kc + 2);            // [kc + 3] common successor per cell
     const uint32_t nc32 = static_cast<uint32_t>(n_corr);
     const uint32_t wl32 = static_cast<uint32_t>(gq.work_len);
     constexpr uint32_t kChunkSpan = kChunkGroups * GS;  // positions per chunk
@@ -673,7 +665,8 @@ k_sync_orbit_global(const uint64_t *__restrict__ words, const uint32_t *__restri
     uint32_t count = 0;
     if (!walk) {
         for (uint32_t wq = tid; wq < n_nodes / 32 + 1; wq += kOrbitThreads) gst(w_mark + wq, 0u);
-        if (tid == 0) s_count = base_d;
+        for (uint32_t c = tid; c < kc + 3; c += kOrbitThreads) gst(w_succ + c, 0xFFFFFFFFu);
+        if (tid == 0) { s_count = base_d; s_conflict = 0; s_endcell = kc + 2; }
         __syncthreads();
         for (uint32_t v = tid; v < base_d; v += kOrbitThreads) {
             gst(w_list + v, v);
@@ -684,18 +677,34 @@ k_sync_orbit_global(const uint64_t *__restrict__ words, const uint32_t *__restri
         for (int level = 0; level < kMaxLevels && lo < hi; ++level) {
             for (uint32_t idx = lo + tid; idx < hi; idx += kOrbitThreads) {
                 const uint32_t v = gld(w_list + idx);
-                uint32_t cell, u = 0, nx = END;
+                uint32_t cell, u = 0, nx = END, nxcell = 0;
                 const uint32_t sv = node_start(v, &cell);
                 if (sv < nc32) {
                     const uint32_t e = first_node_terminal(sv, &u);
                     const uint32_t a = u + md + 1;
                     const uint32_t b = (cell + 1) * spr;
                     const uint32_t s2 = a > b ? a : b;
-                    if (s2 < nc32) nx = (a >= b) ? base_d + e : cell;  // grid(cell+1) has id `cell`
+                    if (s2 < nc32) {
+                        nx = (a >= b) ? base_d + e : cell;  // grid(cell+1) has id `cell`
+                        nxcell = (a >= b) ? div_spr(a) : cell + 1;
+                    }
                 }
                 gst(w_ja + v, nx);
                 gst(w_u + v, u);
-                if (nx != END) {
+                // confluence bookkeeping for the direct path: every visited start of a cell must
+                // agree on the successor, and the successor must sit in the very next cell
+                if (cell < kc + 3) {
+                    if (v < base_d) {
+                        // seeds (root, grid nodes) are alone in their cell: plain store, no round trip
+                        gst(w_succ + cell, nx);
+                    } else {
+                        const uint32_t old = atomicCAS(w_succ + cell, 0xFFFFFFFFu, nx);
+                        if (old != 0xFFFFFFFFu && old != nx) s_conflict = 1;
+                    }
+                }
+                if (nx == END) atomicMin(&s_endcell, cell);
+                else if (nxcell != cell + 1) s_conflict = 1;
+                if (nx != END && nx >= base_d) {  // grid targets are seeds: already visited
                     const uint32_t bit = 1u << (nx & 31);
                     if (!(atomicOr(w_mark + (nx >> 5), bit) & bit)) gst(w_list + atomicAdd(&s_count, 1u), nx);
                 }
@@ -722,10 +731,21 @@ k_sync_orbit_global(const uint64_t *__restrict__ words, const uint32_t *__restri
     if (tid == 0) { gst(w_ja + END, END); gst(w_jb + END, END); gst(w_path, 0u); }
     __syncthreads();
 
-    // ---- orbit of the root by pointer doubling over the visited nodes:
-    // path[m + 2^r] = J_r[path[m]],  J_{r+1} = J_r o J_r (double-buffered)
     const uint32_t path_cap = kc + 2;  // root + at most one start per cell
+    const bool direct = s_conflict == 0;  // uniform (shared)
+    if (direct) {
+        // ---- confluent recording: the start in cell k+1 is the common successor of cell k, so the
+        // orbit is read off without any pointer chasing: path[0] = root (acts as cell 1),
+        // path[k] = succ[k] up to the first cell whose successor is END
+        const uint32_t endc = s_endcell;
+        for (uint32_t k = tid + 1; k < path_cap; k += kOrbitThreads)
+            gst(w_path + k, k < endc ? gld(w_succ + k) : END);
+        __syncthreads();
+    }
+    // ---- otherwise: orbit of the root by pointer doubling over the visited nodes:
+    // path[m + 2^r] = J_r[path[m]],  J_{r+1} = J_r o J_r (double-buffered)
     uint32_t *ja = w_ja, *jb = w_jb;
+    if (!direct) {
     constexpr int kKeep = 4;  // visited ids (and their current jump) kept in registers
     uint32_t vk[kKeep], jk[kKeep];
 #pragma unroll
@@ -749,6 +769,7 @@ k_sync_orbit_global(const uint64_t *__restrict__ words, const uint32_t *__restri
         __syncthreads();
         uint32_t *t = ja; ja = jb; jb = t;
     }
+    }  // !direct
     stamp(1);  // orbit extracted
 
     // ---- peak list: path[k] (k >= 1) starts at s in cell c; pushes fill
@@ -798,6 +819,7 @@ k_sync_orbit_global(const uint64_t *__restrict__ words, const uint32_t *__restri
         flags[2] = nt_cap;
         flags[3] = n_nodes;
         flags[4] = count;
+        flags[6] = direct ? 1u : 0u;
     }
     stamp(2);  // peaks written
 }
@@ -836,7 +858,7 @@ size_t sync_orbit_ws_words(uint64_t n_corr, uint32_t spr)
     const uint64_t nt_cap = chunks * kSlotCap;
     const uint64_t kc = (spr ? n_corr / spr : 0) + 2;
     const uint64_t node_cap = 1 + kc + nt_cap + 1;
-    return 4 * node_cap + (node_cap / 32 + 1) + (kc + 2) + 64;
+    return 4 * node_cap + (node_cap / 32 + 1) + (kc + 2) + (kc + 3) + 64;
 }
 
 void sync_orbit(hipStream_t s, const uint64_t *words, const uint32_t *slot_nt,

@@ -325,6 +325,30 @@ def test_steps_export(ctx, oracle):
     assert_bitexact(by["resample_decimated"][1][1], want_rows)
 
 
+def test_picker_paths_direct_and_doubling(oracle):
+    """The global-memory picker reads the orbit off directly on a confluent (continuous APT)
+    recording and falls back to pointer doubling otherwise; both bit-exact."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    cases = [("apt", synth_apt(48000, 20, 5)), ("noise", synth_noise(48000, 20.0, 5, sigma=4000.0))]
+    seen = {}
+    for name, x in cases:
+        plan = apt.Plan(apt.Settings(), apt.Rate.hz(48000), True, max_samples=x.size)
+        d_in = torch.from_numpy(x).to(dev)
+        cap = int(plan.info.max_rows)
+        d_out = torch.empty(cap * 2080, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        plan.decode_device([d_in.data_ptr()], [x.size], [d_out.data_ptr()], [cap])
+        res = plan.results(1)[0]
+        flags = plan.read_internal("picker_flags", np.uint32, 32)
+        want = oracle.decode(x, 48000, True)
+        assert_bitexact(d_out[:res.n_out].cpu().numpy(), want, name)
+        seen[name] = (int(flags[1]), int(flags[6]))
+        plan.close()
+    assert seen["apt"] == (2, 1)       # global kernel, direct orbit
+    assert seen["noise"][0] == 2       # global kernel (orbit direct or doubling, data dependent)
+
+
 # ------------------------------------------------------------------ plans / batch
 def test_plan_device_resident_batch(ctx, oracle):
     torch = pytest.importorskip("torch")
