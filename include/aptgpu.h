@@ -187,7 +187,8 @@ int aptgpu_plan_synchronize(aptgpu_plan *plan);
 int aptgpu_plan_join(aptgpu_plan *plan);
 
 /* Kernel timing with HIP events recorded on the plan's stream.  on = 0: off;
- * 1: only the dominant (first-stage) kernel of each decode is bracketed; 2: every
+ * 1: the dominant (first-stage) kernel of every 8th decode is bracketed (sampling keeps the
+ * markers, which serialise the stream, cheap); 2: every
  * kernel launch is.  Enable, run decodes, then collect: averages are over all
  * bracketed launches since the last collect. */
 typedef struct aptgpu_kernel_time {

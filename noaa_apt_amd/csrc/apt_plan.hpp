@@ -55,7 +55,7 @@ struct DeviceBuffer {
 class KernelTimer {
 public:
     ~KernelTimer();
-    // 0 = off, 1 = only launches flagged `dominant`, 2 = every launch
+    // 0 = off, 1 = every 8th launch flagged `dominant`, 2 = every launch
     void enable(int mode);
     int mode() const { return mode_; }
     void begin(hipStream_t s, const char *name, bool dominant);
@@ -70,6 +70,7 @@ private:
     };
     int mode_ = 0;
     bool open_ = false;
+    uint64_t sampled_ = 0;
     std::vector<Pair> pairs_;
     std::vector<hipEvent_t> pool_;
     hipEvent_t take();
