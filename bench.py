@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=600.0)
     ap.add_argument("--profile", default="standard")
     ap.add_argument("--mode", default="strict", choices=["strict", "generic", "fp16taps"])
+    ap.add_argument("--inputs", type=int, default=4,
+                    help="distinct recordings resident in HBM, decoded round-robin (4 x 115 MB exceeds "
+                         "the 256 MB Infinity Cache, so every step reads its input from HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="experiment: leave the per-kernel HIP events out of the timed region")
@@ -68,20 +71,28 @@ def main():
     rate = apt.Rate.hz(args.rate)
 
     # ---- synthetic recording (seeded per rank), moved to HBM before any timing
-    x = synth_apt(args.rate, args.seconds, seed=2 + rank)
+    # recording 0 is the one checked against the oracle; the others differ in seed (noise, image)
+    n_inputs = max(1, args.inputs)
+    xs = [synth_apt(args.rate, args.seconds, seed=2 + rank + 1000 * j) for j in range(n_inputs)]
+    x = xs[0]
     n = x.size
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        d_x = torch.from_numpy(x).to(dev)
+        d_xs = [torch.from_numpy(v).to(dev) for v in xs]
+        d_x = d_xs[0]
         mode = {"strict": apt.MODE_STRICT, "generic": apt.MODE_GENERIC, "fp16taps": apt.MODE_FP16_TAPS}[args.mode]
         plan = apt.Plan(settings, rate, True, max_samples=n, max_batch=1, device=local_rank,
                         mode=mode, stream=stream.cuda_stream)
         cap = int(plan.info.max_rows)
         d_rows = torch.empty(cap * 2080, dtype=torch.float32, device=dev)
-        sig, nn, out, caps = [d_x.data_ptr()], [n], [d_rows.data_ptr()], [cap]
+        sigs, nn, out, caps = [[d.data_ptr()] for d in d_xs], [n], [d_rows.data_ptr()], [cap]
+        counter = [0]
 
-        def step():
-            plan.decode_device(sig, nn, out, caps)
+        def step(j=None):
+            if j is None:
+                j = counter[0] % n_inputs
+                counter[0] += 1
+            plan.decode_device(sigs[j], nn, out, caps)
 
         for _ in range(args.warmup):
             step()
@@ -107,6 +118,7 @@ def main():
             step()
         ktimes = plan.collect_timing()
         plan.enable_timing(0)
+        step(0)  # the recording that is compared with the oracle below
         res = plan.results(1)[0]
         pflags = plan.read_internal("picker_flags", np.uint32, 32)
 
@@ -164,6 +176,7 @@ def main():
                 "rows": int(res.n_rows),
                 "n_sync": int(res.n_sync),
                 "input_resident_in_hbm": True,
+                "distinct_inputs_round_robin": n_inputs,
                 "picker": {"path": {0: "lds", 1: "sequential-walk", 2: "global"}.get(int(pflags[1]), "?"),
                            "node_capacity": int(pflags[3]), "visited_nodes": int(pflags[4]), "orbit": "direct" if int(pflags[6]) else "doubling",
                            "cycle_stamps": [int(v) for v in pflags[8:11]]},

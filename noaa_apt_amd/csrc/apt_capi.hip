@@ -122,15 +122,9 @@ void aptgpu_plan_destroy(aptgpu_plan *plan)
 {
     if (!plan) return;
     (void)hipSetDevice(plan->device);
-    if (plan->stream) (void)hipStreamSynchronize(plan->stream);
-    if (plan->stream2) (void)hipStreamSynchronize(plan->stream2);
-    for (auto &sl : plan->slots) {
-        if (sl.ev_front) (void)hipEventDestroy(sl.ev_front);
-        if (sl.ev_free) (void)hipEventDestroy(sl.ev_free);
-    }
+    for (hipStream_t st : plan->streams) (void)hipStreamSynchronize(st);
     if (plan->ev_user) (void)hipEventDestroy(plan->ev_user);
-    if (plan->stream) (void)hipStreamDestroy(plan->stream);
-    if (plan->stream2) (void)hipStreamDestroy(plan->stream2);
+    for (hipStream_t st : plan->streams) (void)hipStreamDestroy(st);
     delete plan;
 }
 
@@ -191,7 +185,7 @@ int aptgpu_plan_join(aptgpu_plan *plan)
     if (!plan->user_stream) return aptgpu_plan_synchronize(plan);
     (void)hipSetDevice(plan->device);
     // ctx.stream waits (on the device) for everything enqueued so far on both internal streams
-    for (hipStream_t st : {plan->stream, plan->stream2}) {
+    for (hipStream_t st : plan->streams) {
         if (hipEventRecord(plan->ev_user, st) != hipSuccess ||
             hipStreamWaitEvent(plan->user_stream, plan->ev_user, 0) != hipSuccess)
             return APTGPU_ERR_HIP;
@@ -255,6 +249,7 @@ int aptgpu_plan_collect_timing(aptgpu_plan *plan, aptgpu_kernel_time *out, size_
     try {
         (void)hipSetDevice(plan->device);
         plan->sync_all();
+        plan->sync_all();  // the event pairs live on both streams
         auto v = plan->timer.collect(plan->stream);
         *n_out = v.size();
         for (size_t i = 0; i < v.size() && i < cap && out; ++i) out[i] = v[i];
@@ -317,7 +312,7 @@ int aptgpu_decode(const aptgpu_context *ctx_in, const aptgpu_settings *settings,
 
         PlanPtr plan(apt::plan_create(&ctx, *settings, input_rate_hz, sync != 0, n, 1));
         if (plan->spr == 0) throw Error{ErrorKind::Invalid, "work_rate too small"};
-        hipStream_t s = plan->stream;
+        hipStream_t s = plan->stream;  // a fresh plan's first recording runs on streams[0] == stream
         const uint64_t w = plan->work_len_for(n);
 
         apt::DeviceBuffer<float> d_in, d_rows;

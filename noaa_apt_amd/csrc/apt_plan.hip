@@ -175,12 +175,6 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
 
     // ---- device side
     hip_check(hipSetDevice(plan->device), "hipSetDevice");
-    hip_check(hipStreamCreateWithFlags(&plan->stream, hipStreamNonBlocking), "hipStreamCreate");
-    {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
-        hip_check(hipStreamCreateWithPriority(&plan->stream2, hipStreamNonBlocking, hi), "hipStreamCreate");
-    }
     if (ctx && ctx->stream) {
         plan->user_stream = static_cast<hipStream_t>(ctx->stream);
         hip_check(hipEventCreateWithFlags(&plan->ev_user, hipEventDisableTiming), "hipEventCreate");
@@ -223,6 +217,11 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
 
     // one extra slot so that consecutive calls (and consecutive recordings of a call) overlap
     plan->slots.resize(static_cast<size_t>(max_batch) + 1);
+    // two streams measured best on MI355X (3 is slower, 4 equal): slot k always runs on stream k % 2
+    plan->streams.resize(std::min<size_t>(plan->slots.size(), 2));
+    for (auto &st : plan->streams)
+        hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+    plan->stream = plan->streams[0];
     const uint64_t w = plan->max_work_len;
     for (auto &sl : plan->slots) {
         sl.resampled.alloc(w + 64);
@@ -242,10 +241,6 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
             sl.flags.alloc(32);
             hip_check(hipMemset(sl.flags.ptr, 0, 32 * sizeof(uint32_t)), "hipMemset flags");
         }
-    }
-    for (auto &sl : plan->slots) {
-        hip_check(hipEventCreateWithFlags(&sl.ev_front, hipEventDisableTiming), "hipEventCreate");
-        hip_check(hipEventCreateWithFlags(&sl.ev_free, hipEventDisableTiming), "hipEventCreate");
     }
     plan->d_results.alloc(plan->slots.size());
     hip_check(hipMemset(plan->d_results.ptr, 0, sizeof(gpu::Result) * plan->slots.size()), "hipMemset");
@@ -275,14 +270,13 @@ void aptgpu_plan::begin_call(int count)
     last_slots.assign(static_cast<size_t>(count), 0);
     if (user_stream) {
         apt::hip_check(hipEventRecord(ev_user, user_stream), "hipEventRecord");
-        apt::hip_check(hipStreamWaitEvent(stream, ev_user, 0), "hipStreamWaitEvent");
+        for (hipStream_t st : streams) apt::hip_check(hipStreamWaitEvent(st, ev_user, 0), "hipStreamWaitEvent");
     }
 }
 
 void aptgpu_plan::sync_all()
 {
-    apt::hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
-    apt::hip_check(hipStreamSynchronize(stream2), "hipStreamSynchronize");
+    for (hipStream_t st : streams) apt::hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
 }
 
 int aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows,
@@ -294,25 +288,9 @@ int aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows
     Slot &sl = slots[static_cast<size_t>(slot)];
     Result *res = d_results.ptr + slot;
     const uint64_t w = work_len_for(n);
-    // the previous user of this slot must have finished its picker/gather
-    if (sl.used) apt::hip_check(hipStreamWaitEvent(stream, sl.ev_free, 0), "hipStreamWaitEvent");
-    sl.used = true;
-    hipStream_t front = stream, back = stream2;
-    bool handed_over = false;
-    auto hand_over = [&] {  // front end done -> picker stream may start
-        if (handed_over) return;
-        apt::hip_check(hipEventRecord(sl.ev_front, front), "hipEventRecord");
-        apt::hip_check(hipStreamWaitEvent(back, sl.ev_front, 0), "hipStreamWaitEvent");
-        handed_over = true;
-    };
-    auto release = [&] {  // everything of this recording is enqueued: mark the slot's end
-        hand_over();
-        apt::hip_check(hipEventRecord(sl.ev_free, back), "hipEventRecord");
-    };
-
-    // the first-stage kernels carry the bulk of the work: they are the "dominant" launches
-    // that timing mode 1 brackets with events (mode 2 brackets every launch)
-    hipStream_t cur = front;  // stream the next launch goes to
+    // everything of this recording runs in order on the slot's own stream; the recording that
+    // reuses the slot is enqueued on the same stream, so no hand-over events are needed
+    hipStream_t cur = streams[static_cast<size_t>(slot) % streams.size()];
     auto timed = [&](const char *name, auto &&launch) {
         const bool dominant = !std::strcmp(name, "fused_front_end") || !std::strcmp(name, "resample_generic") ||
                               !std::strcmp(name, "resample_f16taps");
@@ -323,8 +301,7 @@ int aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows
 
     // decode.rs:79-83 — fewer than 10 rows of samples
     if (w < 10ull * spr) {
-        set_result(front, res, Result{APTGPU_ERR_INTERNAL, 1, 0, 0, w, 0});
-        release();
+        set_result(cur, res, Result{APTGPU_ERR_INTERNAL, 1, 0, 0, w, 0});
         return slot;
     }
 
@@ -375,8 +352,6 @@ int aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows
         const uint64_t n_corr = w - n_sync_taps;  // w >= 10*spr > 38*pw
         if (!use_fused)
             timed("correlate", [&] { correlate(cur, sl.filtered.ptr, n_corr, pw, sl.correlation.ptr); });
-        hand_over();
-        cur = back;
         if (mode == APTGPU_MODE_GENERIC) {
             // reference-shaped picker: full sliding-window terminals + sequential orbit
             timed("terminals", [&] { terminals(cur, sl.correlation.ptr, n_corr, md, sl.bits.ptr); });
@@ -421,6 +396,5 @@ int aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows
         set_result(cur, res,
                    Result{APTGPU_OK, 0, static_cast<uint32_t>(n_out / 2080u), 0, w, n_out});
     }
-    release();
     return slot;
 }

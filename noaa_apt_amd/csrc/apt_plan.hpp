@@ -82,11 +82,13 @@ private:
 struct aptgpu_plan {
     int device = 0;
     int mode = APTGPU_MODE_STRICT;
-    // Two internal streams form a software pipeline over consecutive recordings: the front
-    // end (resample .. correlation) of recording i+1 runs on `stream` while the peak picker
-    // and row gather of recording i run on `stream2`; events hand the workspace slots over.
-    hipStream_t stream = nullptr;   // front end
-    hipStream_t stream2 = nullptr;  // picker + gather
+    // Software pipeline over consecutive recordings: a recording's whole chain (front end ->
+    // picker -> gather) runs in order on ONE of two streams, recordings alternate between
+    // them (slot k -> stream k % 2).  The front end of recording i+1 therefore overlaps the
+    // latency-bound picker/gather of recording i without any cross-stream events, and a slot
+    // is only ever reused by a later recording on its own stream (in-order => no hazards).
+    std::vector<hipStream_t> streams;
+    hipStream_t stream = nullptr;       // = streams[0] (host-API helpers, timing collection)
     hipStream_t user_stream = nullptr;  // ctx.stream: inputs are ordered after it (may be null)
     hipEvent_t ev_user = nullptr;
     uint64_t seq = 0;               // recordings enqueued so far (slot = seq % slots.size())
@@ -129,9 +131,6 @@ struct aptgpu_plan {
         apt::DeviceBuffer<float> gm;          // per-group maxima of the correlation
         apt::DeviceBuffer<uint64_t> words;    // 52-bit terminal words
         apt::DeviceBuffer<uint32_t> slot_nt, slot_cnt, flags, orbit_ws;
-        hipEvent_t ev_front = nullptr;  // front end of this slot finished (stream -> stream2)
-        hipEvent_t ev_free = nullptr;   // picker/gather finished with this slot (stream2 -> stream)
-        bool used = false;
     };
     std::vector<Slot> slots;
     apt::DeviceBuffer<apt::gpu::Result> d_results;
