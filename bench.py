@@ -112,6 +112,13 @@ def main():
             dist.barrier()
         t1 = time.perf_counter()
         dom_times = plan.collect_timing()
+        # untimed: the dominant kernel with nothing else on the GPU (one step at a time)
+        plan.enable_timing(1)
+        iso_n = 16  # mode 1 samples every 8th dominant launch
+        for _ in range(iso_n):
+            step()
+            torch.cuda.synchronize()
+        iso_times = plan.collect_timing()
         # untimed extra pass with events around every kernel, for the per-kernel breakdown
         plan.enable_timing(2)
         for _ in range(min(args.steps, 10)):
@@ -193,6 +200,12 @@ def main():
                 "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
                                   if traffic else None,
                 "algorithmic_bytes_per_launch": b_alg,
+                # the pipeline keeps two recordings in flight, so a launch in the timed region
+                # shares the GPU with the other recording's kernels; alone it takes:
+                "co_resident_recordings": 2,
+                "kernel_alone_avg_ms": round(iso_times.get(dom[0], (0.0, 0))[0], 5) if iso_times else None,
+                "frac_alone": round(b_alg / (iso_times[dom[0]][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                              if iso_times and iso_times.get(dom[0], (0, 0))[0] > 0 else None,
             },
             "pipeline": {
                 "achieved": round(pipe_achieved, 2),

@@ -165,9 +165,9 @@ int aptgpu_plan_get_info(const aptgpu_plan *plan, aptgpu_plan_info *info);
 /* Enqueue decode() of `count` independent recordings already resident in HBM.
  * d_signals[i] points to n[i] device floats; d_rows[i] receives up to
  * rows_cap[i]*2080 device floats.  Asynchronous, no host synchronisation.
- * The plan runs a two-stream software pipeline: the front end of recording
- * i+1 (also across consecutive calls) overlaps the peak picker and row gather
- * of recording i, handing max_batch+1 workspace slots over with events.  If
+ * The plan alternates recordings between two in-order streams (also across
+ * consecutive calls), so the front end of recording i+1 overlaps the peak
+ * picker and row gather of recording i; it owns max_batch+1 workspace slots.  If
  * ctx.stream was given at plan creation the work is ordered AFTER what is
  * already enqueued on ctx.stream (inputs may be produced there); to order
  * ctx.stream after the decode, call aptgpu_plan_join().  Outcome per recording
@@ -247,7 +247,71 @@ int aptgpu_find_sync(const aptgpu_context *ctx, const float *signal, size_t n,
                      float **correlation_out, size_t *n_corr, char *err, size_t err_cap);
 
 /* ====================================================================== */
-/* 4. misc                                                                 */
+/* 4. consumers of the pixel rows                 */
+/* ====================================================================== */
+/* The grayscale part of noaa_apt::process() (src/noaa_apt.rs:132-192): contrast limits   */
+/* -> map_signal_u8, plus telemetry.rs and the 180-degree channel rotation.  False colour, */
+/* histogram equalisation and the map overlay stay on the host (out of scope).            */
+
+#define APTGPU_CONTRAST_TELEMETRY 0 /* Contrast::Telemetry   src/noaa_apt.rs:141-150 */
+#define APTGPU_CONTRAST_PERCENT 1   /* Contrast::Percent(p)  src/noaa_apt.rs:151-157 */
+#define APTGPU_CONTRAST_MINMAX 2    /* Contrast::MinMax      src/noaa_apt.rs:158-164 (Histogram
+                                       takes the same limits before its equalisation) */
+#define APTGPU_ROTATE_NO 0          /* Rotate::No  */
+#define APTGPU_ROTATE_YES 1         /* Rotate::Yes  src/noaa_apt.rs:228-231, processing.rs:21-37 */
+
+/* What the image stage found; also the telemetry::Telemetry values (src/telemetry.rs:19-23). */
+typedef struct aptgpu_image_result {
+    int32_t status;          /* APTGPU_OK or APTGPU_ERR_INTERNAL */
+    int32_t reason;          /* 1 zero-length signal (dsp.rs:40-44), 2 too short for telemetry
+                                (telemetry.rs:199-203), 3 no low bucket (misc.rs:172 panics),
+                                4 the decode before it failed */
+    uint32_t height;         /* rows of 2080 px */
+    uint32_t telemetry_row;  /* best frame start, telemetry.rs:196,228-230 */
+    float low, high;         /* the contrast limits used by map_signal_u8 */
+    float telemetry_quality;
+    int32_t channel_a, channel_b; /* index for aptgpu_channel_name(), -1 = not computed */
+    uint32_t reserved;
+    uint64_t n_px;           /* u8 pixels written */
+    float values_a[16], values_b[16]; /* wedges 1-16 of each band */
+} aptgpu_image_result;
+
+/* dsp::get_min / dsp::get_max          src/dsp.rs:20-54 */
+int aptgpu_get_min(const aptgpu_context *ctx, const float *signal, size_t n, float *out, char *err,
+                   size_t err_cap);
+int aptgpu_get_max(const aptgpu_context *ctx, const float *signal, size_t n, float *out, char *err,
+                   size_t err_cap);
+/* misc::percent(signal, percent)       src/misc.rs:119-175 */
+int aptgpu_percent(const aptgpu_context *ctx, const float *signal, size_t n, float percent,
+                   float *low, float *high, char *err, size_t err_cap);
+/* map_signal_u8(signal, low, high)     src/noaa_apt.rs:249-259; *out malloc'd, n bytes */
+int aptgpu_map_signal_u8(const aptgpu_context *ctx, const float *signal, size_t n, float low,
+                         float high, uint8_t **out, char *err, size_t err_cap);
+/* telemetry::read_telemetry(context, signal)   src/telemetry.rs:125-243; fills values_*,
+ * telemetry_row/quality, channel_*.  With ctx->step set, the five "telemetry_*" steps are
+ * exported in the reference's order (telemetry.rs:234-238). */
+int aptgpu_read_telemetry(const aptgpu_context *ctx, const float *signal, size_t n,
+                          aptgpu_image_result *telemetry, char *err, size_t err_cap);
+/* Telemetry::get_channel_name table    src/telemetry.rs:104-106 */
+const char *aptgpu_channel_name(int index);
+/* process() up to the GrayImage (+ rotate): contrast limits, status callbacks at 0.1 / 0.3 /
+ * 0.90 with the reference's texts, u8 image rows*2080 (malloc'd).  src/noaa_apt.rs:132-235 */
+int aptgpu_process_gray(const aptgpu_context *ctx, const float *signal, size_t n, int contrast,
+                        float percent, int rotate, uint8_t **image_out, size_t *n_out,
+                        aptgpu_image_result *info, char *err, size_t err_cap);
+/* Device-resident: the same stage chained behind the most recent aptgpu_plan_decode_device
+ * call, recording i of that call, on the recording's own stream (no host round trip; the
+ * pixel count comes from the decode result on the device).  d_rows[i] must be the rows
+ * buffer given to the decode call (same rows_cap[i]); d_images[i] has room for
+ * rows_cap[i]*2080 bytes. */
+int aptgpu_plan_process_device(aptgpu_plan *plan, int count, const float *const *d_rows,
+                               const size_t *rows_cap, int contrast, float percent, int rotate,
+                               uint8_t *const *d_images, char *err, size_t err_cap);
+/* Waits for the image stage of the last call and copies the records. */
+int aptgpu_plan_image_results(aptgpu_plan *plan, int count, aptgpu_image_result *results);
+
+/* ====================================================================== */
+/* 5. misc                                                                 */
 /* ====================================================================== */
 const char *aptgpu_version(void);
 int aptgpu_device_count(void);

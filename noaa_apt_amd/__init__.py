@@ -12,6 +12,9 @@ Names, argument meaning and error behaviour follow the reference:
     Lowpass, LowpassDcRemoval, NoFilter                    /root/reference/src/filters.rs:22-138
     resample_with_filter, resample, demodulate, filter     /root/reference/src/dsp.rs:62,132,350,386
     find_sync, generate_sync_frame                         /root/reference/src/decode.rs:171,204
+    process (grayscale part), Contrast, Rotate             /root/reference/src/noaa_apt.rs:25-60,132-235
+    percent, get_min, get_max, map_signal_u8               /root/reference/src/misc.rs:119, dsp.rs:20-54
+    read_telemetry, Telemetry                              /root/reference/src/telemetry.rs:19-243
 
 There is no CPU fallback: if libaptgpu.so is missing or no GPU is present the calls
 raise.  (The CPU oracle lives in oracle/ and is test infrastructure only.)
@@ -22,6 +25,8 @@ from .api import (  # noqa: F401
     Rate, Freq, Settings, Context, Stats,
     NoFilter, Lowpass, LowpassDcRemoval,
     decode, resample_with_filter, resample, demodulate, filter, find_sync, generate_sync_frame,
+    Contrast, Rotate, Telemetry, ImageResult,
+    get_min, get_max, percent, map_signal_u8, read_telemetry, process,
     Plan, PlanInfo, Result, KernelTime,
     lib, lib_path, build, device_count, version,
     MODE_STRICT, MODE_GENERIC, MODE_FP16_TAPS,

@@ -20,6 +20,7 @@ _LIB = os.path.join(_HERE, "libaptgpu.so")
 _f32p = C.POINTER(C.c_float)
 _u64p = C.POINTER(C.c_uint64)
 _i8p = C.POINTER(C.c_int8)
+_u8p = C.POINTER(C.c_uint8)
 _ERRCAP = 1024
 
 
@@ -97,6 +98,15 @@ class PlanInfo(C.Structure):
 class Result(C.Structure):
     _fields_ = [("status", C.c_int32), ("reason", C.c_int32), ("n_rows", C.c_uint32),
                 ("n_sync", C.c_uint32), ("work_len", C.c_uint64), ("n_out", C.c_uint64)]
+
+
+class ImageResult(C.Structure):
+    """aptgpu_image_result: contrast limits, image height and the telemetry values."""
+    _fields_ = [("status", C.c_int32), ("reason", C.c_int32), ("height", C.c_uint32),
+                ("telemetry_row", C.c_uint32), ("low", C.c_float), ("high", C.c_float),
+                ("telemetry_quality", C.c_float), ("channel_a", C.c_int32), ("channel_b", C.c_int32),
+                ("reserved", C.c_uint32), ("n_px", C.c_uint64), ("values_a", C.c_float * 16),
+                ("values_b", C.c_float * 16)]
 
 
 class KernelTime(C.Structure):
@@ -177,6 +187,19 @@ def lib():
                                        C.c_char_p, sz]
     L.aptgpu_find_sync.argtypes = [C.POINTER(_CContext), _f32p, sz, u32, C.POINTER(_u64p),
                                    C.POINTER(sz), C.POINTER(_f32p), C.POINTER(sz), C.c_char_p, sz]
+    cp, f = C.POINTER(_CContext), C.c_float
+    L.aptgpu_get_min.argtypes = [cp, _f32p, sz, _f32p, C.c_char_p, sz]
+    L.aptgpu_get_max.argtypes = [cp, _f32p, sz, _f32p, C.c_char_p, sz]
+    L.aptgpu_percent.argtypes = [cp, _f32p, sz, f, _f32p, _f32p, C.c_char_p, sz]
+    L.aptgpu_map_signal_u8.argtypes = [cp, _f32p, sz, f, f, C.POINTER(_u8p), C.c_char_p, sz]
+    L.aptgpu_read_telemetry.argtypes = [cp, _f32p, sz, C.POINTER(ImageResult), C.c_char_p, sz]
+    L.aptgpu_channel_name.argtypes = [i32]
+    L.aptgpu_channel_name.restype = C.c_char_p
+    L.aptgpu_process_gray.argtypes = [cp, _f32p, sz, i32, f, i32, C.POINTER(_u8p), C.POINTER(sz),
+                                      C.POINTER(ImageResult), C.c_char_p, sz]
+    L.aptgpu_plan_process_device.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(sz), i32, f, i32,
+                                             C.POINTER(vp), C.c_char_p, sz]
+    L.aptgpu_plan_image_results.argtypes = [vp, i32, C.POINTER(ImageResult)]
     _lib = L
     return L
 
@@ -421,6 +444,119 @@ def generate_sync_frame(work_rate: Rate):
     return _take(out, n.value, np.int8)
 
 
+# ------------------------------------------------------------------ consumers of the rows
+class Contrast:
+    """noaa_apt::Contrast (noaa_apt.rs:25-37).  Histogram's equalisation is host-side and out
+    of scope; it takes MinMax limits first (noaa_apt.rs:158)."""
+    TELEMETRY, MINMAX = ("telemetry",), ("minmax",)
+
+    @staticmethod
+    def Percent(p):  # noqa: N802 - the reference's variant name
+        return ("percent", float(p))
+
+    @staticmethod
+    def _c(contrast):
+        kind = contrast[0]
+        return ({"telemetry": 0, "percent": 1, "minmax": 2}[kind],
+                contrast[1] if kind == "percent" else 0.0)
+
+
+class Rotate:
+    """noaa_apt::Rotate (noaa_apt.rs:52-60); Orbit needs orbit propagation (out of scope)."""
+    NO, YES, ORBIT = 0, 1, 2
+
+
+class Telemetry:
+    """telemetry::Telemetry (telemetry.rs:19-121): wedge values of both bands."""
+
+    def __init__(self, values_a, values_b, row=0, quality=0.0, channels=(-1, -1)):
+        self.values_a = np.asarray(values_a, np.float32)
+        self.values_b = np.asarray(values_b, np.float32)
+        self.row, self.quality, self._channels = int(row), np.float32(quality), channels
+
+    @staticmethod
+    def _from(r: ImageResult):
+        return Telemetry(list(r.values_a), list(r.values_b), r.telemetry_row, r.telemetry_quality,
+                         (r.channel_a, r.channel_b))
+
+    def get_wedge_value(self, wedge, channel=None):
+        if channel == "A":
+            return self.values_a[wedge - 1]
+        if channel == "B":
+            return self.values_b[wedge - 1]
+        return np.float32((self.values_a[wedge - 1] + self.values_b[wedge - 1]) / np.float32(2.))
+
+    def get_channel_name(self, channel):
+        i = self._channels[{"A": 0, "B": 1}[channel]]
+        if i < 0:
+            raise InternalError("Can't compare values")
+        return lib().aptgpu_channel_name(i).decode()
+
+
+def _reduce(fn, context, signal):
+    cctx = (context or Context())._c()
+    x, xp = _as_f32(signal)
+    out = C.c_float()
+    err = C.create_string_buffer(_ERRCAP)
+    _check(fn(C.byref(cctx), xp, x.size, C.byref(out), err, _ERRCAP), err)
+    return np.float32(out.value)
+
+
+def get_min(signal, context=None):   # dsp.rs:38
+    return _reduce(lib().aptgpu_get_min, context, signal)
+
+
+def get_max(signal, context=None):   # dsp.rs:20
+    return _reduce(lib().aptgpu_get_max, context, signal)
+
+
+def percent(signal, percent_value, context=None):  # misc.rs:119
+    cctx = (context or Context())._c()
+    x, xp = _as_f32(signal)
+    lo, hi = C.c_float(), C.c_float()
+    err = C.create_string_buffer(_ERRCAP)
+    _check(lib().aptgpu_percent(C.byref(cctx), xp, x.size, percent_value, C.byref(lo), C.byref(hi),
+                                err, _ERRCAP), err)
+    return np.float32(lo.value), np.float32(hi.value)
+
+
+def map_signal_u8(signal, low, high, context=None):  # noaa_apt.rs:249
+    cctx = (context or Context())._c()
+    x, xp = _as_f32(signal)
+    out = _u8p()
+    err = C.create_string_buffer(_ERRCAP)
+    _check(lib().aptgpu_map_signal_u8(C.byref(cctx), xp, x.size, low, high, C.byref(out), err,
+                                      _ERRCAP), err)
+    return _take(out, x.size, np.uint8)
+
+
+def read_telemetry(context, signal):  # telemetry.rs:125
+    cctx = (context or Context())._c()
+    x, xp = _as_f32(signal)
+    r = ImageResult()
+    err = C.create_string_buffer(_ERRCAP)
+    _check(lib().aptgpu_read_telemetry(C.byref(cctx), xp, x.size, C.byref(r), err, _ERRCAP), err)
+    return Telemetry._from(r)
+
+
+def process(context, signal, contrast_adjustment, rotate=Rotate.NO, color=None, orbit=None,
+            return_info=False):
+    """noaa_apt::process (noaa_apt.rs:132-235) up to the grayscale image: returns the
+    height x 2080 u8 array.  False colour, histogram equalisation and the map overlay are
+    host-side features of the reference that this path does not offer."""
+    if color is not None or orbit is not None:
+        raise UnsupportedError("false colour / map overlay are not part of the GPU path")
+    cctx = (context or Context())._c()
+    x, xp = _as_f32(signal)
+    kind, p = Contrast._c(contrast_adjustment)
+    img, n, info = _u8p(), C.c_size_t(), ImageResult()
+    err = C.create_string_buffer(_ERRCAP)
+    _check(lib().aptgpu_process_gray(C.byref(cctx), xp, x.size, kind, p, int(rotate), C.byref(img),
+                                     C.byref(n), C.byref(info), err, _ERRCAP), err)
+    out = _take(img, n.value, np.uint8).reshape(-1, PX_PER_ROW)
+    return (out, info) if return_info else out
+
+
 # ------------------------------------------------------------------ plans (device-resident)
 class Plan:
     """aptgpu_plan: device-resident / batched decode().  Device pointers are plain ints
@@ -458,6 +594,22 @@ class Plan:
         cap = (C.c_size_t * k)(*rows_cap)
         err = C.create_string_buffer(_ERRCAP)
         _check(lib().aptgpu_plan_decode_device(self._p, k, sig, nn, rows, cap, err, _ERRCAP), err)
+
+    def process_device(self, d_rows: Sequence[int], rows_cap: Sequence[int], contrast_adjustment,
+                       d_images: Sequence[int], rotate=Rotate.NO):
+        """Contrast limits -> u8 image (and telemetry) of the recordings of the last
+        decode_device call, chained on the device behind their decode."""
+        k = len(d_rows)
+        kind, p = Contrast._c(contrast_adjustment)
+        err = C.create_string_buffer(_ERRCAP)
+        _check(lib().aptgpu_plan_process_device(self._p, k, (C.c_void_p * k)(*d_rows),
+                                                (C.c_size_t * k)(*rows_cap), kind, p, int(rotate),
+                                                (C.c_void_p * k)(*d_images), err, _ERRCAP), err)
+
+    def image_results(self, count=1) -> List[ImageResult]:
+        arr = (ImageResult * count)()
+        _check(lib().aptgpu_plan_image_results(self._p, count, arr))
+        return list(arr)
 
     def results(self, count=1) -> List[Result]:
         arr = (Result * count)()

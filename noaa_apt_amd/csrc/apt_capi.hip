@@ -6,66 +6,17 @@
 #include <memory>
 #include <string>
 
-#include "apt_plan.hpp"
+#include "apt_capi_util.hpp"
 
 namespace {
 
-using apt::Error;
-using apt::ErrorKind;
-
-void put_err(char *err, size_t cap, const std::string &msg)
-{
-    if (err && cap) std::snprintf(err, cap, "%s", msg.c_str());
-}
-
-int fail(const Error &e, char *err, size_t cap)
-{
-    put_err(err, cap, e.message);
-    return static_cast<int>(e.kind);
-}
-
-template <typename Fn>
-int guarded(char *err, size_t cap, Fn &&fn)
-{
-    try {
-        return fn();
-    } catch (const Error &e) {
-        return fail(e, err, cap);
-    } catch (const std::bad_alloc &) {
-        put_err(err, cap, "out of host memory");
-        return APTGPU_ERR_INVALID;
-    } catch (const std::exception &e) {
-        put_err(err, cap, e.what());
-        return APTGPU_ERR_INTERNAL;
-    }
-}
-
-template <typename T>
-T *host_alloc(size_t n)
-{
-    T *p = static_cast<T *>(std::malloc((n ? n : 1) * sizeof(T)));
-    if (!p) throw std::bad_alloc();
-    return p;
-}
+using namespace apt::capi;
 
 struct PlanDeleter {
     void operator()(aptgpu_plan *p) const { aptgpu_plan_destroy(p); }
 };
 using PlanPtr = std::unique_ptr<aptgpu_plan, PlanDeleter>;
 
-void status(const aptgpu_context *ctx, float progress, const std::string &text)
-{
-    if (ctx && ctx->status) ctx->status(progress, text.c_str(), ctx->user);
-}
-
-// Context::step through the C callback; a nonzero return aborts like `?` in the reference.
-void step(const aptgpu_context *ctx, bool on, const char *id, int variant, const float *data,
-          size_t n, uint32_t rate)
-{
-    if (!on || !ctx || !ctx->step) return;
-    if (ctx->step(id, variant, data, n, rate, ctx->user) != 0)
-        throw Error{ErrorKind::Internal, std::string("step callback failed at \"") + id + "\""};
-}
 
 apt::Signal download(const float *d, size_t n, hipStream_t s)
 {
@@ -481,51 +432,6 @@ int aptgpu_generate_sync_frame(uint32_t work_rate_hz, int8_t **frame_out, size_t
 }
 
 namespace {
-
-struct Scratch {
-    int device;
-    hipStream_t stream = nullptr;
-    bool own = false;
-    explicit Scratch(const aptgpu_context *ctx) : device(ctx ? ctx->device : 0)
-    {
-        apt::hip_check(hipSetDevice(device), "hipSetDevice");
-        if (ctx && ctx->stream) {
-            stream = static_cast<hipStream_t>(ctx->stream);
-        } else {
-            apt::hip_check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking),
-                           "hipStreamCreate");
-            own = true;
-        }
-    }
-    ~Scratch()
-    {
-        if (own && stream) {
-            (void)hipStreamSynchronize(stream);
-            (void)hipStreamDestroy(stream);
-        }
-    }
-    apt::DeviceBuffer<float> upload(const float *h, size_t n, size_t pad = 16)
-    {
-        apt::DeviceBuffer<float> d;
-        d.alloc(n + pad);
-        if (n)
-            apt::hip_check(hipMemcpyAsync(d.ptr, h, n * sizeof(float), hipMemcpyHostToDevice, stream),
-                           "hipMemcpyAsync H2D");
-        return d;
-    }
-    float *download_malloc(const float *d, size_t n)
-    {
-        float *p = host_alloc<float>(n);
-        if (n) {
-            if (hipMemcpyAsync(p, d, n * sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess ||
-                hipStreamSynchronize(stream) != hipSuccess) {
-                std::free(p);
-                throw Error{ErrorKind::Hip, "D2H copy failed"};
-            }
-        }
-        return p;
-    }
-};
 
 // resample_with_filter, dsp.rs:62-126, on host buffers.
 int resample_with_filter_impl(const aptgpu_context *ctx, const float *signal, size_t n,

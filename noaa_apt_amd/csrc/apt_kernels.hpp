@@ -19,6 +19,20 @@ struct Result {
     uint64_t n_out;
 };
 
+// Device-side record of the image stage == aptgpu_image_result (include/aptgpu.h).
+struct ImageResult {
+    int32_t status;   // 0 ok, 1 Internal
+    int32_t reason;   // 1 zero-length signal, 2 too short for telemetry, 3 no low bucket, 4 decode failed
+    uint32_t height;  // rows of 2080 px
+    uint32_t telemetry_row;
+    float low, high;
+    float telemetry_quality;
+    int32_t channel_a, channel_b;  // index into the reference's channel-name table, -1 = none
+    uint32_t reserved;
+    uint64_t n_px;
+    float values_a[16], values_b[16];
+};
+
 // ---- generic kernels (any l, m, tap count) --------------------------------------
 // fast_resampling, dsp.rs:186-289: out[k], k < w
 void resample_generic(hipStream_t s, const float *x, uint64_t n, const float *coeff,
@@ -79,6 +93,31 @@ void sync_orbit(hipStream_t s, const uint64_t *words, const uint32_t *slot_nt,
                 const uint32_t *slot_cnt, uint32_t *flags, uint64_t n_corr, uint64_t work_len,
                 uint32_t spr, uint32_t md, uint32_t *ws, uint32_t *peaks, uint32_t peaks_cap,
                 Result *res, int force /* 0 global-memory kernel, 1 sequential walk, 4 LDS kernel first */);
+
+// ---- consumers of the pixel rows (apt_kernels_image.hip) ------
+// All take the pixel count from `res` (device) when it is non-null, else `n`; `cap` bounds it
+// and sizes the launch.  `ws` is image_ws_bytes(cap) bytes of scratch, 16-byte aligned.
+size_t image_ws_bytes(uint64_t max_px);
+struct ImageWsPointers {
+    float *limits;     // [0] low, [1] high
+    uint32_t *counts;  // 1000 histogram buckets
+    float *mean_a, *mean_b, *variance, *corr, *quality;
+};
+ImageWsPointers image_ws_pointers(void *ws, uint64_t max_px);
+void image_begin(hipStream_t s, ImageResult *out);
+// dsp::get_min / get_max, dsp.rs:20-54 -> limits
+void image_minmax(hipStream_t s, const float *x, const Result *res, uint64_t n, uint64_t cap, void *ws,
+                  ImageResult *out);
+// misc::percent, misc.rs:119-175 -> limits
+void image_percent(hipStream_t s, const float *x, const Result *res, uint64_t n, uint64_t cap, float percent,
+                   void *ws, ImageResult *out);
+// telemetry::read_telemetry, telemetry.rs:125-243 -> out->values_*, rows; limits if set_limits
+void image_telemetry(hipStream_t s, const float *x, const Result *res, uint64_t n, uint64_t cap, void *ws,
+                     ImageResult *out, bool set_limits);
+void image_set_limits(hipStream_t s, void *ws, uint64_t cap, float low, float high);
+// map_signal_u8, noaa_apt.rs:249-259 (+ processing::rotate, processing.rs:21-37)
+void image_map_u8(hipStream_t s, const float *x, const Result *res, uint64_t n, uint64_t cap, void *ws,
+                  bool rotate, uint8_t *out, ImageResult *info);
 
 // writes a result record from the host's knowledge (too-short recording, no-sync path)
 void set_result(hipStream_t s, Result *res, Result value);

@@ -398,3 +398,39 @@ int aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows
     }
     return slot;
 }
+
+// ------------------------------------------------------------------ image stage
+void aptgpu_plan::enqueue_image(int i, const float *d_rows, uint64_t rows_cap_floats, int contrast,
+                                float percent, bool rotate, uint8_t *d_image)
+{
+    using namespace apt::gpu;
+    const size_t slot = static_cast<size_t>(last_slots[static_cast<size_t>(i)]);
+    Slot &sl = slots[slot];
+    uint64_t cap = static_cast<uint64_t>(max_rows) * 2080u;
+    if (!sync) cap = out_len_nosync(work_len_for(max_samples)) + 16;
+    if (rows_cap_floats < cap) cap = rows_cap_floats;
+    const uint64_t ws_cap = std::max<uint64_t>(static_cast<uint64_t>(max_rows) * 2080u,
+                                               out_len_nosync(work_len_for(max_samples)) + 16);
+    if (!d_image_results.ptr) {
+        d_image_results.alloc(slots.size());
+        apt::hip_check(hipMemset(d_image_results.ptr, 0, sizeof(ImageResult) * slots.size()), "hipMemset");
+    }
+    if (!sl.image_ws.ptr) sl.image_ws.alloc(image_ws_bytes(ws_cap));
+    hipStream_t cur = stream_of(i);
+    ImageResult *out = d_image_results.ptr + slot;
+    const Result *res = d_results.ptr + slot;
+    void *ws = sl.image_ws.ptr;
+    auto timed = [&](const char *name, auto &&launch) {
+        timer.begin(cur, name, false);
+        launch();
+        timer.end(cur);
+    };
+    image_begin(cur, out);
+    if (contrast == APTGPU_CONTRAST_TELEMETRY)
+        timed("image_telemetry", [&] { image_telemetry(cur, d_rows, res, 0, cap, ws, out, true); });
+    else if (contrast == APTGPU_CONTRAST_PERCENT)
+        timed("image_percent", [&] { image_percent(cur, d_rows, res, 0, cap, percent, ws, out); });
+    else
+        timed("image_minmax", [&] { image_minmax(cur, d_rows, res, 0, cap, ws, out); });
+    timed("image_map_u8", [&] { image_map_u8(cur, d_rows, res, 0, cap, ws, rotate, d_image, out); });
+}

@@ -131,9 +131,19 @@ struct aptgpu_plan {
         apt::DeviceBuffer<float> gm;          // per-group maxima of the correlation
         apt::DeviceBuffer<uint64_t> words;    // 52-bit terminal words
         apt::DeviceBuffer<uint32_t> slot_nt, slot_cnt, flags, orbit_ws;
+        apt::DeviceBuffer<char> image_ws;  // scratch of the image stage, allocated on first use
     };
     std::vector<Slot> slots;
     apt::DeviceBuffer<apt::gpu::Result> d_results;
+    apt::DeviceBuffer<apt::gpu::ImageResult> d_image_results;  // one per slot, on first use
+    // image stage (contrast limits -> u8, telemetry) of recording i of the last call, enqueued
+    // behind its decode on the same stream
+    void enqueue_image(int i, const float *d_rows, uint64_t rows_cap_floats, int contrast, float percent,
+                       bool rotate, uint8_t *d_image);
+    hipStream_t stream_of(int i)
+    {
+        return streams[static_cast<size_t>(last_slots[static_cast<size_t>(i)]) % streams.size()];
+    }
 
     apt::KernelTimer timer;
 

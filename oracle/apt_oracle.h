@@ -127,6 +127,31 @@ int apt_oracle_decode(const apt_oracle_settings *s, const float *x, size_t n,
                       uint32_t input_rate, int sync, float **out, size_t *n_out,
                       apt_oracle_steps *steps /* nullable */, char *err, size_t err_cap);
 
+/* --- consumers of decode()'s rows (apt_oracle_image.c) ---------- */
+/* dsp::get_max / get_min, src/dsp.rs:20-54 */
+int apt_oracle_get_max(const float *x, size_t n, float *out, char *err, size_t err_cap);
+int apt_oracle_get_min(const float *x, size_t n, float *out, char *err, size_t err_cap);
+/* misc::percent, src/misc.rs:119-175; buckets_out nullable (1000 counts) */
+int apt_oracle_percent(const float *x, size_t n, float percent, float *low, float *high,
+                       uint32_t *buckets_out, char *err, size_t err_cap);
+/* map_signal_u8, src/noaa_apt.rs:249-259 */
+void apt_oracle_map_signal_u8(const float *x, size_t n, float low, float high, uint8_t *out);
+/* telemetry.rs:30-121; channel: 0 = A, 1 = B, -1 = None (average) */
+void apt_oracle_telemetry_from_bands(const float *means_a, const float *means_b, size_t n,
+                                     size_t row, float values_a[16], float values_b[16]);
+float apt_oracle_telemetry_wedge_value(const float values_a[16], const float values_b[16],
+                                       uint32_t wedge, int channel);
+int apt_oracle_telemetry_channel_index(const float values_a[16], const float values_b[16], int channel);
+/* read_telemetry, src/telemetry.rs:125-243; optional malloc'd step outputs */
+int apt_oracle_read_telemetry(const float *signal, size_t n, float values_a[16], float values_b[16],
+                              uint64_t *best_row, float *best_quality, float **mean_a_out,
+                              float **mean_b_out, float **variance_out, float **corr_out,
+                              float **quality_out, size_t *rows_out, char *err, size_t err_cap);
+/* grayscale part of process(), src/noaa_apt.rs:132-192; contrast 0 Telemetry, 1 Percent, 2 MinMax */
+int apt_oracle_process_gray(const float *signal, size_t n, int contrast, float percent,
+                            uint8_t **image_out, size_t *n_out, float *low_out, float *high_out,
+                            char *err, size_t err_cap);
+
 void apt_oracle_free(void *p);
 void apt_oracle_free_steps(apt_oracle_steps *s);
 

@@ -73,7 +73,8 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_LIB_PATH):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if not os.path.exists(_LIB_PATH) or any(os.path.getmtime(f) > os.path.getmtime(_LIB_PATH) for f in srcs):
         build()
     L = C.CDLL(_LIB_PATH)
     L.apt_oracle_freq_hz.restype = C.c_float
