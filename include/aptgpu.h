@@ -37,6 +37,8 @@ extern "C" {
 #define APTGPU_ERR_HIP 3           /* HIP runtime / device failure (Rust shim: Internal) */
 #define APTGPU_ERR_INVALID 4       /* FFI misuse: null pointer, capacity too small, ...  */
 #define APTGPU_ERR_UNSUPPORTED 5   /* reference feature not offered on the GPU path      */
+#define APTGPU_ERR_WAV_OPEN 6      /* err::Error::WavOpen(String)       src/err.rs:14   */
+#define APTGPU_ERR_IO 7            /* err::Error::Io(std::io::Error)    src/err.rs:11   */
 
 /* ---- filters (src/filters.rs:22-46) ------------------------------------ */
 #define APTGPU_FILTER_NOFILTER 0          /* filters::NoFilter          */
@@ -311,7 +313,61 @@ int aptgpu_plan_process_device(aptgpu_plan *plan, int count, const float *const 
 int aptgpu_plan_image_results(aptgpu_plan *plan, int count, aptgpu_image_result *results);
 
 /* ====================================================================== */
-/* 5. misc                                                                 */
+/* 5. WAV ingest in front of decode()                 */
+/* ====================================================================== */
+/* noaa_apt::load / wav::load_wav (src/noaa_apt.rs:114-130, src/wav.rs:11-57): the container is */
+/* walked on the host exactly as hound 3.5.1's WavReader does (Cargo.toml:29), the samples are   */
+/* converted on the GPU: first channel only, integers `as f32`, never scaled (wav.rs:30-51).     */
+
+#define APTGPU_WAV_U8 0    /* 8 bit unsigned (minus 128)              */
+#define APTGPU_WAV_I16 1   /* 16 bit                                  */
+#define APTGPU_WAV_I24 2   /* 24 bit packed                           */
+#define APTGPU_WAV_I24_4 3 /* 24 bit in a 4-byte container            */
+#define APTGPU_WAV_I32 4   /* 32 bit                                  */
+#define APTGPU_WAV_F32 5   /* IEEE float                              */
+
+/* hound::WavSpec (+ where the samples are) */
+typedef struct aptgpu_wav_spec {
+    uint16_t channels;
+    uint16_t bits_per_sample;
+    uint16_t bytes_per_sample; /* block_align / channels */
+    uint16_t sample_format;    /* 0 = hound::SampleFormat::Int, 1 = Float */
+    uint32_t sample_rate;
+    int32_t codec;             /* APTGPU_WAV_* */
+    uint64_t data_offset;      /* payload of the data chunk inside the file image */
+    uint64_t data_len;         /* bytes */
+    uint64_t n_samples;        /* all channels (WavReader::len) */
+    uint64_t n_frames;         /* == length of the Signal load_wav returns */
+} aptgpu_wav_spec;
+
+/* hound::WavReader::new + spec() on an in-memory image of the file (host only, no GPU).
+ * Errors as the reference maps them (src/err.rs:72-83): APTGPU_ERR_WAV_OPEN for malformed or
+ * unsupported files, APTGPU_ERR_IO for a short file, APTGPU_ERR_INTERNAL for too-wide samples. */
+int aptgpu_wav_parse(const void *file_bytes, size_t n, aptgpu_wav_spec *spec, char *err,
+                     size_t err_cap);
+/* wav::load_wav: file image -> (Signal, rate).  *signal_out malloc'd; spec nullable. */
+int aptgpu_load_wav(const aptgpu_context *ctx, const void *file_bytes, size_t n, float **signal_out,
+                    size_t *n_out, uint32_t *sample_rate_hz, aptgpu_wav_spec *spec, char *err,
+                    size_t err_cap);
+/* noaa_apt::load(input_filename): reads the file, then as above. */
+int aptgpu_load_wav_file(const aptgpu_context *ctx, const char *path, float **signal_out,
+                         size_t *n_out, uint32_t *sample_rate_hz, aptgpu_wav_spec *spec, char *err,
+                         size_t err_cap);
+/* load + decode in one call: the data chunk is uploaded as it is (2 bytes per sample for PCM16
+ * instead of 4) and converted in HBM — inside the fused front end for mono PCM16.  Output and
+ * callbacks as aptgpu_decode; *sample_rate_hz (nullable) receives the WAV's rate. */
+int aptgpu_decode_wav(const aptgpu_context *ctx, const aptgpu_settings *settings,
+                      const void *file_bytes, size_t n, int sync, float **rows_out, size_t *n_out,
+                      aptgpu_stats *stats, uint32_t *sample_rate_hz, char *err, size_t err_cap);
+/* Device-resident batch: d_data[i] points at recording i's data-chunk payload in HBM, specs[i]
+ * describes it (sample_rate must equal the plan's input rate).  Otherwise as
+ * aptgpu_plan_decode_device. */
+int aptgpu_plan_decode_device_wav(aptgpu_plan *plan, int count, const void *const *d_data,
+                                  const aptgpu_wav_spec *specs, float *const *d_rows,
+                                  const size_t *rows_cap, char *err, size_t err_cap);
+
+/* ====================================================================== */
+/* 6. misc                                                                 */
 /* ====================================================================== */
 const char *aptgpu_version(void);
 int aptgpu_device_count(void);

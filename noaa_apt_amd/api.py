@@ -45,12 +45,20 @@ class InvalidError(AptError):        # FFI misuse
     code = 4
 
 
+class WavOpenError(AptError):        # err::Error::WavOpen
+    code = 6
+
+
+class IoError(AptError):             # err::Error::Io
+    code = 7
+
+
 class UnsupportedError(AptError):
     code = 5
 
 
 _ERRORS = {c.code: c for c in (InternalError, RateOverflowError, HipError, InvalidError,
-                               UnsupportedError)}
+                               UnsupportedError, WavOpenError, IoError)}
 
 
 def _check(rc, err=None):
@@ -107,6 +115,14 @@ class ImageResult(C.Structure):
                 ("telemetry_quality", C.c_float), ("channel_a", C.c_int32), ("channel_b", C.c_int32),
                 ("reserved", C.c_uint32), ("n_px", C.c_uint64), ("values_a", C.c_float * 16),
                 ("values_b", C.c_float * 16)]
+
+
+class WavSpec(C.Structure):
+    """aptgpu_wav_spec: hound::WavSpec plus where the samples are."""
+    _fields_ = [("channels", C.c_uint16), ("bits_per_sample", C.c_uint16),
+                ("bytes_per_sample", C.c_uint16), ("sample_format", C.c_uint16),
+                ("sample_rate", C.c_uint32), ("codec", C.c_int32), ("data_offset", C.c_uint64),
+                ("data_len", C.c_uint64), ("n_samples", C.c_uint64), ("n_frames", C.c_uint64)]
 
 
 class KernelTime(C.Structure):
@@ -188,6 +204,16 @@ def lib():
     L.aptgpu_find_sync.argtypes = [C.POINTER(_CContext), _f32p, sz, u32, C.POINTER(_u64p),
                                    C.POINTER(sz), C.POINTER(_f32p), C.POINTER(sz), C.c_char_p, sz]
     cp, f = C.POINTER(_CContext), C.c_float
+    wsp = C.POINTER(WavSpec)
+    L.aptgpu_wav_parse.argtypes = [C.c_char_p, sz, wsp, C.c_char_p, sz]
+    L.aptgpu_load_wav.argtypes = [cp, C.c_char_p, sz, C.POINTER(_f32p), C.POINTER(sz), C.POINTER(u32),
+                                  wsp, C.c_char_p, sz]
+    L.aptgpu_load_wav_file.argtypes = [cp, C.c_char_p, C.POINTER(_f32p), C.POINTER(sz), C.POINTER(u32),
+                                       wsp, C.c_char_p, sz]
+    L.aptgpu_decode_wav.argtypes = [cp, C.POINTER(_CSettings), C.c_char_p, sz, i32, C.POINTER(_f32p),
+                                    C.POINTER(sz), C.POINTER(Stats), C.POINTER(u32), C.c_char_p, sz]
+    L.aptgpu_plan_decode_device_wav.argtypes = [vp, i32, C.POINTER(vp), wsp, C.POINTER(vp),
+                                                C.POINTER(sz), C.c_char_p, sz]
     L.aptgpu_get_min.argtypes = [cp, _f32p, sz, _f32p, C.c_char_p, sz]
     L.aptgpu_get_max.argtypes = [cp, _f32p, sz, _f32p, C.c_char_p, sz]
     L.aptgpu_percent.argtypes = [cp, _f32p, sz, f, _f32p, _f32p, C.c_char_p, sz]
@@ -444,6 +470,45 @@ def generate_sync_frame(work_rate: Rate):
     return _take(out, n.value, np.int8)
 
 
+# ------------------------------------------------------------------ WAV ingest
+def wav_parse(file_bytes: bytes) -> WavSpec:
+    """hound::WavReader::new(...).spec() on an in-memory file image (host only)."""
+    spec = WavSpec()
+    err = C.create_string_buffer(_ERRCAP)
+    _check(lib().aptgpu_wav_parse(file_bytes, len(file_bytes), C.byref(spec), err, _ERRCAP), err)
+    return spec
+
+
+def load(input_filename, context=None, return_spec=False):
+    """noaa_apt::load (noaa_apt.rs:114-130): (Signal, Rate).  Also accepts the file's bytes."""
+    cctx = (context or Context())._c()
+    out, n, rate, spec = _f32p(), C.c_size_t(), C.c_uint32(), WavSpec()
+    err = C.create_string_buffer(_ERRCAP)
+    if isinstance(input_filename, (bytes, bytearray, memoryview)):
+        data = bytes(input_filename)
+        _check(lib().aptgpu_load_wav(C.byref(cctx), data, len(data), C.byref(out), C.byref(n),
+                                     C.byref(rate), C.byref(spec), err, _ERRCAP), err)
+    else:
+        _check(lib().aptgpu_load_wav_file(C.byref(cctx), os.fsencode(input_filename), C.byref(out),
+                                          C.byref(n), C.byref(rate), C.byref(spec), err, _ERRCAP), err)
+    res = (_take(out, n.value), Rate.hz(rate.value))
+    return res + (spec,) if return_spec else res
+
+
+def decode_wav(context: Optional[Context], settings: Settings, file_bytes: bytes, sync: bool,
+               return_stats=False):
+    """load() + decode() without the host-side f32 detour: the data chunk goes to the GPU as it
+    is and is converted there (inside the fused front end for mono PCM16)."""
+    cctx = (context or Context())._c()
+    cs = settings._c()
+    out, n, st, rate = _f32p(), C.c_size_t(), Stats(), C.c_uint32()
+    err = C.create_string_buffer(_ERRCAP)
+    _check(lib().aptgpu_decode_wav(C.byref(cctx), C.byref(cs), file_bytes, len(file_bytes), int(sync),
+                                   C.byref(out), C.byref(n), C.byref(st), C.byref(rate), err, _ERRCAP), err)
+    rows = _take(out, n.value)
+    return (rows, st) if return_stats else rows
+
+
 # ------------------------------------------------------------------ consumers of the rows
 class Contrast:
     """noaa_apt::Contrast (noaa_apt.rs:25-37).  Histogram's equalisation is host-side and out
@@ -594,6 +659,15 @@ class Plan:
         cap = (C.c_size_t * k)(*rows_cap)
         err = C.create_string_buffer(_ERRCAP)
         _check(lib().aptgpu_plan_decode_device(self._p, k, sig, nn, rows, cap, err, _ERRCAP), err)
+
+    def decode_device_wav(self, d_data: Sequence[int], specs: Sequence[WavSpec], d_rows: Sequence[int],
+                          rows_cap: Sequence[int]):
+        """As decode_device, but every recording is the payload of a WAV data chunk in HBM."""
+        k = len(d_data)
+        err = C.create_string_buffer(_ERRCAP)
+        _check(lib().aptgpu_plan_decode_device_wav(self._p, k, (C.c_void_p * k)(*d_data),
+                                                   (WavSpec * k)(*specs), (C.c_void_p * k)(*d_rows),
+                                                   (C.c_size_t * k)(*rows_cap), err, _ERRCAP), err)
 
     def process_device(self, d_rows: Sequence[int], rows_cap: Sequence[int], contrast_adjustment,
                        d_images: Sequence[int], rotate=Rotate.NO):

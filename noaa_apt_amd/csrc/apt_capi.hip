@@ -241,14 +241,16 @@ int aptgpu_plan_read_internal(aptgpu_plan *plan, int i, const char *name, void *
 }
 
 // ------------------------------------------------------------------ decode()
-int aptgpu_decode(const aptgpu_context *ctx_in, const aptgpu_settings *settings,
-                  const float *signal, size_t n, uint32_t input_rate_hz, int sync,
-                  float **rows_out, size_t *n_out, aptgpu_stats *stats, char *err, size_t err_cap)
+}  // extern "C"
+
+namespace apt::capi {
+
+// decode() on a host buffer: the f32 Signal, or (wav != nullptr) the payload of a WAV data chunk
+// that is uploaded as it is and converted on the device (wav.rs:30-51).
+int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, const float *signal,
+                const uint8_t *wav_data, const apt::WavInfo *wav, size_t n, uint32_t input_rate_hz, int sync,
+                float **rows_out, size_t *n_out, aptgpu_stats *stats, char *err, size_t err_cap)
 {
-    if (!settings || (!signal && n) || !rows_out || !n_out) {
-        put_err(err, err_cap, "null argument");
-        return APTGPU_ERR_INVALID;
-    }
     *rows_out = nullptr;
     *n_out = 0;
     aptgpu_context ctx = ctx_in ? *ctx_in : default_ctx();
@@ -256,10 +258,10 @@ int aptgpu_decode(const aptgpu_context *ctx_in, const aptgpu_settings *settings,
 
     return guarded(err, err_cap, [&]() -> int {
         const uint32_t work = settings->work_rate;
-        // decode.rs:59
-        step(&ctx, steps, "input", 0, signal, n, input_rate_hz);
+        // decode.rs:59 (a WAV input is exported after its conversion, below)
+        if (!wav) step(&ctx, steps, "input", 0, signal, n, input_rate_hz);
         // decode.rs:63
-        status(&ctx, 0.1f, "Resampling to " + std::to_string(work));
+        if (!wav || !steps) status(&ctx, 0.1f, "Resampling to " + std::to_string(work));
 
         PlanPtr plan(apt::plan_create(&ctx, *settings, input_rate_hz, sync != 0, n, 1));
         if (plan->spr == 0) throw Error{ErrorKind::Invalid, "work_rate too small"};
@@ -267,17 +269,36 @@ int aptgpu_decode(const aptgpu_context *ctx_in, const aptgpu_settings *settings,
         const uint64_t w = plan->work_len_for(n);
 
         apt::DeviceBuffer<float> d_in, d_rows;
-        d_in.alloc(n + 16);
-        apt::hip_check(hipMemcpyAsync(d_in.ptr, signal, n * sizeof(float), hipMemcpyHostToDevice, s),
-                       "hipMemcpyAsync H2D");
+        apt::DeviceBuffer<uint8_t> d_wav;
+        aptgpu_plan::Input in;
+        in.n = n;
+        if (wav) {
+            d_wav.alloc(wav->data_len + 16);
+            apt::hip_check(hipMemcpyAsync(d_wav.ptr, wav_data, wav->data_len, hipMemcpyHostToDevice, s),
+                           "hipMemcpyAsync H2D");
+            in.ptr = d_wav.ptr;
+            in.channels = wav->channels;
+            in.bytes_per_sample = wav->bytes_per_sample;
+            in.codec = static_cast<int>(wav->codec);
+        } else {
+            d_in.alloc(n + 16);
+            apt::hip_check(hipMemcpyAsync(d_in.ptr, signal, n * sizeof(float), hipMemcpyHostToDevice, s),
+                           "hipMemcpyAsync H2D");
+            in.ptr = d_in.ptr;
+        }
         const uint64_t out_cap =
             sync ? static_cast<uint64_t>(plan->max_rows) * 2080u : plan->out_len_nosync(w) + 16;
         d_rows.alloc(out_cap);
 
         plan->begin_call(1);
-        plan->enqueue(0, d_in.ptr, n, d_rows.ptr, out_cap, steps);
+        plan->enqueue(0, in, d_rows.ptr, out_cap, steps);
         aptgpu_plan::Slot &sl = plan->slot_of(0);
         if (steps) plan->sync_all();  // the step exports below read the slot's buffers
+        if (wav && steps) {
+            apt::Signal x = download(sl.ingest.ptr, n, s);
+            step(&ctx, steps, "input", 0, x.data(), x.size(), input_rate_hz);
+            status(&ctx, 0.1f, "Resampling to " + std::to_string(work));
+        }
 
         // dsp.rs:96 / :106 — the resample filter, then the resample steps
         step(&ctx, steps, "resample_filter", 1, plan->taps_resample.data(),
@@ -379,6 +400,22 @@ int aptgpu_decode(const aptgpu_context *ctx_in, const aptgpu_settings *settings,
         }
         return APTGPU_OK;
     });
+}
+
+}  // namespace apt::capi
+
+extern "C" {
+
+int aptgpu_decode(const aptgpu_context *ctx_in, const aptgpu_settings *settings,
+                  const float *signal, size_t n, uint32_t input_rate_hz, int sync,
+                  float **rows_out, size_t *n_out, aptgpu_stats *stats, char *err, size_t err_cap)
+{
+    if (!settings || (!signal && n) || !rows_out || !n_out) {
+        put_err(err, err_cap, "null argument");
+        return APTGPU_ERR_INVALID;
+    }
+    return apt::capi::decode_host(ctx_in, settings, signal, nullptr, nullptr, n, input_rate_hz, sync, rows_out,
+                                  n_out, stats, err, err_cap);
 }
 
 // ------------------------------------------------------------------ building blocks

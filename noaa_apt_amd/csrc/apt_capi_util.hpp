@@ -109,4 +109,9 @@ struct Scratch {
     }
 };
 
+// apt_capi.hip
+int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, const float *signal,
+                const uint8_t *wav_data, const apt::WavInfo *wav, size_t n, uint32_t input_rate_hz, int sync,
+                float **rows_out, size_t *n_out, aptgpu_stats *stats, char *err, size_t err_cap);
+
 }  // namespace apt::capi

@@ -28,7 +28,7 @@ constexpr uint32_t PX_PER_ROW = 2080;   // decode.rs:35
 constexpr uint32_t CARRIER_FREQ = 2400; // decode.rs:38
 constexpr float PI_F32 = 3.14159265358979323846f;
 
-enum class ErrorKind { Internal = 1, RateOverflow = 2, Hip = 3, Invalid = 4, Unsupported = 5 };
+enum class ErrorKind { Internal = 1, RateOverflow = 2, Hip = 3, Invalid = 4, Unsupported = 5, WavOpen = 6, Io = 7 };
 
 // err::Error restricted to the variants the path can produce (err.rs:9-44).
 struct Error {

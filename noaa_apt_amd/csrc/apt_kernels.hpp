@@ -73,8 +73,9 @@ void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, 
 void fused_lowpass_pairs(const float *h2, uint32_t t2, float *h2p);
 // x -> F (filtered work-rate signal) and, if gm_out != nullptr, the per-group maxima of
 // the sync cross-correlation.  Returns false if no specialisation matches.
+// x is the f32 Signal, or (pcm16) mono int16 samples at a 4-byte aligned address.
 bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
-                     const float *x, uint64_t n, const float *hs, const float *h2, const float *h2p,
+                     const void *x, bool pcm16, uint64_t n, const float *hs, const float *h2, const float *h2p,
                      float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out,
                      uint64_t w, uint64_t n_corr);
 
@@ -118,6 +119,12 @@ void image_set_limits(hipStream_t s, void *ws, uint64_t cap, float low, float hi
 // map_signal_u8, noaa_apt.rs:249-259 (+ processing::rotate, processing.rs:21-37)
 void image_map_u8(hipStream_t s, const float *x, const Result *res, uint64_t n, uint64_t cap, void *ws,
                   bool rotate, uint8_t *out, ImageResult *info);
+
+// ---- WAV ingest (apt_kernels_ingest.hip) --------------------------
+// data chunk bytes -> f32 Signal, first channel only, unscaled (wav.rs:30-51); codec is
+// apt::WavCodec as int
+void wav_to_signal(hipStream_t s, const void *d_data, uint64_t n_frames, uint32_t channels,
+                   uint32_t bytes_per_sample, int codec, float *d_signal);
 
 // writes a result record from the host's knowledge (too-short recording, no-sync path)
 void set_result(hipStream_t s, Result *res, Result value);

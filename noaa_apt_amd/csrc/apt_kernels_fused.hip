@@ -106,9 +106,11 @@ __host__ __device__ constexpr bool sync_plus(int j)
     return (((j - pulse) / pulse) & 1) == 1;
 }
 
-template <int L, int M, int T1, int T2, int PW, int NTHR>
+// XT = float: the f32 Signal; XT = int16_t: mono PCM16 straight from the WAV data chunk
+// (`*x as f32`, wav.rs:37), which halves the compulsory input bytes.
+template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT>
 __global__ void __launch_bounds__(NTHR, (APT_FUSED_MIN_WAVES * NTHR + 255) / 256)
-k_fused(const float *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][PS] tap pairs*/,
+k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][PS] tap pairs*/,
         const float *__restrict__ h2 /*[T2]*/, const f2 *__restrict__ h2p /*[T2+1] (h2[m-1], h2[m])*/,
         float cosphi2, float sinphi,
         float *__restrict__ f_out, float *__restrict__ c_out, float *__restrict__ gm_out,
@@ -137,7 +139,7 @@ k_fused(const float *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WI
     const int c_hi = rel(static_cast<int64_t>(n_corr) - k0);      // tile index of position n_corr
 
     // ---- stage 0: input tile -> LDS (coalesced 16-byte loads, zero outside [0, n))
-    {
+    if constexpr (sizeof(XT) == 4) {
         const float *xt = x + xs0;  // only dereferenced inside [x_lo, x_hi)
         for (int q = tid * 4; q < Gm::XT_PAD; q += kFusedThreads * 4) {
             float4 v;
@@ -148,6 +150,26 @@ k_fused(const float *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WI
                 v.y = (q + 1 >= x_lo && q + 1 < x_hi) ? xt[q + 1] : 0.f;
                 v.z = (q + 2 >= x_lo && q + 2 < x_hi) ? xt[q + 2] : 0.f;
                 v.w = (q + 3 >= x_lo && q + 3 < x_hi) ? xt[q + 3] : 0.f;
+            }
+            *reinterpret_cast<float4 *>(P + q) = v;
+        }
+    } else {
+        // PCM16: x is 4-byte aligned and xs0, q are even, so sample pairs load as one dword
+        const int16_t *xt = x + xs0;
+        for (int q = tid * 4; q < Gm::XT_PAD; q += kFusedThreads * 4) {
+            float4 v;
+            if (q >= x_lo && q + 3 < x_hi) {
+                const uint32_t *pp = reinterpret_cast<const uint32_t *>(xt + q);
+                const uint32_t a = pp[0], b = pp[1];
+                v.x = static_cast<float>(static_cast<int16_t>(a & 0xffffu));
+                v.y = static_cast<float>(static_cast<int16_t>(a >> 16));
+                v.z = static_cast<float>(static_cast<int16_t>(b & 0xffffu));
+                v.w = static_cast<float>(static_cast<int16_t>(b >> 16));
+            } else {
+                v.x = (q >= x_lo && q < x_hi) ? static_cast<float>(xt[q]) : 0.f;
+                v.y = (q + 1 >= x_lo && q + 1 < x_hi) ? static_cast<float>(xt[q + 1]) : 0.f;
+                v.z = (q + 2 >= x_lo && q + 2 < x_hi) ? static_cast<float>(xt[q + 2]) : 0.f;
+                v.w = (q + 3 >= x_lo && q + 3 < x_hi) ? static_cast<float>(xt[q + 3]) : 0.f;
             }
             *reinterpret_cast<float4 *>(P + q) = v;
         }
@@ -415,15 +437,15 @@ k_fused(const float *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WI
     }
 }
 
-template <int L, int M, int T1, int T2, int PW, int NTHR>
-void launch_fused(hipStream_t s, const float *x, uint64_t n, const float *hb, const float *h2,
+template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT>
+void launch_fused(hipStream_t s, const XT *x, uint64_t n, const float *hb, const float *h2,
                   const float *h2p, float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w,
                   uint64_t n_corr)
 {
     using Gm = FusedGeom<L, M, T1, T2, PW, NTHR>;
     constexpr int kFusedThreads = NTHR;
     const size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
-    auto kern = k_fused<L, M, T1, T2, PW, NTHR>;
+    auto kern = k_fused<L, M, T1, T2, PW, NTHR, XT>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -491,19 +513,30 @@ void fused_lowpass_pairs(const float *h2, uint32_t t2, float *h2p)
 }
 
 bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
-                     const float *x, uint64_t n, const float *hb, const float *h2, const float *h2p,
+                     const void *x, bool pcm16, uint64_t n, const float *hb, const float *h2, const float *h2p,
                      float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out,
                      uint64_t w, uint64_t n_corr)
 {
+    const float *xf = static_cast<const float *>(x);
+    const int16_t *xi = static_cast<const int16_t *>(x);
+    if (pcm16 && (reinterpret_cast<uintptr_t>(x) & 3u)) return false;  // dword loads of sample pairs
     if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
-        launch_fused<13, 50, 959, 37, 3, 256>(s, x, n, hb, h2, h2p, cosphi2, sinphi, f_out, c_out,
-                                              gm_out, w, n_corr);
+        if (pcm16)
+            launch_fused<13, 50, 959, 37, 3, 256>(s, xi, n, hb, h2, h2p, cosphi2, sinphi, f_out, c_out, gm_out, w,
+                                                  n_corr);
+        else
+            launch_fused<13, 50, 959, 37, 3, 256>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, f_out, c_out, gm_out, w,
+                                                  n_corr);
         return true;
     }
     if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3) {
         // twice the input per work sample: 128-thread workgroups keep the x tile at 51.8 KB
-        launch_fused<13, 100, 1915, 37, 3, 128>(s, x, n, hb, h2, h2p, cosphi2, sinphi, f_out, c_out,
-                                                gm_out, w, n_corr);
+        if (pcm16)
+            launch_fused<13, 100, 1915, 37, 3, 128>(s, xi, n, hb, h2, h2p, cosphi2, sinphi, f_out, c_out, gm_out,
+                                                    w, n_corr);
+        else
+            launch_fused<13, 100, 1915, 37, 3, 128>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, f_out, c_out, gm_out,
+                                                    w, n_corr);
         return true;
     }
     return false;

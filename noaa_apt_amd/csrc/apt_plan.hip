@@ -279,10 +279,10 @@ void aptgpu_plan::sync_all()
     for (hipStream_t st : streams) apt::hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
 }
 
-int aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows,
-                         uint64_t rows_cap_floats, bool keep_steps)
+int aptgpu_plan::enqueue(int i, const Input &in, float *d_rows, uint64_t rows_cap_floats, bool keep_steps)
 {
     using namespace apt::gpu;
+    const uint64_t n = in.n;
     const int slot = static_cast<int>(seq++ % slots.size());
     if (static_cast<size_t>(i) < last_slots.size()) last_slots[static_cast<size_t>(i)] = slot;
     Slot &sl = slots[static_cast<size_t>(slot)];
@@ -306,11 +306,24 @@ int aptgpu_plan::enqueue(int i, const float *d_signal, uint64_t n, float *d_rows
     }
 
     const bool use_fused = fused && !keep_steps;
+    // WAV ingest (wav.rs:30-51): mono PCM16 goes straight into the fused front end, anything
+    // else is converted into the slot's f32 staging buffer first
+    const float *d_signal = static_cast<const float *>(in.ptr);
+    const bool pcm16 = in.codec == static_cast<int>(apt::WavCodec::I16) && in.channels == 1 && use_fused &&
+                       (reinterpret_cast<uintptr_t>(in.ptr) & 3u) == 0;
+    if (in.codec >= 0 && !pcm16) {
+        if (!sl.ingest.ptr) sl.ingest.alloc(max_samples + 16);
+        timed("wav_to_signal", [&] {
+            wav_to_signal(cur, in.ptr, n, in.channels, in.bytes_per_sample, in.codec, sl.ingest.ptr);
+        });
+        d_signal = sl.ingest.ptr;
+    }
     if (use_fused) {
         // 1-3 fused: resample -> envelope -> low-pass in one launch (apt_kernels_fused.hip)
         timed("fused_front_end", [&] {
             fused_front_end(cur, l, m, static_cast<uint32_t>(taps_resample.size()),
-                            static_cast<uint32_t>(taps_lowpass.size()), pw, d_signal, n,
+                            static_cast<uint32_t>(taps_lowpass.size()), pw,
+                            pcm16 ? in.ptr : static_cast<const void *>(d_signal), pcm16, n,
                             d_taps_branch.ptr, d_taps_lowpass.ptr, d_taps_lowpass_pairs.ptr, cosphi2, sinphi,
                             sl.filtered.ptr,
                             (sync && work_is_multiple) ? sl.correlation.ptr : nullptr,

@@ -11,6 +11,7 @@
 #include "../../include/aptgpu.h"
 #include "apt_host.hpp"
 #include "apt_kernels.hpp"
+#include "apt_wav.hpp"
 
 namespace apt {
 
@@ -132,6 +133,7 @@ struct aptgpu_plan {
         apt::DeviceBuffer<uint64_t> words;    // 52-bit terminal words
         apt::DeviceBuffer<uint32_t> slot_nt, slot_cnt, flags, orbit_ws;
         apt::DeviceBuffer<char> image_ws;  // scratch of the image stage, allocated on first use
+        apt::DeviceBuffer<float> ingest;   // WAV -> f32 staging when the fused PCM16 path does not apply
     };
     std::vector<Slot> slots;
     apt::DeviceBuffer<apt::gpu::Result> d_results;
@@ -153,8 +155,24 @@ struct aptgpu_plan {
 
     // enqueue the whole decode() of one device-resident recording (recording `i` of the
     // current call) into the next pipeline slot; returns the slot used
+    // what a recording looks like in HBM: the f32 Signal (codec < 0), or the payload of a WAV
+    // data chunk (codec = apt::WavCodec) that is converted on the device — inside the fused
+    // front end for mono PCM16, through the slot's staging buffer otherwise
+    struct Input {
+        const void *ptr = nullptr;
+        uint64_t n = 0;  // samples of the Signal == WAV frames
+        uint32_t channels = 1, bytes_per_sample = 4;
+        int codec = -1;
+    };
+    int enqueue(int i, const Input &in, float *d_rows, uint64_t rows_cap_floats, bool keep_steps);
     int enqueue(int i, const float *d_signal, uint64_t n, float *d_rows, uint64_t rows_cap_floats,
-                bool keep_steps);
+                bool keep_steps)
+    {
+        Input in;
+        in.ptr = d_signal;
+        in.n = n;
+        return enqueue(i, in, d_rows, rows_cap_floats, keep_steps);
+    }
     void begin_call(int count);     // orders the front-end stream after ctx.stream
     void sync_all();                // waits for both internal streams
     Slot &slot_of(int i) { return slots[static_cast<size_t>(last_slots[static_cast<size_t>(i)])]; }

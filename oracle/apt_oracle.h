@@ -44,6 +44,8 @@ extern "C" {
 #define APT_ORACLE_OK 0
 #define APT_ORACLE_ERR_INTERNAL 1      /* err::Error::Internal(String) */
 #define APT_ORACLE_ERR_RATE_OVERFLOW 2 /* err::Error::RateOverflow(String) */
+#define APT_ORACLE_ERR_WAV_OPEN 6      /* err::Error::WavOpen(String)      */
+#define APT_ORACLE_ERR_IO 7            /* err::Error::Io(std::io::Error)   */
 
 /* filter kinds (src/filters.rs:22-46) */
 #define APT_FILTER_NOFILTER 0
@@ -151,6 +153,16 @@ int apt_oracle_read_telemetry(const float *signal, size_t n, float values_a[16],
 int apt_oracle_process_gray(const float *signal, size_t n, int contrast, float percent,
                             uint8_t **image_out, size_t *n_out, float *low_out, float *high_out,
                             char *err, size_t err_cap);
+
+/* --- WAV ingest (apt_oracle_wav.c) ---------------------------------- */
+typedef struct {
+    uint16_t channels, bits_per_sample, bytes_per_sample, sample_format; /* 0 Int, 1 Float */
+    uint32_t sample_rate;
+    uint64_t data_offset, data_len, n_samples;
+} apt_oracle_wav_spec;
+/* wav::load_wav on an in-memory file image, src/wav.rs:11-57 (+ hound 3.5.1's WavReader) */
+int apt_oracle_load_wav(const uint8_t *bytes, size_t n, float **signal_out, size_t *n_out,
+                        apt_oracle_wav_spec *spec, char *err, size_t err_cap);
 
 void apt_oracle_free(void *p);
 void apt_oracle_free_steps(apt_oracle_steps *s);
