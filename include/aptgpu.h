@@ -366,6 +366,26 @@ int aptgpu_plan_decode_device_wav(aptgpu_plan *plan, int count, const void *cons
                                   const aptgpu_wav_spec *specs, float *const *d_rows,
                                   const size_t *rows_cap, char *err, size_t err_cap);
 
+/* wav::write_wav (src/wav.rs:59-98) for the {1 channel, 16 bit, Int} spec the resample tool
+ * uses (src/resample.rs:53-58): normalise by dsp::get_max, `as i16`; returns the file image
+ * hound's writer produces (44-byte PCM header + samples), malloc'd. */
+int aptgpu_write_wav_i16(const aptgpu_context *ctx, const float *signal, size_t n,
+                         uint32_t sample_rate_hz, void **wav_out, size_t *n_out, char *err,
+                         size_t err_cap);
+/* resample::resample (src/resample.rs:17-71) between file images: load_wav ->
+ * dsp::resample(atten, delta_w) -> write_wav, all on the device; status callbacks at 0.0 / 0.2 /
+ * 0.8 / 1.0 with the reference's texts (output_name, nullable, only appears in the 0.8 text),
+ * "input" step when ctx->step is set.  atten / delta_w_pi_rad are settings.wav_resample_atten /
+ * wav_resample_delta_freq (src/config.rs:100-106). */
+int aptgpu_resample_wav(const aptgpu_context *ctx, const void *file_bytes, size_t n,
+                        uint32_t output_rate_hz, float atten, float delta_w_pi_rad,
+                        const char *output_name, void **wav_out, size_t *n_out, char *err,
+                        size_t err_cap);
+/* The same with file IO on both sides, copying the modification time (misc.rs:181-205). */
+int aptgpu_resample_wav_file(const aptgpu_context *ctx, const char *input_path,
+                             const char *output_path, uint32_t output_rate_hz, float atten,
+                             float delta_w_pi_rad, char *err, size_t err_cap);
+
 /* ====================================================================== */
 /* 6. misc                                                                 */
 /* ====================================================================== */

@@ -13,6 +13,7 @@ Names, argument meaning and error behaviour follow the reference:
     resample_with_filter, resample, demodulate, filter     /root/reference/src/dsp.rs:62,132,350,386
     find_sync, generate_sync_frame                         /root/reference/src/decode.rs:171,204
     load (WAV ingest), decode_wav                          /root/reference/src/noaa_apt.rs:114-130, wav.rs:11-57
+    resample_wav (WAV->WAV tool), write_wav                /root/reference/src/resample.rs:17-71, wav.rs:59-98
     process (grayscale part), Contrast, Rotate             /root/reference/src/noaa_apt.rs:25-60,132-235
     percent, get_min, get_max, map_signal_u8               /root/reference/src/misc.rs:119, dsp.rs:20-54
     read_telemetry, Telemetry                              /root/reference/src/telemetry.rs:19-243
@@ -23,7 +24,7 @@ raise.  (The CPU oracle lives in oracle/ and is test infrastructure only.)
 from .api import (  # noqa: F401
     FINAL_RATE, PX_PER_ROW, CARRIER_FREQ,
     AptError, InternalError, RateOverflowError, HipError, InvalidError, UnsupportedError,
-    WavOpenError, IoError, WavSpec, wav_parse, load, decode_wav,
+    WavOpenError, IoError, WavSpec, wav_parse, load, decode_wav, write_wav, resample_wav,
     Rate, Freq, Settings, Context, Stats,
     NoFilter, Lowpass, LowpassDcRemoval,
     decode, resample_with_filter, resample, demodulate, filter, find_sync, generate_sync_frame,

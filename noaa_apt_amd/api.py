@@ -212,6 +212,10 @@ def lib():
                                        wsp, C.c_char_p, sz]
     L.aptgpu_decode_wav.argtypes = [cp, C.POINTER(_CSettings), C.c_char_p, sz, i32, C.POINTER(_f32p),
                                     C.POINTER(sz), C.POINTER(Stats), C.POINTER(u32), C.c_char_p, sz]
+    L.aptgpu_write_wav_i16.argtypes = [cp, _f32p, sz, u32, C.POINTER(vp), C.POINTER(sz), C.c_char_p, sz]
+    L.aptgpu_resample_wav.argtypes = [cp, C.c_char_p, sz, u32, f, f, C.c_char_p, C.POINTER(vp),
+                                      C.POINTER(sz), C.c_char_p, sz]
+    L.aptgpu_resample_wav_file.argtypes = [cp, C.c_char_p, C.c_char_p, u32, f, f, C.c_char_p, sz]
     L.aptgpu_plan_decode_device_wav.argtypes = [vp, i32, C.POINTER(vp), wsp, C.POINTER(vp),
                                                 C.POINTER(sz), C.c_char_p, sz]
     L.aptgpu_get_min.argtypes = [cp, _f32p, sz, _f32p, C.c_char_p, sz]
@@ -296,15 +300,21 @@ class Settings:
     demodulation_atten: float = 25.0
     export_wav: bool = False
     export_resample_filtered: bool = False
+    # used only by the WAV->WAV resample tool (config.rs:100-106)
+    wav_resample_atten: float = 40.0
+    wav_resample_delta_freq: float = 0.1
 
     @staticmethod
     def profile(name):
         p = {"standard": dict(work_rate=12480, resample_atten=30.0, resample_delta_freq=1000.0,
-                              resample_cutout=4800.0, demodulation_atten=25.0),
+                              resample_cutout=4800.0, demodulation_atten=25.0,
+                              wav_resample_atten=40.0, wav_resample_delta_freq=0.1),
              "fast": dict(work_rate=16640, resample_atten=30.0, resample_delta_freq=3000.0,
-                          resample_cutout=4800.0, demodulation_atten=23.0),
+                          resample_cutout=4800.0, demodulation_atten=23.0,
+                          wav_resample_atten=30.0, wav_resample_delta_freq=0.2),
              "slow": dict(work_rate=20800, resample_atten=40.0, resample_delta_freq=500.0,
-                          resample_cutout=4800.0, demodulation_atten=25.0)}[name]
+                          resample_cutout=4800.0, demodulation_atten=25.0,
+                          wav_resample_atten=50.0, wav_resample_delta_freq=0.05)}[name]
         return Settings(**p)
 
     def _c(self):
@@ -507,6 +517,42 @@ def decode_wav(context: Optional[Context], settings: Settings, file_bytes: bytes
                                    C.byref(out), C.byref(n), C.byref(st), C.byref(rate), err, _ERRCAP), err)
     rows = _take(out, n.value)
     return (rows, st) if return_stats else rows
+
+
+def _take_bytes(ptr, n):
+    out = C.string_at(ptr, n) if n else b""
+    lib().aptgpu_free(ptr)
+    return out
+
+
+def write_wav(signal, sample_rate: Rate, context=None) -> bytes:
+    """wav::write_wav (wav.rs:59-98) with the {1 channel, 16 bit, Int} spec: the file image."""
+    cctx = (context or Context())._c()
+    x, xp = _as_f32(signal)
+    out, n = C.c_void_p(), C.c_size_t()
+    err = C.create_string_buffer(_ERRCAP)
+    _check(lib().aptgpu_write_wav_i16(C.byref(cctx), xp, x.size, sample_rate.get_hz(), C.byref(out),
+                                      C.byref(n), err, _ERRCAP), err)
+    return _take_bytes(out, n.value)
+
+
+def resample_wav(context, settings, input_wav, output_filename, output_rate: int):
+    """resample::resample (resample.rs:17-71).  `input_wav` / `output_filename` are paths (the
+    result is written, modification time copied) — or pass the input file's bytes and get the
+    output file's bytes back (output_filename then only labels the status text)."""
+    cctx = (context or Context())._c()
+    atten, delta = settings.wav_resample_atten, settings.wav_resample_delta_freq
+    err = C.create_string_buffer(_ERRCAP)
+    if isinstance(input_wav, (bytes, bytearray, memoryview)):
+        data = bytes(input_wav)
+        out, n = C.c_void_p(), C.c_size_t()
+        name = os.fsencode(output_filename) if output_filename else None
+        _check(lib().aptgpu_resample_wav(C.byref(cctx), data, len(data), output_rate, atten, delta, name,
+                                         C.byref(out), C.byref(n), err, _ERRCAP), err)
+        return _take_bytes(out, n.value)
+    _check(lib().aptgpu_resample_wav_file(C.byref(cctx), os.fsencode(input_wav), os.fsencode(output_filename),
+                                          output_rate, atten, delta, err, _ERRCAP), err)
+    return None
 
 
 # ------------------------------------------------------------------ consumers of the rows

@@ -477,43 +477,12 @@ int resample_with_filter_impl(const aptgpu_context *ctx, const float *signal, si
 {
     if (out_hz == 0) throw Error{ErrorKind::Internal, "Can't resample to 0Hz"};
     if (in_hz == 0) throw Error{ErrorKind::Invalid, "input_rate is 0"};
-    const apt::Rate in_rate = apt::Rate::hz(in_hz), out_rate = apt::Rate::hz(out_hz);
-    const apt::LM lm = apt::interpolation_factors(in_rate, out_rate);
     Scratch sc(ctx);
-    if (lm.l > 1) {
-        apt::Rate interpolated{};
-        if (!in_rate.checked_mul(lm.l, &interpolated)) {
-            char buf[512];
-            std::snprintf(buf, sizeof buf,
-                          "Can't resample, looks like the sample rates do not have a big\n"
-                          "                divisor in common. input_rate: %u, output_rate: %u, "
-                          "l: %u, m: %u",
-                          in_hz, out_hz, lm.l, lm.m);
-            throw Error{ErrorKind::RateOverflow, buf};
-        }
-        filt.resample(in_rate, interpolated);
-        const apt::Signal coeff = filt.design();
-        const uint64_t w = apt::fast_resampling_len(n, lm.l, lm.m, coeff.size());
-        auto d_x = sc.upload(signal, n);
-        auto d_c = sc.upload(coeff.data(), coeff.size());
-        apt::DeviceBuffer<float> d_y;
-        d_y.alloc(w + 16);
-        apt::gpu::resample_generic(sc.stream, d_x.ptr, n, d_c.ptr,
-                                   static_cast<uint32_t>(coeff.size()), lm.l, lm.m, d_y.ptr, w);
-        *out = sc.download_malloc(d_y.ptr, w);
-        *n_out = w;
-    } else {
-        const apt::Signal coeff = filt.design();
-        const uint64_t w = n / lm.m;
-        auto d_x = sc.upload(signal, n);
-        auto d_c = sc.upload(coeff.data(), coeff.size());
-        apt::DeviceBuffer<float> d_y;
-        d_y.alloc(w + 16);
-        apt::gpu::fir_decimate(sc.stream, d_x.ptr, n, d_c.ptr, static_cast<uint32_t>(coeff.size()),
-                               lm.m, d_y.ptr, w);
-        *out = sc.download_malloc(d_y.ptr, w);
-        *n_out = w;
-    }
+    auto d_x = sc.upload(signal, n);
+    apt::DeviceBuffer<float> d_y;
+    const uint64_t w = resample_device(sc, d_x.ptr, n, in_hz, out_hz, filt, d_y);
+    *out = sc.download_malloc(d_y.ptr, w);
+    *n_out = w;
     return APTGPU_OK;
 }
 

@@ -109,6 +109,44 @@ struct Scratch {
     }
 };
 
+// resample_with_filter (dsp.rs:62-126) on a signal already in HBM; returns the output length
+inline uint64_t resample_device(Scratch &sc, const float *d_x, size_t n, uint32_t in_hz, uint32_t out_hz,
+                                apt::Filter &filt, apt::DeviceBuffer<float> &d_y)
+{
+    if (out_hz == 0) throw Error{ErrorKind::Internal, "Can't resample to 0Hz"};  // dsp.rs:69-71
+    const apt::Rate in_rate = apt::Rate::hz(in_hz), out_rate = apt::Rate::hz(out_hz);
+    const apt::LM lm = apt::interpolation_factors(in_rate, out_rate);
+    uint64_t w;
+    if (lm.l > 1) {
+        apt::Rate interpolated{};
+        if (!in_rate.checked_mul(lm.l, &interpolated)) {
+            char buf[512];
+            std::snprintf(buf, sizeof buf,
+                          "Can't resample, looks like the sample rates do not have a big\n"
+                          "                divisor in common. input_rate: %u, output_rate: %u, "
+                          "l: %u, m: %u",
+                          in_hz, out_hz, lm.l, lm.m);
+            throw Error{ErrorKind::RateOverflow, buf};
+        }
+        filt.resample(in_rate, interpolated);
+        const apt::Signal coeff = filt.design();
+        w = apt::fast_resampling_len(n, lm.l, lm.m, coeff.size());
+        auto d_c = sc.upload(coeff.data(), coeff.size());
+        d_y.alloc(w + 16);
+        apt::gpu::resample_generic(sc.stream, d_x, n, d_c.ptr, static_cast<uint32_t>(coeff.size()), lm.l, lm.m,
+                                   d_y.ptr, w);
+        apt::hip_check(hipStreamSynchronize(sc.stream), "hipStreamSynchronize");  // d_c goes out of scope
+    } else {
+        const apt::Signal coeff = filt.design();
+        w = n / lm.m;
+        auto d_c = sc.upload(coeff.data(), coeff.size());
+        d_y.alloc(w + 16);
+        apt::gpu::fir_decimate(sc.stream, d_x, n, d_c.ptr, static_cast<uint32_t>(coeff.size()), lm.m, d_y.ptr, w);
+        apt::hip_check(hipStreamSynchronize(sc.stream), "hipStreamSynchronize");
+    }
+    return w;
+}
+
 // apt_capi.hip
 int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, const float *signal,
                 const uint8_t *wav_data, const apt::WavInfo *wav, size_t n, uint32_t input_rate_hz, int sync,

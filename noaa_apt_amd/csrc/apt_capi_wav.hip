@@ -1,4 +1,7 @@
 // apt_capi_wav.hip — extern "C" surface of include/aptgpu.h §5: WAV ingest in front of decode().
+#include <fcntl.h>
+#include <sys/stat.h>
+
 #include <cstdio>
 #include <vector>
 
@@ -60,9 +63,162 @@ int load_impl(const aptgpu_context *ctx, const uint8_t *bytes, size_t n, float *
     return APTGPU_OK;
 }
 
+// wav::write_wav (wav.rs:59-98) for the 16-bit Int spec on a signal in HBM: the file image hound's
+// WavWriter produces for {channels: 1, bits_per_sample: 16, Int} — a 16-byte PCMWAVEFORMAT fmt
+// chunk, i.e. the canonical 44-byte header — followed by the normalised samples.
+std::vector<uint8_t> write_wav_i16_device(Scratch &sc, const float *d_signal, uint64_t n, uint32_t rate)
+{
+    if (n == 0) throw Error{ErrorKind::Internal, "Can't get maximum of a zero length vector"};  // wav.rs:70
+    if (2 * n + 36 > 0xFFFFFFFFull) throw Error{ErrorKind::Unsupported, "WAV data chunk would exceed 4 GiB"};
+    apt::DeviceBuffer<char> ws;
+    ws.alloc(apt::gpu::image_ws_bytes(n));
+    apt::DeviceBuffer<apt::gpu::ImageResult> d_info;
+    d_info.alloc(1);
+    apt::gpu::image_begin(sc.stream, d_info.ptr);
+    apt::gpu::image_minmax(sc.stream, d_signal, nullptr, n, n, ws.ptr, d_info.ptr);  // dsp::get_max
+    apt::DeviceBuffer<int16_t> d_q;
+    d_q.alloc(n + 16);
+    apt::gpu::quantize_i16(sc.stream, d_signal, n, apt::gpu::image_ws_pointers(ws.ptr, n).limits, d_q.ptr);
+    std::vector<uint8_t> file(44 + 2 * n);
+    auto put32 = [&](size_t at, uint32_t v) {
+        for (int k = 0; k < 4; ++k) file[at + k] = static_cast<uint8_t>(v >> (8 * k));
+    };
+    auto put16 = [&](size_t at, uint16_t v) {
+        file[at] = static_cast<uint8_t>(v);
+        file[at + 1] = static_cast<uint8_t>(v >> 8);
+    };
+    std::memcpy(&file[0], "RIFF", 4);
+    put32(4, static_cast<uint32_t>(36 + 2 * n));
+    std::memcpy(&file[8], "WAVEfmt ", 8);
+    put32(16, 16);
+    put16(20, 1);  // WAVE_FORMAT_PCM
+    put16(22, 1);  // channels
+    put32(24, rate);
+    put32(28, rate * 2);  // bytes per second
+    put16(32, 2);         // block align
+    put16(34, 16);        // bits per sample
+    std::memcpy(&file[36], "data", 4);
+    put32(40, static_cast<uint32_t>(2 * n));
+    apt::hip_check(hipMemcpyAsync(&file[44], d_q.ptr, 2 * n, hipMemcpyDeviceToHost, sc.stream), "hipMemcpyAsync D2H");
+    apt::hip_check(hipStreamSynchronize(sc.stream), "hipStreamSynchronize");
+    return file;
+}
+
+void *to_malloc(const std::vector<uint8_t> &v)
+{
+    uint8_t *p = host_alloc<uint8_t>(v.size());
+    std::memcpy(p, v.data(), v.size());
+    return p;
+}
+
+// resample::resample (resample.rs:17-71) between file images
+std::vector<uint8_t> resample_wav_impl(const aptgpu_context *ctx, const uint8_t *bytes, size_t n,
+                                       uint32_t output_rate, float atten, float delta_w_pi_rad,
+                                       const char *output_name, bool reading_announced)
+{
+    if (!reading_announced) status(ctx, 0.0f, "Reading WAV file");  // resample.rs:25
+    const apt::WavInfo w = apt::parse_wav(bytes, n);
+    Scratch sc(ctx);
+    apt::DeviceBuffer<uint8_t> d_raw;
+    d_raw.alloc(w.data_len + 16);
+    if (w.data_len)
+        apt::hip_check(hipMemcpyAsync(d_raw.ptr, bytes + w.data_offset, w.data_len, hipMemcpyHostToDevice,
+                                      sc.stream),
+                       "hipMemcpyAsync H2D");
+    apt::DeviceBuffer<float> d_sig;
+    d_sig.alloc(w.n_frames + 16);
+    apt::gpu::wav_to_signal(sc.stream, d_raw.ptr, w.n_frames, w.channels, w.bytes_per_sample,
+                            static_cast<int>(w.codec), d_sig.ptr);
+    if (ctx && ctx->step) {  // resample.rs:31
+        float *x = sc.download_malloc(d_sig.ptr, w.n_frames);
+        const int rc = ctx->step("input", 0, x, w.n_frames, w.sample_rate, ctx->user);
+        std::free(x);
+        if (rc != 0) throw Error{ErrorKind::Internal, "step callback failed at \"input\""};
+    }
+    status(ctx, 0.2f, "Resampling to " + std::to_string(output_rate));  // resample.rs:34
+    if (w.sample_rate == 0) throw Error{ErrorKind::Invalid, "input_rate is 0"};
+    // dsp::resample, dsp.rs:132-162
+    const apt::Rate in_rate = apt::Rate::hz(w.sample_rate);
+    const apt::Freq cutout = output_rate > w.sample_rate
+                                 ? apt::Freq::hz(static_cast<float>(w.sample_rate) / 2.f, in_rate)
+                                 : apt::Freq::hz(static_cast<float>(output_rate) / 2.f, in_rate);
+    apt::Lowpass f(cutout, atten, apt::Freq::pi_rad(delta_w_pi_rad));
+    apt::DeviceBuffer<float> d_y;
+    const uint64_t n_res = resample_device(sc, d_sig.ptr, w.n_frames, w.sample_rate, output_rate, f, d_y);
+    if (n_res == 0)  // resample.rs:45-51
+        throw Error{ErrorKind::Internal,
+                    "Got zero samples after resampling, audio file too short or output sampling frequency too low"};
+    status(ctx, 0.8f, std::string("Writing WAV to '") + (output_name ? output_name : "") + "'");  // resample.rs:61
+    std::vector<uint8_t> out = write_wav_i16_device(sc, d_y.ptr, n_res, output_rate);
+    return out;
+}
+
 }  // namespace
 
 extern "C" {
+
+int aptgpu_write_wav_i16(const aptgpu_context *ctx, const float *signal, size_t n, uint32_t sample_rate_hz,
+                         void **wav_out, size_t *n_out, char *err, size_t err_cap)
+{
+    if ((!signal && n) || !wav_out || !n_out) return APTGPU_ERR_INVALID;
+    *wav_out = nullptr;
+    *n_out = 0;
+    return guarded(err, err_cap, [&] {
+        Scratch sc(ctx);
+        auto d_x = sc.upload(signal, n);
+        const std::vector<uint8_t> file = write_wav_i16_device(sc, d_x.ptr, n, sample_rate_hz);
+        *wav_out = to_malloc(file);
+        *n_out = file.size();
+        return APTGPU_OK;
+    });
+}
+
+int aptgpu_resample_wav(const aptgpu_context *ctx, const void *file_bytes, size_t n, uint32_t output_rate_hz,
+                        float atten, float delta_w_pi_rad, const char *output_name, void **wav_out,
+                        size_t *n_out, char *err, size_t err_cap)
+{
+    if ((!file_bytes && n) || !wav_out || !n_out) return APTGPU_ERR_INVALID;
+    *wav_out = nullptr;
+    *n_out = 0;
+    return guarded(err, err_cap, [&] {
+        const std::vector<uint8_t> file = resample_wav_impl(ctx, static_cast<const uint8_t *>(file_bytes), n,
+                                                            output_rate_hz, atten, delta_w_pi_rad, output_name, false);
+        *wav_out = to_malloc(file);
+        *n_out = file.size();
+        status(ctx, 1.f, "Finished");  // resample.rs:69
+        return APTGPU_OK;
+    });
+}
+
+int aptgpu_resample_wav_file(const aptgpu_context *ctx, const char *input_path, const char *output_path,
+                             uint32_t output_rate_hz, float atten, float delta_w_pi_rad, char *err,
+                             size_t err_cap)
+{
+    if (!input_path || !output_path) return APTGPU_ERR_INVALID;
+    return guarded(err, err_cap, [&] {
+        status(ctx, 0.0f, "Reading WAV file");
+        const std::vector<uint8_t> in = read_file(input_path);
+        struct stat st {};
+        if (::stat(input_path, &st) != 0)  // misc::read_timestamp, misc.rs:181-194
+            throw Error{ErrorKind::Internal, "Could not read metadata from input file: stat failed"};
+        const std::vector<uint8_t> out = resample_wav_impl(ctx, in.data(), in.size(), output_rate_hz, atten,
+                                                           delta_w_pi_rad, output_path, true);
+        std::FILE *f = std::fopen(output_path, "wb");
+        if (!f) throw Error{ErrorKind::Io, std::string("could not create ") + output_path};
+        const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+        if (std::fclose(f) != 0 || !ok) throw Error{ErrorKind::Io, std::string("write error on ") + output_path};
+        // misc::write_timestamp, misc.rs:200-205: modification time, whole seconds
+        struct timespec ts[2];
+        ts[0].tv_sec = st.st_atime;
+        ts[0].tv_nsec = 0;
+        ts[1].tv_sec = st.st_mtime;
+        ts[1].tv_nsec = 0;
+        if (::utimensat(AT_FDCWD, output_path, ts, 0) != 0)
+            throw Error{ErrorKind::Internal, "Could not write timestamp to file"};
+        status(ctx, 1.f, "Finished");  // resample.rs:69
+        return APTGPU_OK;
+    });
+}
 
 int aptgpu_wav_parse(const void *file_bytes, size_t n, aptgpu_wav_spec *spec, char *err, size_t err_cap)
 {

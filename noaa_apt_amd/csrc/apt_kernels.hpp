@@ -126,6 +126,9 @@ void image_map_u8(hipStream_t s, const float *x, const Result *res, uint64_t n, 
 void wav_to_signal(hipStream_t s, const void *d_data, uint64_t n_frames, uint32_t channels,
                    uint32_t bytes_per_sample, int codec, float *d_signal);
 
+// wav::write_wav, 16-bit branch (wav.rs:83-86): normalise by d_limits[1] (get_max) -> i16
+void quantize_i16(hipStream_t s, const float *d_x, uint64_t n, const float *d_limits, int16_t *d_out);
+
 // writes a result record from the host's knowledge (too-short recording, no-sync path)
 void set_result(hipStream_t s, Result *res, Result value);
 

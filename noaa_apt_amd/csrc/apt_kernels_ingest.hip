@@ -68,7 +68,34 @@ __global__ __launch_bounds__(kThreads) void k_wav_pcm16_mono(const uint32_t *__r
     for (uint64_t i = q; i < n_frames; i++) out[i] = static_cast<float>(static_cast<int16_t>(h[i]));
 }
 
+// wav::write_wav's 16-bit branch (wav.rs:83-86): (sample / max * 32767.) as i16 — Rust's
+// float -> int cast truncates toward zero, saturates, and maps NaN to 0.  max = limits[1].
+__global__ __launch_bounds__(kThreads) void k_quantize_i16(const float *__restrict__ x, uint64_t n,
+                                                           const float *limits, int16_t *__restrict__ out)
+{
+    const float mx = limits[1];
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kThreads;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
+        const float v = x[i] / mx * 32767.f;
+        int q;
+        if (v != v) q = 0;
+        else if (v >= 32767.f) q = 32767;
+        else if (v <= -32768.f) q = -32768;
+        else q = static_cast<int>(v);  // truncation
+        out[i] = static_cast<int16_t>(q);
+    }
+}
+
 }  // namespace
+
+void quantize_i16(hipStream_t s, const float *d_x, uint64_t n, const float *d_limits, int16_t *d_out)
+{
+    if (n == 0) return;
+    uint64_t blocks = (n + kThreads * 4 - 1) / (kThreads * 4);
+    if (blocks > (1u << 20)) blocks = 1u << 20;
+    hipLaunchKernelGGL(k_quantize_i16, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, s, d_x, n, d_limits,
+                       d_out);
+}
 
 void wav_to_signal(hipStream_t s, const void *d_data, uint64_t n_frames, uint32_t channels,
                    uint32_t bytes_per_sample, int codec, float *d_signal)

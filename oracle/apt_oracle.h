@@ -164,6 +164,10 @@ typedef struct {
 int apt_oracle_load_wav(const uint8_t *bytes, size_t n, float **signal_out, size_t *n_out,
                         apt_oracle_wav_spec *spec, char *err, size_t err_cap);
 
+/* wav::write_wav for the 16-bit Int spec, src/wav.rs:59-98 */
+int apt_oracle_write_wav_i16(const float *signal, size_t n, uint32_t rate, uint8_t **out, size_t *n_out,
+                             char *err, size_t err_cap);
+
 void apt_oracle_free(void *p);
 void apt_oracle_free_steps(apt_oracle_steps *s);
 

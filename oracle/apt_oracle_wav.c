@@ -215,3 +215,44 @@ int apt_oracle_load_wav(const uint8_t *bytes, size_t n, float **signal_out, size
     *n_out = k;
     return APT_ORACLE_OK;
 }
+
+/* wav::write_wav, src/wav.rs:59-98, for the {channels: 1, bits_per_sample: 16, Int} spec that
+ * resample::resample uses (src/resample.rs:53-58): `(sample / max * 32767.) as i16` with
+ * max = dsp::get_max(signal) (wav.rs:70,83-86; Rust's float->int `as` truncates, saturates, NaN->0),
+ * behind the header hound 3.5.1's WavWriter emits for such a spec (PCMWAVEFORMAT, 16-byte fmt
+ * chunk: the canonical 44-byte header). */
+int apt_oracle_write_wav_i16(const float *signal, size_t n, uint32_t rate, uint8_t **out, size_t *n_out,
+                             char *err, size_t err_cap)
+{
+    float max;
+    int rc = apt_oracle_get_max(signal, n, &max, err, err_cap);
+    if (rc) return rc;
+    uint8_t *f = malloc(44 + 2 * n);
+    uint32_t data_len = (uint32_t)(2 * n), riff_len = 36 + data_len, byte_rate = rate * 2;
+    memcpy(f, "RIFF", 4);
+    memcpy(f + 4, &riff_len, 4); /* little-endian host */
+    memcpy(f + 8, "WAVEfmt ", 8);
+    uint32_t sixteen = 16;
+    uint16_t pcm = 1, ch = 1, align = 2, bits = 16;
+    memcpy(f + 16, &sixteen, 4);
+    memcpy(f + 20, &pcm, 2);
+    memcpy(f + 22, &ch, 2);
+    memcpy(f + 24, &rate, 4);
+    memcpy(f + 28, &byte_rate, 4);
+    memcpy(f + 32, &align, 2);
+    memcpy(f + 34, &bits, 2);
+    memcpy(f + 36, "data", 4);
+    memcpy(f + 40, &data_len, 4);
+    for (size_t i = 0; i < n; i++) {
+        const float v = signal[i] / max * 32767.f;
+        int16_t q;
+        if (v != v) q = 0;
+        else if (v >= 32767.f) q = 32767;
+        else if (v <= -32768.f) q = -32768;
+        else q = (int16_t)v;
+        memcpy(f + 44 + 2 * i, &q, 2);
+    }
+    *out = f;
+    *n_out = 44 + 2 * n;
+    return APT_ORACLE_OK;
+}

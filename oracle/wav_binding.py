@@ -28,6 +28,10 @@ def lib():
         L.apt_oracle_load_wav.restype = C.c_int
         L.apt_oracle_load_wav.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_float)),
                                           C.POINTER(C.c_size_t), C.POINTER(WavSpec), C.c_char_p, C.c_size_t]
+        L.apt_oracle_write_wav_i16.restype = C.c_int
+        L.apt_oracle_write_wav_i16.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_uint32,
+                                               C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t),
+                                               C.c_char_p, C.c_size_t]
         _ready = True
     return L
 
@@ -40,3 +44,24 @@ def load_wav(file_bytes: bytes):
     if rc != 0:
         raise _b.OracleError(rc, err.value.decode())
     return _b._take(out, n.value), spec
+
+
+def write_wav_i16(signal, rate) -> bytes:
+    """wav::write_wav with the resample tool's spec: the file image."""
+    a, p = _b._as_f32(signal)
+    out, n = C.POINTER(C.c_uint8)(), C.c_size_t()
+    err = C.create_string_buffer(512)
+    rc = lib().apt_oracle_write_wav_i16(p, a.size, rate, C.byref(out), C.byref(n), err, 512)
+    if rc != 0:
+        raise _b.OracleError(rc, err.value.decode())
+    return _b._take(out, n.value, np.uint8).tobytes()
+
+
+def resample_wav(file_bytes: bytes, output_rate, atten, delta_w_pi_rad) -> bytes:
+    """resample::resample (resample.rs:17-71) between file images."""
+    sig, spec = load_wav(file_bytes)
+    res = _b.resample(sig, spec.sample_rate, output_rate, atten, delta_w_pi_rad)
+    if res.size == 0:
+        raise _b.OracleError(1, "Got zero samples after resampling, audio file too short or output "
+                                "sampling frequency too low")
+    return write_wav_i16(res, output_rate)

@@ -188,3 +188,60 @@ def test_plan_decode_device_wav_batch(oracle, ow):
         bad = apt.wav_parse(make_wav(np.zeros(100, np.int16), 44100))
         plan.decode_device_wav([d_data[0]], [bad], [d_rows[0].data_ptr()], [cap])
     plan.close()
+
+
+# ------------------------------------------------------------------ write_wav / resample tool (N4)
+def test_write_wav_matches_oracle(ow):
+    rng = np.random.default_rng(21)
+    cases = {
+        "normal": (rng.standard_normal(100_003) * 900).astype(f32),
+        "with_nan": np.concatenate([[1.0], [np.nan] * 3, rng.standard_normal(50)]).astype(f32),
+        "negative_peak": np.array([1.0, -3.0, 0.5, -0.99999], f32),
+        "all_negative": np.array([-1.0, -3.0, -0.5], f32),     # max < 0: signs flip, as in the reference
+        "zeros": np.zeros(17, f32),                             # 0/0 = NaN -> 0
+        "one": np.array([42.0], f32),
+    }
+    for name, x in cases.items():
+        assert apt.write_wav(x, apt.Rate.hz(6000)) == ow.write_wav_i16(x, 6000), name
+    with pytest.raises(apt.InternalError, match="maximum of a zero length vector"):
+        apt.write_wav(np.zeros(0, f32), apt.Rate.hz(6000))
+
+
+# test/test.sh:48-52 of the reference: up-sampling, down-sampling, pure decimation
+@pytest.mark.parametrize("in_rate,out_rate", [(11025, 48000), (11025, 6000), (11025, 3675),
+                                              (48000, 80000), (48000, 11025)])
+@pytest.mark.parametrize("profile", ["standard", "fast"])
+def test_resample_wav_tool(ow, in_rate, out_rate, profile):
+    x = synth_apt(in_rate, 6, seed=out_rate % 97)
+    data = make_wav(_pcm16(x), in_rate)
+    s = apt.Settings.profile(profile)
+    status, steps = [], {}
+    c = apt.Context(ui_callback=lambda p, t: status.append((round(p, 2), t)),
+                    step_callback=lambda ident, variant, arr, rate: steps.setdefault(ident, (arr, rate)))
+    got = apt.resample_wav(c, s, data, "out.wav", out_rate)
+    want = ow.resample_wav(data, out_rate, s.wav_resample_atten, s.wav_resample_delta_freq)
+    assert got == want
+    assert status == [(0.0, "Reading WAV file"), (0.2, f"Resampling to {out_rate}"),
+                      (0.8, "Writing WAV to 'out.wav'"), (1.0, "Finished")]
+    assert _same(steps["input"][0], ow.load_wav(data)[0]) and steps["input"][1] == in_rate
+
+
+def test_resample_wav_files_and_errors(ow, tmp_path):
+    import os
+    x = synth_apt(11025, 4, seed=9)
+    src, dst = tmp_path / "in.wav", tmp_path / "out.wav"
+    src.write_bytes(make_wav(_pcm16(x), 11025))
+    os.utime(src, (1_500_000_000, 1_545_511_181))
+    s = apt.Settings()
+    apt.resample_wav(None, s, str(src), str(dst), 20800)
+    assert dst.read_bytes() == ow.resample_wav(src.read_bytes(), 20800, s.wav_resample_atten,
+                                               s.wav_resample_delta_freq)
+    assert int(os.stat(dst).st_mtime) == 1_545_511_181       # misc::write_timestamp
+    with pytest.raises(apt.InternalError, match="Can't resample to 0Hz"):
+        apt.resample_wav(None, s, src.read_bytes(), None, 0)
+    with pytest.raises(apt.InternalError, match="Got zero samples after resampling"):
+        apt.resample_wav(None, s, make_wav(np.zeros(3, np.int16), 48000), None, 4160)
+    with pytest.raises(apt.RateOverflowError):
+        apt.resample_wav(None, s, make_wav(np.zeros(1000, np.int16), 99371), None, 93911)
+    with pytest.raises(apt.IoError):
+        apt.resample_wav(None, s, str(tmp_path / "nope.wav"), str(dst), 8000)

@@ -181,3 +181,34 @@ def test_missing_fmt_chunk():
     for fn, exc in ((ow.load_wav, OracleError), (apt.wav_parse, apt.WavOpenError)):
         with pytest.raises(exc, match="missing fmt chunk"):
             fn(data)
+
+
+# ------------------------------------------------------------------ write_wav (oracle)
+def test_write_wav_oracle_vs_numpy_and_wave_reader():
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal(5001) * 900).astype(f32)
+    x[7] = np.nan
+    data = ow.write_wav_i16(x, 6000)
+    with wave.open(io.BytesIO(data), "rb") as r:
+        assert (r.getnchannels(), r.getsampwidth(), r.getframerate(), r.getnframes()) == (1, 2, 6000, 5001)
+        got = np.frombuffer(r.readframes(5001), "<i2")
+    mx = np.nanmax(x)  # x[0] is not NaN, so get_max skips the NaN
+    with np.errstate(invalid="ignore"):
+        v = x / f32(mx) * f32(32767.)
+    want = np.where(np.isnan(v), 0, np.clip(np.trunc(v), -32768, 32767)).astype(np.int16)
+    assert np.array_equal(got, want)
+    assert len(data) == 44 + 2 * 5001 and data[:4] == b"RIFF" and data[36:40] == b"data"
+    # the product's parser reads the oracle's writer back
+    spec = apt.wav_parse(data)
+    assert (spec.channels, spec.bits_per_sample, spec.sample_rate, spec.n_frames) == (1, 16, 6000, 5001)
+
+
+def test_write_wav_negative_peak_saturates():
+    x = np.array([1.0, -3.0, 0.5, -0.99999], f32)  # max = 1: -3 -> -98301 -> saturates
+    got = np.frombuffer(ow.write_wav_i16(x, 8000)[44:], "<i2")
+    assert got.tolist() == [32767, -32768, 16383, -32766]
+
+
+def test_write_wav_empty():
+    with pytest.raises(OracleError, match="maximum of a zero length vector"):
+        ow.write_wav_i16(np.zeros(0, f32), 8000)
