@@ -105,6 +105,8 @@ struct ImageWsPointers {
     float *mean_a, *mean_b, *variance, *corr, *quality;
 };
 ImageWsPointers image_ws_pointers(void *ws, uint64_t max_px);
+// resets the record; image_minmax / image_percent / image_telemetry do it themselves, so this is
+// only needed in front of a bare image_set_limits + image_map_u8
 void image_begin(hipStream_t s, ImageResult *out);
 // dsp::get_min / get_max, dsp.rs:20-54 -> limits
 void image_minmax(hipStream_t s, const float *x, const Result *res, uint64_t n, uint64_t cap, void *ws,

@@ -40,8 +40,6 @@ struct Extreme {
     unsigned long long i;
 };
 
-// dsp::get_max / get_min (dsp.rs:20-54): strict comparison keeps the FIRST of equal values
-// (matters for the sign of zero); NaN never wins a comparison.
 __device__ inline bool beats_max(float v, unsigned long long i, const Extreme &b)
 {
     return v > b.v || (v == b.v && i < b.i);
@@ -59,7 +57,7 @@ __device__ inline Extreme shfl_extreme(Extreme e, int delta)
     return o;
 }
 
-// block reduction of a (max, min) pair; result valid in thread 0
+// block reduction of a (max, min) pair with lowest-index ties; result valid in thread 0
 __device__ inline void block_extremes(Extreme &mx, Extreme &mn)
 {
     __shared__ Extreme s_mx[kThreads / 64], s_mn[kThreads / 64];
@@ -82,40 +80,93 @@ __device__ inline void block_extremes(Extreme &mx, Extreme &mn)
     }
 }
 
-__global__ __launch_bounds__(kThreads) void k_minmax_partial(const float *__restrict__ x,
-                                                             const Result *res, uint64_t n_host,
-                                                             uint64_t cap, Extreme *partial)
+// dsp::get_max / get_min (dsp.rs:20-54).  The strict comparisons keep the FIRST of equal
+// values, which only shows when the extreme is zero (+0.0 == -0.0 with different bits), and a
+// NaN never wins a comparison.  So the reduction carries plain max/min values plus the index of
+// the first zero-valued element, whose sign the result takes when the extreme is zero.
+struct Range {
+    float mx, mn;
+    unsigned long long zero;  // lowest index with x == 0, ~0 if none
+};
+
+__device__ inline void range_take(Range &r, float v, unsigned long long i)
 {
-    const uint64_t n = px_count(res, n_host, cap);
-    Extreme mx{-INFINITY, ~0ull}, mn{INFINITY, ~0ull};
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kThreads;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride) {
-        const float v = x[i];
-        if (beats_max(v, i, mx)) mx = Extreme{v, i};
-        if (beats_min(v, i, mn)) mn = Extreme{v, i};
-    }
-    block_extremes(mx, mn);
-    if (threadIdx.x == 0) {
-        partial[2 * blockIdx.x] = mx;
-        partial[2 * blockIdx.x + 1] = mn;
-    }
+    r.mx = v > r.mx ? v : r.mx;
+    r.mn = v < r.mn ? v : r.mn;
+    if (v == 0.f && i < r.zero) r.zero = i;
 }
 
-// limits[0] = min, limits[1] = max; also clears the histogram for the pass that follows
-__global__ __launch_bounds__(kThreads) void k_minmax_final(const float *__restrict__ x, const Result *res,
-                                                           uint64_t n_host, uint64_t cap,
-                                                           const Extreme *partial, int n_partial,
-                                                           float *limits, uint32_t *counts, ImageResult *out)
+__device__ inline void range_merge(Range &r, const Range &o)
+{
+    r.mx = o.mx > r.mx ? o.mx : r.mx;
+    r.mn = o.mn < r.mn ? o.mn : r.mn;
+    r.zero = o.zero < r.zero ? o.zero : r.zero;
+}
+
+// result valid in thread 0
+__device__ inline void block_range(Range &r)
+{
+    __shared__ Range s_r[kThreads / 64];
+    for (int d = 32; d >= 1; d >>= 1) {
+        Range o;
+        o.mx = __shfl_down(r.mx, d);
+        o.mn = __shfl_down(r.mn, d);
+        o.zero = __shfl_down(r.zero, d);
+        range_merge(r, o);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_r[wave] = r;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < kThreads / 64; w++) range_merge(r, s_r[w]);
+}
+
+__global__ __launch_bounds__(kThreads) void k_minmax_partial(const float *__restrict__ x,
+                                                             const Result *res, uint64_t n_host,
+                                                             uint64_t cap, Range *partial, uint32_t *counts,
+                                                             ImageResult *out)
 {
     const uint64_t n = px_count(res, n_host, cap);
-    Extreme mx{-INFINITY, ~0ull}, mn{INFINITY, ~0ull};
-    for (int k = threadIdx.x; k < n_partial; k += kThreads) {
-        const Extreme a = partial[2 * k], b = partial[2 * k + 1];
-        if (beats_max(a.v, a.i, mx)) mx = a;
-        if (beats_min(b.v, b.i, mn)) mn = b;
+    if (blockIdx.x == 0) {
+        // first kernel of the stage: fresh record, empty histogram
+        if (threadIdx.x == 0) {
+            ImageResult z{};
+            z.channel_a = z.channel_b = -1;
+            *out = z;
+        }
+        for (int b = threadIdx.x; b < kBuckets; b += kThreads) counts[b] = 0;
     }
-    block_extremes(mx, mn);
-    for (int b = threadIdx.x; b < kBuckets; b += kThreads) counts[b] = 0;
+    Range r{-INFINITY, INFINITY, ~0ull};
+    const uint64_t gtid = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kThreads;
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+        const uint64_t n4 = n / 4;
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        for (uint64_t q = gtid; q < n4; q += stride) {
+            const float4 v = x4[q];
+            range_take(r, v.x, 4 * q);
+            range_take(r, v.y, 4 * q + 1);
+            range_take(r, v.z, 4 * q + 2);
+            range_take(r, v.w, 4 * q + 3);
+        }
+        for (uint64_t i = 4 * n4 + gtid; i < n; i += stride) range_take(r, x[i], i);
+    } else {
+        for (uint64_t i = gtid; i < n; i += stride) range_take(r, x[i], i);
+    }
+    block_range(r);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// limits[0] = min, limits[1] = max
+__global__ __launch_bounds__(kThreads) void k_minmax_final(const float *__restrict__ x, const Result *res,
+                                                           uint64_t n_host, uint64_t cap,
+                                                           const Range *partial, int n_partial,
+                                                           float *limits, ImageResult *out)
+{
+    const uint64_t n = px_count(res, n_host, cap);
+    Range r{-INFINITY, INFINITY, ~0ull};
+    for (int k = threadIdx.x; k < n_partial; k += kThreads) range_merge(r, partial[k]);
+    block_range(r);
     if (threadIdx.x == 0) {
         if (n == 0) {
             // "Can't get minimum of a zero length vector" (dsp.rs:40-44; get_min is called first
@@ -124,12 +175,14 @@ __global__ __launch_bounds__(kThreads) void k_minmax_final(const float *__restri
             out->reason = (res && res->status != 0) ? 4 : 1;
             limits[0] = limits[1] = 0.f;
         } else {
-            // `best = x[0]`: a NaN first element is never replaced; otherwise x[0] takes part in
-            // the reduction like every other element (ties -> lowest index, i.e. x[0] itself)
+            // `best = x[0]`: a NaN first element is never replaced
             const float x0 = x[0];
             const bool nan0 = x0 != x0;
-            limits[0] = nan0 ? x0 : (mn.i == ~0ull ? x0 : mn.v);
-            limits[1] = nan0 ? x0 : (mx.i == ~0ull ? x0 : mx.v);
+            float mn = r.mn, mx = r.mx;
+            if (mn == 0.f) mn = x[r.zero];  // the first zero's sign
+            if (mx == 0.f) mx = x[r.zero];
+            limits[0] = nan0 ? x0 : mn;
+            limits[1] = nan0 ? x0 : mx;
         }
     }
 }
@@ -152,41 +205,101 @@ __global__ __launch_bounds__(kThreads) void k_histogram(const float *__restrict_
     __syncthreads();
     const float mn = limits[0];
     const float range = limits[1] - limits[0];  // misc.rs:137
+    const uint64_t gtid = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kThreads;
-    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x; i < n; i += stride)
-        atomicAdd(&s_counts[bucket_of(x[i], mn, range)], 1u);
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) {
+        const uint64_t n4 = n / 4;
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        for (uint64_t q = gtid; q < n4; q += stride) {
+            const float4 v = x4[q];
+            atomicAdd(&s_counts[bucket_of(v.x, mn, range)], 1u);
+            atomicAdd(&s_counts[bucket_of(v.y, mn, range)], 1u);
+            atomicAdd(&s_counts[bucket_of(v.z, mn, range)], 1u);
+            atomicAdd(&s_counts[bucket_of(v.w, mn, range)], 1u);
+        }
+        for (uint64_t i = 4 * n4 + gtid; i < n; i += stride) atomicAdd(&s_counts[bucket_of(x[i], mn, range)], 1u);
+    } else {
+        for (uint64_t i = gtid; i < n; i += stride) atomicAdd(&s_counts[bucket_of(x[i], mn, range)], 1u);
+    }
     __syncthreads();
     for (int b = threadIdx.x; b < kBuckets; b += kThreads)
         if (s_counts[b]) atomicAdd(&counts[b], s_counts[b]);
 }
 
-// the bucket scan of misc::percent (misc.rs:152-174); one thread, 1000 steps
-__global__ void k_percent_final(const Result *res, uint64_t n_host, uint64_t cap, float percent,
-                                const uint32_t *counts, float *limits, ImageResult *out)
+// The bucket scan of misc::percent (misc.rs:152-174) as a block-wide prefix sum.  With
+// frac_b = accum_b as f32 / len as f32 (monotone in b) the sequential loop's result is
+//   low  = first b with frac_b > remainder
+//   high = first b != low with frac_b > 1 - remainder   (the `else if` skips b == low; for
+//          b < low the second test cannot hold because remainder <= 0.5), else 999.
+// The integer prefix sums are exact, the float compare is the reference's own expression.
+__global__ __launch_bounds__(kThreads) void k_percent_final(const Result *res, uint64_t n_host, uint64_t cap,
+                                                            float percent, const uint32_t *counts,
+                                                            float *limits, ImageResult *out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    __shared__ uint32_t s_wave[kThreads / 64];
+    __shared__ int s_low[kThreads / 64], s_high[kThreads / 64], s_first[2];
     const uint64_t n = px_count(res, n_host, cap);
     if (n == 0) return;  // k_minmax_final has reported it
-    const float remainder = (1.f - percent) / 2.f;
-    const float mn = limits[0];
-    const float total_range = limits[1] - limits[0];
-    uint32_t accum = 0;
-    int low_bucket = -1, high_bucket = -1;
-    const float len = static_cast<float>(n);
-    for (int b = 0; b < kBuckets; b++) {
-        accum += counts[b];
-        const float frac = static_cast<float>(accum) / len;
-        if (low_bucket < 0 && frac > remainder)
-            low_bucket = b;
-        else if (high_bucket < 0 && frac > 1.f - remainder)
-            high_bucket = b;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // 4 consecutive buckets per thread
+    uint32_t c[4], run = 0;
+    for (int k = 0; k < 4; k++) {
+        const int b = tid * 4 + k;
+        c[k] = b < kBuckets ? counts[b] : 0u;
+        run += c[k];
     }
-    if (high_bucket < 0) high_bucket = kBuckets - 1;
-    if (low_bucket < 0) {  // low_bucket.unwrap() panics in the reference (NaN-only input)
+    uint32_t incl = run;  // inclusive scan of the per-thread sums
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - run;
+    for (int w = 0; w < wave; w++) base += s_wave[w];
+    const float remainder = (1.f - percent) / 2.f;
+    const float len = static_cast<float>(n);
+    int low = kBuckets, high_a = kBuckets;  // first b above remainder / above 1-remainder
+    uint32_t accum = base;
+    for (int k = 0; k < 4; k++) {
+        const int b = tid * 4 + k;
+        if (b >= kBuckets) break;
+        accum += c[k];
+        const float frac = static_cast<float>(accum) / len;
+        if (frac > remainder && low == kBuckets) low = b;
+        if (frac > 1.f - remainder && high_a == kBuckets) high_a = b;
+    }
+    // block minima
+    for (int d = 32; d >= 1; d >>= 1) {
+        low = min(low, __shfl_down(low, d));
+        high_a = min(high_a, __shfl_down(high_a, d));
+    }
+    if (lane == 0) {
+        s_low[wave] = low;
+        s_high[wave] = high_a;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kThreads / 64; w++) {
+            low = min(low, s_low[w]);
+            high_a = min(high_a, s_high[w]);
+        }
+        s_first[0] = low;
+        s_first[1] = high_a;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    int low_bucket = s_first[0], high_bucket = s_first[1];
+    // `else if`: the bucket that set low cannot also set high; the next one can (frac is monotone)
+    if (high_bucket == low_bucket && high_bucket < kBuckets) high_bucket = high_bucket + 1 < kBuckets ? high_bucket + 1 : kBuckets;
+    if (high_bucket >= kBuckets) high_bucket = kBuckets - 1;  // misc.rs:165-169
+    if (low_bucket >= kBuckets) {  // low_bucket.unwrap() panics in the reference (NaN-only input)
         out->status = 1;
         out->reason = 3;
         return;
     }
+    const float mn = limits[0];
+    const float total_range = limits[1] - limits[0];
     limits[0] = static_cast<float>(low_bucket) / 1000.f * total_range + mn;
     limits[1] = static_cast<float>(high_bucket) / 1000.f * total_range + mn;
 }
@@ -252,10 +365,15 @@ __global__ __launch_bounds__(kThreads) void k_map_u8(const float *__restrict__ x
 // per-row band statistics, telemetry.rs:154-177: one thread per row, sequential sums
 __global__ __launch_bounds__(kThreads) void k_telemetry_rows(const float *__restrict__ x, const Result *res,
                                                              uint64_t n_host, uint64_t cap, float *mean_a,
-                                                             float *mean_b, float *variance)
+                                                             float *mean_b, float *variance, ImageResult *out)
 {
     const uint64_t rows = px_count(res, n_host, cap) / kPx;
     const uint64_t r = static_cast<uint64_t>(blockIdx.x) * kThreads + threadIdx.x;
+    if (r == 0) {  // first kernel of the stage: fresh record
+        ImageResult z{};
+        z.channel_a = z.channel_b = -1;
+        *out = z;
+    }
     if (r >= rows) return;
     const float *a = x + r * kPx + 994;
     const float *b = x + r * kPx + 2034;
@@ -418,13 +536,13 @@ inline unsigned blocks_for(uint64_t n, unsigned per_block, unsigned max_blocks)
 size_t image_ws_bytes(uint64_t max_px)
 {
     const uint64_t rows = max_px / kPx + 1;
-    return 2 * kMinMaxBlocks * sizeof(Extreme) + 2 * sizeof(float) + kBuckets * sizeof(uint32_t) +
+    return kMinMaxBlocks * sizeof(Range) + 4 * sizeof(float) + kBuckets * sizeof(uint32_t) +
            5 * rows * sizeof(float) + 64;
 }
 
 namespace {
 struct WsView {
-    Extreme *partial;
+    Range *partial;
     float *limits;
     uint32_t *counts;
     float *mean_a, *mean_b, *variance, *corr, *quality;
@@ -434,8 +552,8 @@ inline WsView carve(void *ws, uint64_t max_px)
     const uint64_t rows = max_px / kPx + 1;
     WsView v;
     char *p = static_cast<char *>(ws);
-    v.partial = reinterpret_cast<Extreme *>(p);
-    p += 2 * kMinMaxBlocks * sizeof(Extreme);
+    v.partial = reinterpret_cast<Range *>(p);
+    p += kMinMaxBlocks * sizeof(Range);
     v.limits = reinterpret_cast<float *>(p);
     p += 4 * sizeof(float);
     v.counts = reinterpret_cast<uint32_t *>(p);
@@ -464,10 +582,11 @@ void image_minmax(hipStream_t s, const float *x, const Result *res, uint64_t n, 
                   ImageResult *out)
 {
     const WsView v = carve(ws, cap);
-    const unsigned nb = blocks_for(cap, kThreads * 8, kMinMaxBlocks);
-    hipLaunchKernelGGL(k_minmax_partial, dim3(nb), dim3(kThreads), 0, s, x, res, n, cap, v.partial);
+    const unsigned nb = blocks_for(cap, kThreads * 16, kMinMaxBlocks);
+    hipLaunchKernelGGL(k_minmax_partial, dim3(nb), dim3(kThreads), 0, s, x, res, n, cap, v.partial, v.counts,
+                       out);
     hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(kThreads), 0, s, x, res, n, cap, v.partial,
-                       static_cast<int>(nb), v.limits, v.counts, out);
+                       static_cast<int>(nb), v.limits, out);
 }
 
 void image_percent(hipStream_t s, const float *x, const Result *res, uint64_t n, uint64_t cap, float percent,
@@ -475,10 +594,11 @@ void image_percent(hipStream_t s, const float *x, const Result *res, uint64_t n,
 {
     const WsView v = carve(ws, cap);
     image_minmax(s, x, res, n, cap, ws, out);
-    const unsigned nb = blocks_for(cap, kThreads * 16, 1024);
+    // few, fat workgroups: every one ends with up to 1000 same-address global atomics
+    const unsigned nb = blocks_for(cap, kThreads * 64, 128);
     hipLaunchKernelGGL(k_histogram, dim3(nb), dim3(kThreads), 0, s, x, res, n, cap, v.limits, v.counts);
-    hipLaunchKernelGGL(k_percent_final, dim3(1), dim3(64), 0, s, res, n, cap, percent, v.counts, v.limits,
-                       out);
+    hipLaunchKernelGGL(k_percent_final, dim3(1), dim3(kThreads), 0, s, res, n, cap, percent, v.counts,
+                       v.limits, out);
 }
 
 void image_telemetry(hipStream_t s, const float *x, const Result *res, uint64_t n, uint64_t cap, void *ws,
@@ -487,7 +607,7 @@ void image_telemetry(hipStream_t s, const float *x, const Result *res, uint64_t 
     const WsView v = carve(ws, cap);
     const uint64_t rows = cap / kPx;
     hipLaunchKernelGGL(k_telemetry_rows, dim3(blocks_for(rows, kThreads, 1u << 20)), dim3(kThreads), 0, s, x,
-                       res, n, cap, v.mean_a, v.mean_b, v.variance);
+                       res, n, cap, v.mean_a, v.mean_b, v.variance, out);
     hipLaunchKernelGGL(k_telemetry_corr, dim3(blocks_for(rows, kThreads, 1u << 20)), dim3(kThreads), 0, s,
                        res, n, cap, v.mean_a, v.mean_b, v.variance, v.corr, v.quality);
     hipLaunchKernelGGL(k_telemetry_best, dim3(1), dim3(kThreads), 0, s, res, n, cap, v.mean_a, v.mean_b,

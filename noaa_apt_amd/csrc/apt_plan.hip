@@ -438,7 +438,7 @@ void aptgpu_plan::enqueue_image(int i, const float *d_rows, uint64_t rows_cap_fl
         launch();
         timer.end(cur);
     };
-    image_begin(cur, out);
+    // (the first kernel of every variant resets the record)
     if (contrast == APTGPU_CONTRAST_TELEMETRY)
         timed("image_telemetry", [&] { image_telemetry(cur, d_rows, res, 0, cap, ws, out, true); });
     else if (contrast == APTGPU_CONTRAST_PERCENT)
