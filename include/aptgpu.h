@@ -101,7 +101,8 @@ typedef struct aptgpu_stats {
     uint64_t n_rows;        /* image rows returned                              */
     uint32_t l, m;          /* interpolation / decimation factors dsp.rs:73-75  */
     uint32_t n_resample_taps, n_lowpass_taps;
-    int32_t fused;          /* 1 if the fused specialised kernel ran            */
+    int32_t fused;          /* front end used: 0 unfused generic kernels, 1 compile-time
+                               specialised fused kernel, 2 run-time fused kernel */
     int32_t orbit_path;     /* peak-picker path: 0 doubling (LDS), 1 bitmask walk */
 } aptgpu_stats;
 
@@ -143,7 +144,7 @@ typedef struct aptgpu_plan_info {
     uint64_t max_samples;          /* capacity the plan was created for                  */
     uint64_t max_work_len;         /* work-rate samples at max_samples                   */
     uint64_t max_rows;             /* upper bound on rows for max_samples                */
-    int32_t fused;                 /* fused specialised kernels available                */
+    int32_t fused;                 /* front end: 0 unfused, 1 specialised fused, 2 run-time fused */
     int32_t max_batch;
 } aptgpu_plan_info;
 

@@ -92,7 +92,7 @@ int aptgpu_plan_get_info(const aptgpu_plan *plan, aptgpu_plan_info *info)
     info->max_samples = plan->max_samples;
     info->max_work_len = plan->max_work_len;
     info->max_rows = plan->max_rows;
-    info->fused = plan->fused ? 1 : 0;
+    info->fused = plan->fused;
     info->max_batch = plan->max_batch;
     return APTGPU_OK;
 }
@@ -395,7 +395,7 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
             stats->m = plan->m;
             stats->n_resample_taps = static_cast<uint32_t>(plan->taps_resample.size());
             stats->n_lowpass_taps = static_cast<uint32_t>(plan->taps_lowpass.size());
-            stats->fused = plan->fused ? 1 : 0;
+            stats->fused = plan->fused;
             stats->orbit_path = 1;
         }
         return APTGPU_OK;

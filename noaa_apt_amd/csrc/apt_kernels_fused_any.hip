@@ -1,0 +1,422 @@
+// apt_kernels_fused_any.hip — fused front end for ANY (input rate, profile): resample ->
+// envelope -> low-pass -> sync correlation (+ group maxima) in one launch, all run-time
+// parameters.  Used when no compile-time specialisation of k_fused (apt_kernels_fused.hip)
+// matches: 11 025 Hz (L = 832) and 44 100 Hz (L = 208) recordings, the fast / slow profiles,
+// odd rates.  Same outputs, same bit-exact arithmetic (separately rounded products and sums in
+// the reference's order); about 2x the instructions of the specialised kernel because nothing
+// is packed or unrolled against compile-time tap positions.
+//
+// One workgroup = one tile of KT = NTHR*KPT work samples:
+//
+//   tile index:   0 ......... PRE ........................ PRE+OWN ....... KT
+//                 | history    | owned: F, C, GM go to HBM  | look-ahead   |
+//                 | (low-pass) |                            | (sync frame) |
+//
+//   stage 0  polyphase table (phase-major, row stride odd -> conflict-free) and the input
+//            tile -> LDS, coalesced
+//   stage 1  R[k] = sum_i coeff[p + i*l] * x[x0 + i]      (dsp.rs:252-263), one output per
+//            thread and step, taps and samples from LDS
+//   stage 2  D[k] = envelope(R[k-1], R[k])                (dsp.rs:369-377)
+//   stage 3  F[k] = sum_{j<T2} D[k-j] * h[j]              (dsp.rs:396-404), KPT consecutive
+//            outputs per thread: a sliding register window cuts LDS reads per tap to 1/KPT
+//   stage 4  C[k] = sum_{j<G} +-F[k+j]                    (decode.rs:225-233), same blocking
+//   stage 5  owned F and C -> HBM (coalesced), GM[g] = max of C over 52 positions
+//
+// Why zero-filling is exact: a running sum that starts at +0.0 can never be -0.0 (x + y is
+// -0.0 only if both are), so adding the +-0.0 product of a zero-filled sample (inputs at or
+// past n, which the reference skips, dsp.rs:257; D[k <= 0], which the `i > j` guard of
+// dsp.rs:399 excludes and which is 0.0 anyway) leaves every bit unchanged.
+#include "apt_kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace apt::gpu {
+
+namespace {
+
+constexpr int kGS = 52;  // correlation positions per group (apt_kernels_sync.hip)
+constexpr float kNegInfAny = -__builtin_huge_valf();
+
+struct AnyGeom {
+    uint32_t l, m, jlim;   // resampler: factors, taps the reference uses (2*off + 1)
+    uint32_t tpp;          // row stride of the phase-major table (>= taps per phase, odd)
+    uint32_t t2;           // low-pass taps
+    uint32_t g, pulse;     // sync frame length 38*pw and pulse width 2*pw
+    uint32_t kt, pre, own; // tile geometry (work samples)
+    uint32_t xt;           // input tile, floats (multiple of 4)
+    uint32_t off_x, off_a, off_b;  // LDS offsets in floats (table at 0)
+    uint32_t step_q, step_r;       // (NTHR*m) / l and % l: x0 / phase update between a thread's outputs
+    uint32_t jl_a, jl_b;           // jlim / l and % l: taps of phase p = jl_a + (p < jl_b)
+    uint64_t sign[4];              // bit j set <=> sync template[j] = +1 (decode.rs:188-198)
+};
+
+__device__ __forceinline__ float envelope(float prev, float curr, float cosphi2, float sinphi)
+{
+    const float a = prev * prev + curr * curr;
+    const float b = prev * curr * cosphi2;
+    return __builtin_sqrtf(a - b) / sinphi;  // IEEE sqrt and divide (see the Makefile flags)
+}
+
+template <int NTHR, int KPT, typename XT>
+__global__ void __launch_bounds__(NTHR)
+k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ table /*[l][tpp]*/,
+            const float *__restrict__ h2, float cosphi2, float sinphi, float *__restrict__ f_out,
+            float *__restrict__ c_out, float *__restrict__ gm_out, uint64_t w, uint64_t n_corr, AnyGeom G)
+{
+    extern __shared__ float lds[];
+    float *T = lds;
+    float *X = lds + G.off_x;
+    float *A = lds + G.off_a;  // R, then F
+    float *B = lds + G.off_b;  // D, then C
+    const int tid = threadIdx.x;
+    const int64_t o0 = static_cast<int64_t>(blockIdx.x) * G.own;  // first owned work sample
+    const int64_t t0 = o0 - G.pre;                                // work sample at tile index 0
+    const int64_t kb = t0 > 0 ? t0 : 0;                           // first work sample that exists
+    const int idx0 = static_cast<int>(kb - t0);
+    // kb*m = X0*l + rb; the tile's first input sample, rounded down to a 16-byte boundary
+    const uint64_t kbm = static_cast<uint64_t>(kb) * G.m;
+    const uint64_t X0 = kbm / G.l;
+    const uint32_t rb = static_cast<uint32_t>(kbm - X0 * G.l);
+    const uint64_t xfirst = X0 + (rb ? 1 : 0);
+    const uint64_t xs0 = xfirst & ~3ull;
+    const uint32_t xrel0 = static_cast<uint32_t>(X0 - xs0);  // may wrap by -1..: used only with ceil >= 1 or rb == 0
+
+    // ---- stage 0
+    for (uint32_t q = tid; q < G.l * G.tpp; q += NTHR) T[q] = table[q];
+    if constexpr (sizeof(XT) == 4) {
+        const float *xf = reinterpret_cast<const float *>(x);
+        if ((reinterpret_cast<uintptr_t>(xf) & 15u) == 0) {
+            for (uint32_t q = tid * 4; q < G.xt; q += NTHR * 4) {
+                const uint64_t i = xs0 + q;
+                float4 v;
+                if (i + 3 < n) {
+                    v = *reinterpret_cast<const float4 *>(xf + i);
+                } else {
+                    v.x = i < n ? xf[i] : 0.f;
+                    v.y = i + 1 < n ? xf[i + 1] : 0.f;
+                    v.z = i + 2 < n ? xf[i + 2] : 0.f;
+                    v.w = i + 3 < n ? xf[i + 3] : 0.f;
+                }
+                *reinterpret_cast<float4 *>(X + q) = v;
+            }
+        } else {
+            for (uint32_t q = tid; q < G.xt; q += NTHR) X[q] = xs0 + q < n ? xf[xs0 + q] : 0.f;
+        }
+    } else {
+        // mono PCM16 payload (wav.rs:37: `*x as f32`)
+        for (uint32_t q = tid; q < G.xt; q += NTHR) X[q] = xs0 + q < n ? static_cast<float>(x[xs0 + q]) : 0.f;
+    }
+    __syncthreads();
+
+    // ---- stage 1: one output per thread and step, consecutive lanes = consecutive outputs.
+    // k*m - X0*l = v;  x0 - X0 = c = ceil(v / l);  phase p = c*l - v.  One division for the
+    // thread's first output, then v += NTHR*m is  c += step_q (+1),  p -= step_r (+l).
+    {
+        uint32_t c = 0, p = 0;
+        bool primed = false;
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = tid + i * NTHR;
+            const int64_t k = t0 + idx;
+            float sum = 0.f;
+            if (idx >= idx0) {
+                if (!primed) {
+                    const uint32_t v = rb + static_cast<uint32_t>(idx - idx0) * G.m;
+                    c = (v + G.l - 1) / G.l;
+                    p = c * G.l - v;
+                    primed = true;
+                } else {
+                    c += G.step_q;
+                    if (p >= G.step_r) {
+                        p -= G.step_r;
+                    } else {
+                        p += G.l - G.step_r;
+                        c += 1;
+                    }
+                }
+                if (k < static_cast<int64_t>(w)) {
+                    const uint32_t cnt = G.jl_a + (p < G.jl_b ? 1u : 0u);
+                    const float *row = T + p * G.tpp;
+                    const float *xs = X + (xrel0 + c);
+                    for (uint32_t j = 0; j < cnt; ++j) sum = sum + row[j] * xs[j];
+                }
+            }
+            A[idx] = sum;
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 2
+    for (int i = 0; i < KPT; ++i) {
+        const int idx = tid + i * NTHR;
+        const int64_t k = t0 + idx;
+        float d = 0.f;
+        if (idx > 0 && k > 0 && k < static_cast<int64_t>(w)) d = envelope(A[idx - 1], A[idx], cosphi2, sinphi);
+        B[idx] = d;
+    }
+    __syncthreads();
+
+    // ---- stage 3: KPT consecutive outputs per thread, taps ascending, window in registers
+    {
+        const int b0 = static_cast<int>(G.pre) + tid * KPT;
+        if (b0 < static_cast<int>(G.kt)) {
+            float acc[KPT];
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) acc[u] = 0.f;
+            for (uint32_t j0 = 0; j0 < G.t2; j0 += KPT) {
+                // 2*KPT floats from a 16-byte aligned address (b0, j0 and KPT are multiples of 4)
+                float win[2 * KPT];
+                const float4 *src = reinterpret_cast<const float4 *>(B + (b0 - static_cast<int>(j0) - KPT));
+#pragma unroll
+                for (int e = 0; e < 2 * KPT / 4; ++e) {
+                    const float4 v = src[e];
+                    win[4 * e] = v.x;
+                    win[4 * e + 1] = v.y;
+                    win[4 * e + 2] = v.z;
+                    win[4 * e + 3] = v.w;
+                }
+#pragma unroll
+                for (int jj = 0; jj < KPT; ++jj) {
+                    if (j0 + jj < G.t2) {
+                        const float hj = h2[j0 + jj];
+#pragma unroll
+                        for (int u = 0; u < KPT; ++u) acc[u] = acc[u] + win[KPT + u - jj] * hj;
+                    }
+                }
+            }
+            // A (R) was last read in stage 2, before the barrier above: safe to overwrite with F
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) A[b0 + u] = acc[u];
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 5a: owned F -> HBM
+    for (uint32_t q = tid * 4; q < G.own; q += NTHR * 4) {
+        const uint64_t k = static_cast<uint64_t>(o0) + q;
+        const float *src = A + G.pre + q;
+        if (k + 3 < w) {
+            *reinterpret_cast<float4 *>(f_out + k) = *reinterpret_cast<const float4 *>(src);
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (k + e < w) f_out[k + e] = src[e];
+        }
+    }
+    if (gm_out == nullptr) return;  // no sync search wanted
+
+    // ---- stage 4: +-1 correlation, KPT consecutive outputs per thread
+    {
+        const int b0 = static_cast<int>(G.pre) + tid * KPT;
+        if (b0 < static_cast<int>(G.pre + G.own)) {
+            float acc[KPT];
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) acc[u] = 0.f;
+            for (uint32_t j0 = 0; j0 < G.g; j0 += KPT) {
+                float win[2 * KPT];
+                const float4 *src = reinterpret_cast<const float4 *>(A + (b0 + static_cast<int>(j0)));
+#pragma unroll
+                for (int e = 0; e < 2 * KPT / 4; ++e) {
+                    const float4 v = src[e];
+                    win[4 * e] = v.x;
+                    win[4 * e + 1] = v.y;
+                    win[4 * e + 2] = v.z;
+                    win[4 * e + 3] = v.w;
+                }
+                const uint64_t signs = G.sign[j0 >> 6] >> (j0 & 63);  // KPT divides 64: no straddling
+#pragma unroll
+                for (int jj = 0; jj < KPT; ++jj) {
+                    const uint32_t j = j0 + jj;
+                    if (j < G.g) {
+                        const bool plus = (signs >> jj) & 1;  // wave-uniform
+                        if (plus) {
+#pragma unroll
+                            for (int u = 0; u < KPT; ++u) acc[u] = acc[u] + win[u + jj];
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < KPT; ++u) acc[u] = acc[u] - win[u + jj];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) B[b0 + u] = acc[u];
+        }
+    }
+    __syncthreads();
+
+    // ---- stage 5b: owned C -> HBM, group maxima
+    for (uint32_t q = tid * 4; q < G.own; q += NTHR * 4) {
+        const uint64_t k = static_cast<uint64_t>(o0) + q;
+        const float *src = B + G.pre + q;
+        if (k + 3 < n_corr) {
+            *reinterpret_cast<float4 *>(c_out + k) = *reinterpret_cast<const float4 *>(src);
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (k + e < n_corr) c_out[k + e] = src[e];
+        }
+    }
+    for (uint32_t g = tid; g < G.own / kGS; g += NTHR) {
+        const uint64_t k = static_cast<uint64_t>(o0) + static_cast<uint64_t>(g) * kGS;
+        if (k >= n_corr) break;
+        const float *src = B + G.pre + g * kGS;
+        float mx = kNegInfAny;
+        for (int o = 0; o < kGS; ++o) {
+            if (k + o < n_corr) {
+                float v = src[o];
+                if (k + o == 0 && !(v > 0.f)) v = 0.f;  // the picker starts from the peak (0, 0.)
+                mx = fmaxf(mx, v);
+            }
+        }
+        gm_out[static_cast<uint64_t>(o0) / kGS + g] = mx;
+    }
+}
+
+constexpr size_t kLdsLimit = 160 * 1024;
+
+struct Candidate {
+    int nthr, kpt;
+};
+// most resident waves per CU first (LDS permitting), then the larger tile
+constexpr Candidate kCandidates[] = {{256, 8}, {512, 8}, {1024, 8}, {1024, 4}};
+
+bool make_geom(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, int nthr, int kpt, AnyGeom *out,
+               size_t *lds_bytes)
+{
+    AnyGeom g{};
+    g.l = l;
+    g.m = m;
+    g.jlim = 2 * ((t1 - 1) / 2) + 1;
+    const uint32_t per_phase = (g.jlim + l - 1) / l;
+    g.tpp = per_phase | 1u;  // odd stride: rows of consecutive phases start in different banks
+    g.t2 = t2;
+    g.g = 38 * pw;
+    g.pulse = 2 * pw;
+    g.kt = static_cast<uint32_t>(nthr * kpt);
+    if (38 * pw > 256) return false;  // sign bitmap
+    g.pre = (t2 + 2 * static_cast<uint32_t>(kpt) + 3u) & ~3u;
+    if (g.kt < g.pre + g.g + kGS) return false;
+    g.own = (g.kt - g.pre - (g.g - 1)) / kGS * kGS;
+    if (g.own == 0) return false;
+    g.xt = (static_cast<uint32_t>((static_cast<uint64_t>(g.kt) * m + l - 1) / l) + per_phase + 8 + 3) & ~3u;
+    const uint32_t slack = 64;
+    g.off_x = (l * g.tpp + 3u) & ~3u;
+    g.off_a = g.off_x + g.xt;
+    g.off_b = g.off_a + g.kt + slack;
+    g.step_q = static_cast<uint32_t>((static_cast<uint64_t>(nthr) * m) / l);
+    g.step_r = static_cast<uint32_t>((static_cast<uint64_t>(nthr) * m) % l);
+    g.jl_a = g.jlim / l;
+    g.jl_b = g.jlim % l;
+    for (uint32_t j = 0; j < g.g; ++j) {
+        const bool plus = j >= g.pulse && j < 15 * g.pulse && (((j - g.pulse) / g.pulse) & 1) == 1;
+        if (plus) g.sign[j >> 6] |= 1ull << (j & 63);
+    }
+    const size_t floats = static_cast<size_t>(g.off_b) + g.kt + slack;
+    *lds_bytes = floats * sizeof(float);
+    *out = g;
+    return *lds_bytes <= kLdsLimit;
+}
+
+// picks the launch shape: maximise resident waves per CU, then tile size
+bool choose(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, Candidate *best, AnyGeom *geom,
+            size_t *lds)
+{
+    int best_score = 0;
+    uint32_t best_kt = 0;
+    bool found = false;
+    for (const Candidate &c : kCandidates) {
+        AnyGeom g;
+        size_t bytes;
+        if (!make_geom(l, m, t1, t2, pw, c.nthr, c.kpt, &g, &bytes)) continue;
+        int wgs = static_cast<int>(kLdsLimit / bytes);
+        int waves = wgs * (c.nthr / 64);
+        if (waves > 32) waves = 32;  // 8 per SIMD is plenty
+        // tile efficiency matters too: weight by the owned fraction
+        const int score = waves * 1000 + static_cast<int>(1000.0 * g.own / g.kt);
+        if (!found || score > best_score || (score == best_score && g.kt > best_kt)) {
+            best_score = score;
+            best_kt = g.kt;
+            *best = c;
+            *geom = g;
+            *lds = bytes;
+            found = true;
+        }
+    }
+    return found;
+}
+
+template <int NTHR, int KPT, typename XT>
+void launch_any(hipStream_t s, const XT *x, uint64_t n, const float *table, const float *h2, float cosphi2,
+                float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w, uint64_t n_corr,
+                const AnyGeom &g, size_t lds)
+{
+    auto kern = k_fused_any<NTHR, KPT, XT>;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds && lds > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds));
+        attr_lds = lds;
+    }
+    const unsigned tiles = static_cast<unsigned>((w + g.own - 1) / g.own);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHR), lds, s, x, n, table, h2, cosphi2, sinphi, f_out, c_out,
+                       gm_out, w, n_corr, g);
+}
+
+}  // namespace
+
+bool fused_any_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
+{
+    if (l == 0 || m == 0 || t1 == 0 || t2 == 0 || pw == 0) return false;
+    // 32-bit in-tile index math: (tile outputs) * m + l must stay far below 2^32
+    if (static_cast<uint64_t>(8192 + 4096) * m + l > 0x7fffffffull) return false;
+    Candidate c;
+    AnyGeom g;
+    size_t lds;
+    return choose(l, m, t1, t2, pw, &c, &g, &lds);
+}
+
+uint32_t fused_any_table_floats(uint32_t l, uint32_t t1)
+{
+    const uint32_t jlim = 2 * ((t1 - 1) / 2) + 1;
+    return l * (((jlim + l - 1) / l) | 1u);
+}
+
+// host: phase-major table [l][tpp], row p = coeff[p], coeff[p + l], ... (zero padded)
+void fused_any_table(uint32_t l, const float *coeff, uint32_t t1, float *table)
+{
+    const uint32_t jlim = 2 * ((t1 - 1) / 2) + 1;
+    const uint32_t tpp = ((jlim + l - 1) / l) | 1u;
+    for (uint32_t p = 0; p < l; ++p)
+        for (uint32_t i = 0; i < tpp; ++i) {
+            const uint64_t j = p + static_cast<uint64_t>(i) * l;
+            table[static_cast<size_t>(p) * tpp + i] = j < jlim ? coeff[j] : 0.f;
+        }
+}
+
+bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
+                         const void *x, bool pcm16, uint64_t n, const float *table, const float *h2,
+                         float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w,
+                         uint64_t n_corr)
+{
+    Candidate c;
+    AnyGeom g;
+    size_t lds;
+    if (!choose(l, m, t1, t2, pw, &c, &g, &lds)) return false;
+    if (pcm16 && (reinterpret_cast<uintptr_t>(x) & 1u)) return false;
+    const float *xf = static_cast<const float *>(x);
+    const int16_t *xi = static_cast<const int16_t *>(x);
+#define APT_ANY_CASE(NT, KP)                                                                                   \
+    if (c.nthr == NT && c.kpt == KP) {                                                                         \
+        if (pcm16)                                                                                             \
+            launch_any<NT, KP>(s, xi, n, table, h2, cosphi2, sinphi, f_out, c_out, gm_out, w, n_corr, g, lds); \
+        else                                                                                                   \
+            launch_any<NT, KP>(s, xf, n, table, h2, cosphi2, sinphi, f_out, c_out, gm_out, w, n_corr, g, lds); \
+        return true;                                                                                           \
+    }
+    APT_ANY_CASE(256, 8)
+    APT_ANY_CASE(512, 8)
+    APT_ANY_CASE(1024, 8)
+    APT_ANY_CASE(1024, 4)
+#undef APT_ANY_CASE
+    return false;
+}
+
+}  // namespace apt::gpu

@@ -193,10 +193,17 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     upload(plan->d_taps_resample, plan->taps_resample);
     upload(plan->d_taps_lowpass, plan->taps_lowpass);
     upload(plan->d_one, Signal{1.f});
-    plan->fused = plan->mode == APTGPU_MODE_STRICT && plan->l > 1 &&
-                  gpu::fused_supported(plan->l, plan->m, static_cast<uint32_t>(plan->taps_resample.size()),
-                                       static_cast<uint32_t>(plan->taps_lowpass.size()), plan->pw) &&
-                  plan->work_is_multiple;
+    {
+        const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
+        const uint32_t t2 = static_cast<uint32_t>(plan->taps_lowpass.size());
+        const bool eligible = plan->mode == APTGPU_MODE_STRICT && plan->l > 1 && plan->work_is_multiple;
+        const char *force_any = std::getenv("APTGPU_FUSED_ANY");  // tests: run-time kernel even if specialised
+        plan->fused = 0;
+        if (eligible && gpu::fused_supported(plan->l, plan->m, t1, t2, plan->pw) && !(force_any && force_any[0] == '1'))
+            plan->fused = 1;
+        else if (eligible && gpu::fused_any_supported(plan->l, plan->m, t1, t2, plan->pw))
+            plan->fused = 2;
+    }
     if (plan->mode == APTGPU_MODE_FP16_TAPS && plan->l > 1) {
         const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
         std::vector<uint16_t> tab(static_cast<size_t>(plan->l) * gpu::f16taps_pairs_per_phase(plan->l, t1) * 2 + 8, 0);
@@ -204,7 +211,13 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         plan->d_taps_f16.alloc(tab.size());
         hip_check(hipMemcpy(plan->d_taps_f16.ptr, tab.data(), tab.size() * 2, hipMemcpyHostToDevice), "hipMemcpy f16 taps");
     }
-    if (plan->fused) {
+    if (plan->fused == 2) {
+        const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
+        Signal tab(static_cast<size_t>(gpu::fused_any_table_floats(plan->l, t1)) + 16, 0.f);
+        gpu::fused_any_table(plan->l, plan->taps_resample.data(), t1, tab.data());
+        upload(plan->d_taps_any, tab);
+    }
+    if (plan->fused == 1) {
         const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
         Signal hs(static_cast<size_t>(gpu::fused_tap_table_floats(plan->l, plan->m, t1)) + 16, 0.f);
         gpu::fused_branch_taps(plan->l, plan->m, plan->taps_resample.data(), t1, hs.data());
@@ -305,12 +318,12 @@ int aptgpu_plan::enqueue(int i, const Input &in, float *d_rows, uint64_t rows_ca
         return slot;
     }
 
-    const bool use_fused = fused && !keep_steps;
+    const bool use_fused = fused != 0 && !keep_steps;
     // WAV ingest (wav.rs:30-51): mono PCM16 goes straight into the fused front end, anything
     // else is converted into the slot's f32 staging buffer first
     const float *d_signal = static_cast<const float *>(in.ptr);
     const bool pcm16 = in.codec == static_cast<int>(apt::WavCodec::I16) && in.channels == 1 && use_fused &&
-                       (reinterpret_cast<uintptr_t>(in.ptr) & 3u) == 0;
+                       (reinterpret_cast<uintptr_t>(in.ptr) & (fused == 1 ? 3u : 1u)) == 0;
     if (in.codec >= 0 && !pcm16) {
         if (!sl.ingest.ptr) sl.ingest.alloc(max_samples + 16);
         timed("wav_to_signal", [&] {
@@ -321,13 +334,18 @@ int aptgpu_plan::enqueue(int i, const Input &in, float *d_rows, uint64_t rows_ca
     if (use_fused) {
         // 1-3 fused: resample -> envelope -> low-pass in one launch (apt_kernels_fused.hip)
         timed("fused_front_end", [&] {
-            fused_front_end(cur, l, m, static_cast<uint32_t>(taps_resample.size()),
-                            static_cast<uint32_t>(taps_lowpass.size()), pw,
-                            pcm16 ? in.ptr : static_cast<const void *>(d_signal), pcm16, n,
-                            d_taps_branch.ptr, d_taps_lowpass.ptr, d_taps_lowpass_pairs.ptr, cosphi2, sinphi,
-                            sl.filtered.ptr,
-                            (sync && work_is_multiple) ? sl.correlation.ptr : nullptr,
-                            (sync && work_is_multiple) ? sl.gm.ptr : nullptr, w, w - n_sync_taps);
+            const uint32_t t1 = static_cast<uint32_t>(taps_resample.size());
+            const uint32_t t2 = static_cast<uint32_t>(taps_lowpass.size());
+            const void *xin = pcm16 ? in.ptr : static_cast<const void *>(d_signal);
+            float *c_out = (sync && work_is_multiple) ? sl.correlation.ptr : nullptr;
+            float *gm_out = (sync && work_is_multiple) ? sl.gm.ptr : nullptr;
+            if (fused == 1)
+                fused_front_end(cur, l, m, t1, t2, pw, xin, pcm16, n, d_taps_branch.ptr, d_taps_lowpass.ptr,
+                                d_taps_lowpass_pairs.ptr, cosphi2, sinphi, sl.filtered.ptr, c_out, gm_out, w,
+                                w - n_sync_taps);
+            else
+                fused_any_front_end(cur, l, m, t1, t2, pw, xin, pcm16, n, d_taps_any.ptr, d_taps_lowpass.ptr,
+                                    cosphi2, sinphi, sl.filtered.ptr, c_out, gm_out, w, w - n_sync_taps);
         });
     } else {
     // 1. resample to work_rate (dsp.rs:62-126)

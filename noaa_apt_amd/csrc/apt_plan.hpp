@@ -116,13 +116,13 @@ struct aptgpu_plan {
     uint64_t max_work_len = 0;
     uint32_t max_rows = 0;
     int max_batch = 1;
-    bool fused = false;
+    int fused = 0;  // 0 unfused generic kernels, 1 compile-time specialised k_fused, 2 run-time k_fused_any
     // the front end is launched as this many consecutive tile ranges: each kernel boundary lets
     // the previous recording's single-workgroup orbit kernel (147 KB of LDS) grab a CU
     int picker_force = 0;  // 0 global-memory picker; APTGPU_FORCE_WALK=1 -> 1; APTGPU_PICKER_LDS=1 -> 4
   // APTGPU_FORCE_WALK=1: exercise the picker's fallback path
 
-    apt::DeviceBuffer<float> d_taps_resample, d_taps_lowpass, d_one, d_taps_branch, d_taps_lowpass_pairs;
+    apt::DeviceBuffer<float> d_taps_resample, d_taps_lowpass, d_one, d_taps_branch, d_taps_lowpass_pairs, d_taps_any;
     apt::DeviceBuffer<uint16_t> d_taps_f16;  // APTGPU_MODE_FP16_TAPS
     float f16_unscale = 1.f;
     struct Slot {

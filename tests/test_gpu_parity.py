@@ -216,11 +216,50 @@ def test_decode_alternate_paths(oracle, mode, monkeypatch):
 
 
 def test_fused_specialisations_are_used(ctx):
-    """48 kHz and 96 kHz (standard profile) run the fused front end; other rates the generic one."""
-    for rate, want in ((48000, 1), (96000, 1), (44100, 0), (11025, 0)):
-        _, st = apt.decode(ctx, apt.Settings(), synth_apt(rate, 11, 3), apt.Rate.hz(rate), True,
-                           return_stats=True)
-        assert st.fused == want, rate
+    """48 kHz and 96 kHz (standard profile) run the compile-time specialised front end (1);
+    every other rate/profile the run-time fused kernel (2); l == 1 the unfused kernels (0)."""
+    for rate, profile, want in ((48000, "standard", 1), (96000, "standard", 1), (44100, "standard", 2),
+                                (11025, "standard", 2), (48000, "fast", 2), (48000, "slow", 2),
+                                (24960, "standard", 0)):
+        _, st = apt.decode(ctx, apt.Settings.profile(profile), synth_apt(rate, 11, 3), apt.Rate.hz(rate),
+                           True, return_stats=True)
+        assert st.fused == want, (rate, profile)
+
+
+ANY_CASES = [  # (rate, seconds, profile): the run-time fused kernel on every kind of geometry
+    (11025, 40, "standard"), (44100, 14, "standard"), (22050, 14, "standard"), (8000, 40, "standard"),
+    (32000, 14, "standard"), (12000, 20, "standard"), (48000, 14, "fast"), (48000, 14, "slow"),
+    (11025, 30, "fast"), (44100, 14, "slow"), (96000, 12, "fast"), (20800, 15, "standard"), (15600, 20, "standard"),
+    (48000, 14, "standard"), (96000, 12, "standard"),   # forced over the specialisations (env below)
+]
+
+
+@pytest.mark.parametrize("rate,seconds,profile", ANY_CASES)
+@pytest.mark.parametrize("sync", [True, False])
+def test_runtime_fused_kernel_bitexact(oracle, monkeypatch, rate, seconds, profile, sync):
+    monkeypatch.setenv("APTGPU_FUSED_ANY", "1")
+    x = synth_apt(rate, seconds, seed=rate % 89 + seconds)
+    s = apt.Settings.profile(profile)
+    os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                       "resample_cutout", "demodulation_atten")}
+    want = oracle.decode(x, rate, sync, settings=os_)
+    got, st = apt.decode(apt.Context(device=0), s, x, apt.Rate.hz(rate), sync, return_stats=True)
+    # the one combination whose polyphase table (29 k taps) does not fit LDS falls back
+    assert st.fused == (0 if (rate, profile) == (44100, "slow") else 2), (st.l, st.m, st.n_resample_taps)
+    assert_bitexact(got, want, f"run-time fused {rate} {profile} sync={sync}")
+
+
+def test_runtime_fused_kernel_long_and_ragged(oracle, monkeypatch):
+    """Many tiles, lengths that end mid-tile / mid-group, and a 15-minute 11 025 Hz pass."""
+    monkeypatch.setenv("APTGPU_FUSED_ANY", "1")
+    for rate, n in ((11025, 11025 * 900), (11025, 11025 * 20 + 1), (44100, 44100 * 12 + 735),
+                    (48000, 48000 * 14 - 1), (48000, 48000 * 13 + 50)):
+        x = synth_apt(rate, n // rate + 1, seed=n % 101)[:n]
+        want = oracle.decode(x, rate, True)
+        got, st = apt.decode(apt.Context(device=0), apt.Settings(), x, apt.Rate.hz(rate), True,
+                             return_stats=True)
+        assert st.fused == 2
+        assert_bitexact(got, want, f"run-time fused {rate} n={n}")
 
 
 def test_decode_long_recordings(ctx, oracle):
