@@ -15,7 +15,10 @@ import sys
 
 def short(name):
     m = re.search(r"(k_[a-z_0-9]+)", name)
-    return m.group(1) if m else name[:40]
+    base = m.group(1) if m else name[:40]
+    if base.startswith("k_fused") and re.search(r",\s*short>", name):
+        base += "_pcm16"  # the int16-input instantiation (WAV ingest inside the front end)
+    return base
 
 
 def avg(path, counter):
