@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--inputs", type=int, default=4,
                     help="distinct recordings resident in HBM, decoded round-robin (4 x 115 MB exceeds "
                          "the 256 MB Infinity Cache, so every step reads its input from HBM)")
+    ap.add_argument("--no-sync", action="store_true",
+                    help="experiment: decode(sync=false) — front end + final resample only, no peak picker")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed-for-the-headline extra legs (PCM16 ingest, image stage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -83,7 +85,7 @@ def main():
         d_xs = [torch.from_numpy(v).to(dev) for v in xs]
         d_x = d_xs[0]
         mode = {"strict": apt.MODE_STRICT, "generic": apt.MODE_GENERIC, "fp16taps": apt.MODE_FP16_TAPS}[args.mode]
-        plan = apt.Plan(settings, rate, True, max_samples=n, max_batch=1, device=local_rank,
+        plan = apt.Plan(settings, rate, not args.no_sync, max_samples=n, max_batch=1, device=local_rank,
                         mode=mode, stream=stream.cuda_stream)
         cap = int(plan.info.max_rows)
         d_rows = torch.empty(cap * 2080, dtype=torch.float32, device=dev)
@@ -134,7 +136,7 @@ def main():
 
         # ---- extra legs (not part of `value`): the rows either side of the decode path
         extras = {}
-        if not args.no_extras and args.mode == "strict" and res.status == 0:
+        if not args.no_extras and not args.no_sync and args.mode == "strict" and res.status == 0:
             k2 = max(8, min(args.steps, 100))
 
             def timed_loop(fn):
@@ -262,9 +264,11 @@ def main():
                 "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
                                   if traffic else None,
                 "algorithmic_bytes_per_launch": b_alg,
-                # the pipeline keeps two recordings in flight, so a launch in the timed region
-                # shares the GPU with the other recording's kernels; alone it takes:
-                "co_resident_recordings": 2,
+                # the plan keeps several recordings in flight (6 streams), so a launch in the timed
+                # region shares the GPU with other launches of the same kernel: its duration is
+                # `avg_concurrent_launches` x the time the GPU spends per launch.  Alone it takes:
+                "recordings_in_flight": int(os.environ.get("APTGPU_STREAMS", "6")),
+                "avg_concurrent_launches": round(dom_ms / ms_per_step, 3) if ms_per_step > 0 else None,
                 "kernel_alone_avg_ms": round(iso_times.get(dom[0], (0.0, 0))[0], 5) if iso_times else None,
                 "frac_alone": round(b_alg / (iso_times[dom[0]][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                               if iso_times and iso_times.get(dom[0], (0, 0))[0] > 0 else None,
@@ -286,7 +290,7 @@ def main():
                                                       "resample_delta_freq", "resample_cutout",
                                                       "demodulation_atten")}
             c0 = time.perf_counter()
-            ref, st = oracle.decode(x, args.rate, True, settings=os_, want_steps=True)
+            ref, st = oracle.decode(x, args.rate, not args.no_sync, settings=os_, want_steps=True)
             c1 = time.perf_counter()
             got = ref_rows.cpu().numpy()
             parity = bool(got.size == ref.size and

@@ -263,7 +263,7 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
         // decode.rs:63
         if (!wav || !steps) status(&ctx, 0.1f, "Resampling to " + std::to_string(work));
 
-        PlanPtr plan(apt::plan_create(&ctx, *settings, input_rate_hz, sync != 0, n, 1));
+        PlanPtr plan(apt::plan_create(&ctx, *settings, input_rate_hz, sync != 0, n, 1, /*depth*/ 1));
         if (plan->spr == 0) throw Error{ErrorKind::Invalid, "work_rate too small"};
         hipStream_t s = plan->stream;  // a fresh plan's first recording runs on streams[0] == stream
         const uint64_t w = plan->work_len_for(n);

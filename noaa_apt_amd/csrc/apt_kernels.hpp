@@ -86,8 +86,8 @@ uint32_t fused_any_table_floats(uint32_t l, uint32_t t1);
 void fused_any_table(uint32_t l, const float *coeff, uint32_t t1, float *table);  // host
 bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
                          const void *x, bool pcm16, uint64_t n, const float *table, const float *h2,
-                         float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w,
-                         uint64_t n_corr);
+                         const float *h2p /* fused_lowpass_pairs */, float cosphi2, float sinphi, float *f_out,
+                         float *c_out, float *gm_out, uint64_t w, uint64_t n_corr);
 
 // ---- parallel peak picker (apt_kernels_sync.hip) ------------------------------------
 uint32_t sync_group_size();    // correlation positions per group (52)

@@ -28,6 +28,8 @@
 // dsp.rs:399 excludes and which is 0.0 anyway) leaves every bit unchanged.
 #include "apt_kernels.hpp"
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace apt::gpu {
@@ -50,6 +52,26 @@ struct AnyGeom {
     uint64_t sign[4];              // bit j set <=> sync template[j] = +1 (decode.rs:188-198)
 };
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// sign of the sync template at index j (decode.rs:188-198): + inside the seven high pulses
+template <int PW>
+__host__ __device__ constexpr bool sync_plus(int j)
+{
+    const int pulse = 2 * PW;
+    if (j < pulse || j >= pulse + 14 * pulse) return false;
+    return (((j - pulse) / pulse) & 1) == 1;
+}
+
 __device__ __forceinline__ float envelope(float prev, float curr, float cosphi2, float sinphi)
 {
     const float a = prev * prev + curr * curr;
@@ -57,10 +79,16 @@ __device__ __forceinline__ float envelope(float prev, float curr, float cosphi2,
     return __builtin_sqrtf(a - b) / sinphi;  // IEEE sqrt and divide (see the Makefile flags)
 }
 
-template <int NTHR, int KPT, typename XT>
+// T2C / PWC > 0: low-pass length and pixel width known at compile time (the standard profile:
+// 37 taps, pw = 3) — stages 3 and 4 are then fully unrolled in the packed "sample-stationary"
+// form of k_fused: every sample is broadcast against a PAIR of taps (one SGPR pair) or signs
+// (neg modifiers) feeding a pair of accumulators, half the VALU instructions of the run-time
+// loops.  0: run-time loops.
+template <int NTHR, int KPT, typename XT, int T2C, int PWC>
 __global__ void __launch_bounds__(NTHR)
 k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ table /*[l][tpp]*/,
-            const float *__restrict__ h2, float cosphi2, float sinphi, float *__restrict__ f_out,
+            const float *__restrict__ h2, const f2 *__restrict__ h2p /*[t2+1] (h2[k-1], h2[k])*/,
+            float cosphi2, float sinphi, float *__restrict__ f_out,
             float *__restrict__ c_out, float *__restrict__ gm_out, uint64_t w, uint64_t n_corr, AnyGeom G)
 {
     extern __shared__ float lds[];
@@ -155,7 +183,52 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
     }
     __syncthreads();
 
-    // ---- stage 3: KPT consecutive outputs per thread, taps ascending, window in registers
+    // ---- stage 3: KPT consecutive outputs per thread, taps ascending
+    if constexpr (T2C > 0) {
+        // sample D[b0 + e] meets output u at tap j = u - e, so the pair (u, u+1) takes
+        // (h2[j], h2[j+1]) = h2p[j+1]; walking e downwards gives ascending taps per output
+        const int b0 = static_cast<int>(G.pre) + tid * KPT;
+        if (b0 < static_cast<int>(G.kt)) {
+            constexpr int NP = KPT / 2;
+            constexpr int DW = KPT + T2C - 1;  // samples e = KPT-1 ... -(T2C-1)
+            constexpr int CH = 8;
+            f2 fa[NP];
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) fa[pp] = (f2){0.f, 0.f};
+            const float *src = B + b0;
+            static_for<0, (DW + CH - 1) / CH>([&](auto cc) {
+                constexpr int hi = KPT - 1 - decltype(cc)::value * CH;
+                float dv[CH];
+#pragma unroll
+                for (int q = 0; q < CH; ++q) dv[q] = (hi - q >= -(T2C - 1)) ? src[hi - q] : 0.f;
+                static_for<0, CH>([&](auto ee) {
+                    constexpr int e = hi - decltype(ee)::value;
+                    if constexpr (e >= -(T2C - 1)) {
+                        const float d = dv[decltype(ee)::value];
+                        static_for<0, NP>([&](auto pc) {
+                            constexpr int pp = decltype(pc)::value;
+                            constexpr int j = 2 * pp - e;  // tap of output 2pp; output 2pp+1: j+1
+                            constexpr bool va = j >= 0 && j < T2C;
+                            constexpr bool vb = j + 1 >= 0 && j + 1 < T2C;
+                            if constexpr (va && vb) {
+                                fa[pp] = fa[pp] + h2p[j + 1] * (f2){d, d};
+                            } else if constexpr (va) {
+                                fa[pp].x = fa[pp].x + h2[j] * d;
+                            } else if constexpr (vb) {
+                                fa[pp].y = fa[pp].y + h2[j + 1] * d;
+                            }
+                        });
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {
+                A[b0 + 2 * pp] = fa[pp].x;
+                A[b0 + 2 * pp + 1] = fa[pp].y;
+            }
+        }
+    } else
     {
         const int b0 = static_cast<int>(G.pre) + tid * KPT;
         if (b0 < static_cast<int>(G.kt)) {
@@ -204,6 +277,52 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
     if (gm_out == nullptr) return;  // no sync search wanted
 
     // ---- stage 4: +-1 correlation, KPT consecutive outputs per thread
+    if constexpr (PWC > 0) {
+        // sample F[b0 + e] meets output u at template index j = e - u: the pair (u, u+1) adds it
+        // with the signs of T[j] and T[j-1] (neg modifiers); e ascending = j ascending
+        const int b0 = static_cast<int>(G.pre) + tid * KPT;
+        if (b0 < static_cast<int>(G.pre + G.own)) {
+            constexpr int NP = KPT / 2;
+            constexpr int GL = 38 * PWC;
+            constexpr int FW = KPT + GL - 1;
+            constexpr int CH = 8;
+            f2 ca[NP];
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) ca[pp] = (f2){0.f, 0.f};
+            const float *src = A + b0;
+            static_for<0, (FW + CH - 1) / CH>([&](auto cc) {
+                constexpr int q0 = decltype(cc)::value * CH;
+                float fv[CH];
+#pragma unroll
+                for (int q = 0; q < CH; ++q) fv[q] = (q0 + q < FW) ? src[q0 + q] : 0.f;
+                static_for<0, CH>([&](auto ee) {
+                    constexpr int e = q0 + decltype(ee)::value;
+                    if constexpr (e < FW) {
+                        const float v = fv[decltype(ee)::value];
+                        static_for<0, NP>([&](auto pc) {
+                            constexpr int pp = decltype(pc)::value;
+                            constexpr int jx = e - 2 * pp, jy = e - 2 * pp - 1;
+                            constexpr bool va = jx >= 0 && jx < GL;
+                            constexpr bool vb = jy >= 0 && jy < GL;
+                            if constexpr (va && vb) {
+                                ca[pp] = ca[pp] + (f2){sync_plus<PWC>(jx) ? v : -v, sync_plus<PWC>(jy) ? v : -v};
+                            } else if constexpr (va) {
+                                ca[pp].x = sync_plus<PWC>(jx) ? ca[pp].x + v : ca[pp].x - v;
+                            } else if constexpr (vb) {
+                                ca[pp].y = sync_plus<PWC>(jy) ? ca[pp].y + v : ca[pp].y - v;
+                            }
+                        });
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {
+                B[b0 + 2 * pp] = ca[pp].x;
+                B[b0 + 2 * pp + 1] = ca[pp].y;
+            }
+        }
+    } else
     {
         const int b0 = static_cast<int>(G.pre) + tid * KPT;
         if (b0 < static_cast<int>(G.pre + G.own)) {
@@ -276,7 +395,7 @@ struct Candidate {
     int nthr, kpt;
 };
 // most resident waves per CU first (LDS permitting), then the larger tile
-constexpr Candidate kCandidates[] = {{256, 8}, {512, 8}, {1024, 8}, {1024, 4}};
+constexpr Candidate kCandidates[] = {{256, 8}, {1024, 8}, {1024, 4}};
 
 bool make_geom(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, int nthr, int kpt, AnyGeom *out,
                size_t *lds_bytes)
@@ -343,12 +462,12 @@ bool choose(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, Candi
     return found;
 }
 
-template <int NTHR, int KPT, typename XT>
-void launch_any(hipStream_t s, const XT *x, uint64_t n, const float *table, const float *h2, float cosphi2,
-                float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w, uint64_t n_corr,
+template <int NTHR, int KPT, int T2C, int PWC, typename XT>
+void launch_any(hipStream_t s, const XT *x, uint64_t n, const float *table, const float *h2, const float *h2p,
+                float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w, uint64_t n_corr,
                 const AnyGeom &g, size_t lds)
 {
-    auto kern = k_fused_any<NTHR, KPT, XT>;
+    auto kern = k_fused_any<NTHR, KPT, XT, T2C, PWC>;
     static size_t attr_lds = 0;
     if (lds > attr_lds && lds > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -356,7 +475,8 @@ void launch_any(hipStream_t s, const XT *x, uint64_t n, const float *table, cons
         attr_lds = lds;
     }
     const unsigned tiles = static_cast<unsigned>((w + g.own - 1) / g.own);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHR), lds, s, x, n, table, h2, cosphi2, sinphi, f_out, c_out,
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHR), lds, s, x, n, table, h2, reinterpret_cast<const f2 *>(h2p), cosphi2,
+                       sinphi, f_out, c_out,
                        gm_out, w, n_corr, g);
 }
 
@@ -393,8 +513,8 @@ void fused_any_table(uint32_t l, const float *coeff, uint32_t t1, float *table)
 
 bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
                          const void *x, bool pcm16, uint64_t n, const float *table, const float *h2,
-                         float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w,
-                         uint64_t n_corr)
+                         const float *h2p, float cosphi2, float sinphi, float *f_out, float *c_out,
+                         float *gm_out, uint64_t w, uint64_t n_corr)
 {
     Candidate c;
     AnyGeom g;
@@ -403,19 +523,27 @@ bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uin
     if (pcm16 && (reinterpret_cast<uintptr_t>(x) & 1u)) return false;
     const float *xf = static_cast<const float *>(x);
     const int16_t *xi = static_cast<const int16_t *>(x);
-#define APT_ANY_CASE(NT, KP)                                                                                   \
-    if (c.nthr == NT && c.kpt == KP) {                                                                         \
+    const bool standard = t2 == 37 && pw == 3;  // the standard profile's W-rate stages, any input rate
+#define APT_ANY_LAUNCH(NT, KP, T2C, PWC)                                                                       \
+    do {                                                                                                       \
         if (pcm16)                                                                                             \
-            launch_any<NT, KP>(s, xi, n, table, h2, cosphi2, sinphi, f_out, c_out, gm_out, w, n_corr, g, lds); \
+            launch_any<NT, KP, T2C, PWC>(s, xi, n, table, h2, h2p, cosphi2, sinphi, f_out, c_out, gm_out, w,   \
+                                         n_corr, g, lds);                                                      \
         else                                                                                                   \
-            launch_any<NT, KP>(s, xf, n, table, h2, cosphi2, sinphi, f_out, c_out, gm_out, w, n_corr, g, lds); \
+            launch_any<NT, KP, T2C, PWC>(s, xf, n, table, h2, h2p, cosphi2, sinphi, f_out, c_out, gm_out, w,   \
+                                         n_corr, g, lds);                                                      \
         return true;                                                                                           \
+    } while (0)
+#define APT_ANY_CASE(NT, KP)                     \
+    if (c.nthr == NT && c.kpt == KP) {           \
+        if (standard) APT_ANY_LAUNCH(NT, KP, 37, 3); \
+        APT_ANY_LAUNCH(NT, KP, 0, 0);            \
     }
     APT_ANY_CASE(256, 8)
-    APT_ANY_CASE(512, 8)
     APT_ANY_CASE(1024, 8)
     APT_ANY_CASE(1024, 4)
 #undef APT_ANY_CASE
+#undef APT_ANY_LAUNCH
     return false;
 }
 

@@ -87,7 +87,7 @@ std::vector<aptgpu_kernel_time> KernelTimer::collect(hipStream_t s)
 
 // ---------------------------------------------------------------- plan_create
 aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &settings,
-                         uint32_t input_rate, bool sync, size_t max_samples, int max_batch)
+                         uint32_t input_rate, bool sync, size_t max_samples, int max_batch, int depth)
 {
     if (settings.export_resample_filtered)
         throw Error{ErrorKind::Unsupported,
@@ -216,6 +216,10 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         Signal tab(static_cast<size_t>(gpu::fused_any_table_floats(plan->l, t1)) + 16, 0.f);
         gpu::fused_any_table(plan->l, plan->taps_resample.data(), t1, tab.data());
         upload(plan->d_taps_any, tab);
+        Signal h2p(2 * (plan->taps_lowpass.size() + 1) + 16, 0.f);
+        gpu::fused_lowpass_pairs(plan->taps_lowpass.data(), static_cast<uint32_t>(plan->taps_lowpass.size()),
+                                 h2p.data());
+        upload(plan->d_taps_lowpass_pairs, h2p);
     }
     if (plan->fused == 1) {
         const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
@@ -229,16 +233,25 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     }
 
     // one extra slot so that consecutive calls (and consecutive recordings of a call) overlap
-    plan->slots.resize(static_cast<size_t>(max_batch) + 1);
-    // two streams measured best on MI355X (3 is slower, 4 equal): slot k always runs on stream k % 2
-    plan->streams.resize(std::min<size_t>(plan->slots.size(), 2));
+    // Recordings in flight = streams (slot k always runs on stream k % depth).  Measured on
+    // MI355X at config 2 (ms per recording, HBM-cold inputs): 1: 0.143, 2: 0.117, 4: 0.119,
+    // 5: 0.105, 6: 0.103, 7: 0.117, 8: 0.113, 10: 0.103 — six keeps enough front-end launches
+    // queued that the tail of one is always filled by the head of the next, whatever the
+    // latency of the picker chain behind it.
+    if (depth <= 0) {
+        const char *e = std::getenv("APTGPU_STREAMS");
+        depth = e ? std::atoi(e) : 6;
+    }
+    depth = std::max(1, std::min(depth, 16));
+    plan->slots.resize(std::max<size_t>(static_cast<size_t>(max_batch) + (depth > 1 ? 1 : 0),
+                                        static_cast<size_t>(depth)));
+    plan->streams.resize(static_cast<size_t>(depth));
     for (auto &st : plan->streams)
         hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
     plan->stream = plan->streams[0];
     const uint64_t w = plan->max_work_len;
     for (auto &sl : plan->slots) {
-        sl.resampled.alloc(w + 64);
-        sl.demodulated.alloc(w + 64);
+        // (resampled / demodulated are only needed by the unfused kernels: allocated on first use)
         sl.filtered.alloc(w + 64);
         if (sync) {
             sl.correlation.alloc(w + 64);
@@ -281,10 +294,8 @@ uint64_t aptgpu_plan::out_len_nosync(uint64_t work_len) const
 void aptgpu_plan::begin_call(int count)
 {
     last_slots.assign(static_cast<size_t>(count), 0);
-    if (user_stream) {
-        apt::hip_check(hipEventRecord(ev_user, user_stream), "hipEventRecord");
-        for (hipStream_t st : streams) apt::hip_check(hipStreamWaitEvent(st, ev_user, 0), "hipStreamWaitEvent");
-    }
+    // the streams this call uses wait for ctx.stream in enqueue()
+    if (user_stream) apt::hip_check(hipEventRecord(ev_user, user_stream), "hipEventRecord");
 }
 
 void aptgpu_plan::sync_all()
@@ -304,6 +315,7 @@ int aptgpu_plan::enqueue(int i, const Input &in, float *d_rows, uint64_t rows_ca
     // everything of this recording runs in order on the slot's own stream; the recording that
     // reuses the slot is enqueued on the same stream, so no hand-over events are needed
     hipStream_t cur = streams[static_cast<size_t>(slot) % streams.size()];
+    if (user_stream) apt::hip_check(hipStreamWaitEvent(cur, ev_user, 0), "hipStreamWaitEvent");
     auto timed = [&](const char *name, auto &&launch) {
         const bool dominant = !std::strcmp(name, "fused_front_end") || !std::strcmp(name, "resample_generic") ||
                               !std::strcmp(name, "resample_f16taps");
@@ -345,9 +357,13 @@ int aptgpu_plan::enqueue(int i, const Input &in, float *d_rows, uint64_t rows_ca
                                 w - n_sync_taps);
             else
                 fused_any_front_end(cur, l, m, t1, t2, pw, xin, pcm16, n, d_taps_any.ptr, d_taps_lowpass.ptr,
-                                    cosphi2, sinphi, sl.filtered.ptr, c_out, gm_out, w, w - n_sync_taps);
+                                    d_taps_lowpass_pairs.ptr, cosphi2, sinphi, sl.filtered.ptr, c_out, gm_out, w, w - n_sync_taps);
         });
     } else {
+    if (!sl.resampled.ptr) {
+        sl.resampled.alloc(max_work_len + 64);
+        sl.demodulated.alloc(max_work_len + 64);
+    }
     // 1. resample to work_rate (dsp.rs:62-126)
     if (l > 1 && mode == APTGPU_MODE_FP16_TAPS) {
         timed("resample_f16taps", [&] {

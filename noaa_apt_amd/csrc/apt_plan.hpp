@@ -84,8 +84,8 @@ struct aptgpu_plan {
     int device = 0;
     int mode = APTGPU_MODE_STRICT;
     // Software pipeline over consecutive recordings: a recording's whole chain (front end ->
-    // picker -> gather) runs in order on ONE of two streams, recordings alternate between
-    // them (slot k -> stream k % 2).  The front end of recording i+1 therefore overlaps the
+    // picker -> gather) runs in order on ONE of `depth` streams, recordings go round-robin over
+    // them (slot k -> stream k % depth).  The front end of recording i+1 therefore overlaps the
     // latency-bound picker/gather of recording i without any cross-stream events, and a slot
     // is only ever reused by a later recording on its own stream (in-order => no hazards).
     std::vector<hipStream_t> streams;
@@ -183,6 +183,7 @@ namespace apt {
 
 // Builds a plan; throws apt::Error with the reference's messages.
 aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &settings,
-                         uint32_t input_rate, bool sync, size_t max_samples, int max_batch);
+                         uint32_t input_rate, bool sync, size_t max_samples, int max_batch,
+                         int depth = 0 /* recordings in flight; 0 = default (6, or APTGPU_STREAMS) */);
 
 }  // namespace apt
