@@ -168,9 +168,10 @@ int aptgpu_plan_get_info(const aptgpu_plan *plan, aptgpu_plan_info *info);
 /* Enqueue decode() of `count` independent recordings already resident in HBM.
  * d_signals[i] points to n[i] device floats; d_rows[i] receives up to
  * rows_cap[i]*2080 device floats.  Asynchronous, no host synchronisation.
- * The plan alternates recordings between two in-order streams (also across
- * consecutive calls), so the front end of recording i+1 overlaps the peak
- * picker and row gather of recording i; it owns max_batch+1 workspace slots.  If
+ * The plan spreads recordings round-robin over six in-order streams (also
+ * across consecutive calls; APTGPU_STREAMS overrides the depth), so front ends
+ * of later recordings overlap the peak picker and row gather of earlier ones;
+ * it owns max(max_batch + 1, depth) workspace slots.  If
  * ctx.stream was given at plan creation the work is ordered AFTER what is
  * already enqueued on ctx.stream (inputs may be produced there); to order
  * ctx.stream after the decode, call aptgpu_plan_join().  Outcome per recording

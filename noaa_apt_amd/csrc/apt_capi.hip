@@ -219,6 +219,11 @@ int aptgpu_plan_read_internal(aptgpu_plan *plan, int i, const char *name, void *
     const void *src = nullptr;
     size_t size = 0;
     const std::string n(name);
+    if (n == "inv_sinphi") {  // host-side constant: RN(1/sin(phi)) when the fast exact divide is on, else 0
+        if (size_out) *size_out = sizeof(float);
+        if (host_out && bytes >= sizeof(float)) std::memcpy(host_out, &plan->inv_sinphi, sizeof(float));
+        return APTGPU_OK;
+    }
     if (n == "filtered") { src = sl.filtered.ptr; size = sl.filtered.count * sizeof(float); }
     else if (n == "correlation") { src = sl.correlation.ptr; size = sl.correlation.count * sizeof(float); }
     else if (n == "group_max") { src = sl.gm.ptr; size = sl.gm.count * sizeof(float); }

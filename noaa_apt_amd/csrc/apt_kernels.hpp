@@ -76,8 +76,8 @@ void fused_lowpass_pairs(const float *h2, uint32_t t2, float *h2p);
 // x is the f32 Signal, or (pcm16) mono int16 samples at a 4-byte aligned address.
 bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
                      const void *x, bool pcm16, uint64_t n, const float *hs, const float *h2, const float *h2p,
-                     float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out,
-                     uint64_t w, uint64_t n_corr);
+                     float cosphi2, float sinphi, float inv_sinphi /* verified RN(1/sinphi) or 0, apt_envelope.hpp */,
+                     float *f_out, float *c_out, float *gm_out, uint64_t w, uint64_t n_corr);
 
 // ---- fused front end for any rate / profile (apt_kernels_fused_any.hip) -------------
 // run-time parameters, taps phase-major in LDS; same outputs as fused_front_end
@@ -86,7 +86,7 @@ uint32_t fused_any_table_floats(uint32_t l, uint32_t t1);
 void fused_any_table(uint32_t l, const float *coeff, uint32_t t1, float *table);  // host
 bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
                          const void *x, bool pcm16, uint64_t n, const float *table, const float *h2,
-                         const float *h2p /* fused_lowpass_pairs */, float cosphi2, float sinphi, float *f_out,
+                         const float *h2p /* fused_lowpass_pairs */, float cosphi2, float sinphi, float inv_sinphi, float *f_out,
                          float *c_out, float *gm_out, uint64_t w, uint64_t n_corr);
 
 // ---- parallel peak picker (apt_kernels_sync.hip) ------------------------------------
@@ -140,6 +140,10 @@ void wav_to_signal(hipStream_t s, const void *d_data, uint64_t n_frames, uint32_
 
 // wav::write_wav, 16-bit branch (wav.rs:83-86): normalise by d_limits[1] (get_max) -> i16
 void quantize_i16(hipStream_t s, const float *d_x, uint64_t n, const float *d_limits, int16_t *d_out);
+
+// exhaustive device-side check that division by c through rc = RN(1/c) + one FMA correction is
+// correctly rounded (apt_envelope.hpp); run once per plan
+bool verify_fast_divide(hipStream_t s, float c, float rc);
 
 // writes a result record from the host's knowledge (too-short recording, no-sync path)
 void set_result(hipStream_t s, Result *res, Result value);

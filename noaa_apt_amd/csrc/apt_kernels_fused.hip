@@ -21,6 +21,7 @@
 // threads of post-halo (the correlation looks ahead 38*PW-1 samples).  LDS: the input
 // tile, later overwritten by R and then F (region P), plus D (region Q).
 #include "apt_kernels.hpp"
+#include "apt_envelope.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -112,7 +113,7 @@ template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT>
 __global__ void __launch_bounds__(NTHR, (APT_FUSED_MIN_WAVES * NTHR + 255) / 256)
 k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][PS] tap pairs*/,
         const float *__restrict__ h2 /*[T2]*/, const f2 *__restrict__ h2p /*[T2+1] (h2[m-1], h2[m])*/,
-        float cosphi2, float sinphi,
+        float cosphi2, float sinphi, float inv_sinphi /* verified RN(1/sinphi), or 0 */,
         float *__restrict__ f_out, float *__restrict__ c_out, float *__restrict__ gm_out,
         uint64_t w, uint64_t n_corr)
 {
@@ -213,10 +214,14 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
                     tb[buf][e * Gm::PS + k] = (q < Gm::WIN) ? hs[q * Gm::PS + k] : (f2){0.f, 0.f};
             }
         };
-        auto mac = [&](auto cc, auto ee, auto kk) {
+        // product of window sample (c, e) with tap pair k — kept apart from the accumulation so
+        // that a sample's products are all issued before the first dependent add (a v_pk_add
+        // right behind the v_pk_mul it reads costs a wait state)
+        auto prod = [&](auto cc, auto ee, auto kk) -> f2 {
             constexpr int c = decltype(cc)::value, e = decltype(ee)::value, k = decltype(kk)::value;
             constexpr int buf = c & 1;
             constexpr int q = c * CH + e;
+            f2 p = (f2){0.f, 0.f};
             if constexpr (q < Gm::WIN) {
                 const float xq = xb[buf][e];
                 if constexpr (k < Gm::NP) {
@@ -224,28 +229,59 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
                     constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
                     constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
                     if constexpr (va && vb) {
-                        acc[k] = acc[k] + t * (f2){xq, xq};
+                        p = t * (f2){xq, xq};
                     } else if constexpr (va) {
-                        acc[k].x = acc[k].x + t.x * xq;
+                        p.x = t.x * xq;
                     } else if constexpr (vb) {
-                        acc[k].y = acc[k].y + t.y * xq;
+                        p.y = t.y * xq;
                     }
                 } else if constexpr (branch_uses<L, M, T1>(L - 1, q)) {
-                    accl = accl + tl[buf][e] * xq;
+                    p.x = tl[buf][e] * xq;
+                }
+            }
+            return p;
+        };
+        auto accum = [&](auto cc, auto ee, auto kk, f2 p) {
+            constexpr int c = decltype(cc)::value, e = decltype(ee)::value, k = decltype(kk)::value;
+            constexpr int q = c * CH + e;
+            if constexpr (q < Gm::WIN) {
+                if constexpr (k < Gm::NP) {
+                    constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
+                    constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
+                    if constexpr (va && vb) {
+                        acc[k] = acc[k] + p;
+                    } else if constexpr (va) {
+                        acc[k].x = acc[k].x + p.x;
+                    } else if constexpr (vb) {
+                        acc[k].y = acc[k].y + p.y;
+                    }
+                } else if constexpr (branch_uses<L, M, T1>(L - 1, q)) {
+                    accl = accl + p.x;
                 }
             }
         };
         issue(std::integral_constant<int, 0>{});
         static_for<0, NCH>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            mac(cc, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            constexpr int NK = Gm::PS + (L & 1);
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            // the first two products force the wait for the loads issued one chunk ago
+            const f2 p00 = prod(cc, I0{}, I0{});
+            const f2 p01 = prod(cc, I0{}, I1{});
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (c + 1 < NCH) issue(std::integral_constant<int, c + 1>{});
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, CH>([&](auto ee) {
-                static_for<0, Gm::PS + (L & 1)>([&](auto kk) {
-                    if constexpr (!(decltype(ee)::value == 0 && decltype(kk)::value == 0)) mac(cc, ee, kk);
+                constexpr int e = decltype(ee)::value;
+                f2 pr[NK];
+                static_for<0, NK>([&](auto kk) {
+                    constexpr int k = decltype(kk)::value;
+                    if constexpr (e == 0 && k == 0) pr[k] = p00;
+                    else if constexpr (e == 0 && k == 1) pr[k] = p01;
+                    else pr[k] = prod(cc, ee, kk);
                 });
+                static_for<0, NK>([&](auto kk) { accum(cc, ee, kk, pr[decltype(kk)::value]); });
             });
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -267,17 +303,27 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
     // ---- stage 2: AM envelope from consecutive samples (dsp.rs:369-377)
     {
         float prev = (tid > 0) ? P[tid * L - 1] : 0.f;
+        float xr[L];
+        bool in_range = inv_sinphi != 0.f;  // 0: the fast divide did not verify for this sin(phi)
 #pragma unroll
         for (int b = 0; b < L; ++b) {
             const float curr = r[b];
-            float d = 0.f;
-            if (kq + b > k_lo) {  // global index >= 1
-                const float s = (prev * prev) + (curr * curr);
-                const float c = (prev * curr) * cosphi2;
-                d = __builtin_sqrtf(s - c) / sinphi;
-            }
-            Q[tid * L + b] = d;
+            xr[b] = envelope_radicand(prev, curr, cosphi2);
+            // (outputs outside the recording are zeroed below whatever their radicand is)
+            in_range = in_range && (envelope_in_range(xr[b]) || kq + b <= k_lo || kq + b >= k_hi);
             prev = curr;
+        }
+        // wave-uniform choice: the exactly rounded fast path (apt_envelope.hpp) when every value
+        // of the wave is in its range, the compiler's general sequences otherwise
+        if (__all(in_range)) {
+#pragma unroll
+            for (int b = 0; b < L; ++b) {
+                // (positions at or past the end of the recording hold garbage: never read)
+                Q[tid * L + b] = (kq + b > k_lo) ? envelope_fast(xr[b], sinphi, inv_sinphi) : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < L; ++b) Q[tid * L + b] = (kq + b > k_lo) ? envelope_general(xr[b], sinphi) : 0.f;
         }
     }
     __syncthreads();
@@ -304,22 +350,44 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
                     constexpr int qq = hi - decltype(ee)::value;
                     if constexpr (qq >= 0) {
                         const float d = dv[decltype(ee)::value];
+                        // all products of this sample first, then the dependent adds (a
+                        // v_pk_add right behind the v_pk_mul it reads costs a wait state)
+                        f2 pr[Gm::NP > 0 ? Gm::NP : 1];
+                        float pl = 0.f;
                         static_for<0, Gm::NP>([&](auto pc) {
                             constexpr int pp = decltype(pc)::value;
                             constexpr int m = (T2 - 1) + 2 * pp - qq;       // tap of lane x; lane y: m+1
                             constexpr bool va = m >= 0 && m < T2;
                             constexpr bool vb = m + 1 >= 0 && m + 1 < T2;
+                            pr[pp] = (f2){0.f, 0.f};
                             if constexpr (va && vb) {
-                                fa[pp] = fa[pp] + h2p[m + 1] * (f2){d, d};
+                                pr[pp] = h2p[m + 1] * (f2){d, d};
                             } else if constexpr (va) {
-                                fa[pp].x = fa[pp].x + h2[m] * d;
+                                pr[pp].x = h2[m] * d;
                             } else if constexpr (vb) {
-                                fa[pp].y = fa[pp].y + h2[m + 1] * d;
+                                pr[pp].y = h2[m + 1] * d;
                             }
                         });
                         if constexpr (L & 1) {
                             constexpr int ml = (T2 - 1) + (L - 1) - qq;
-                            if constexpr (ml >= 0 && ml < T2) fl = fl + h2[ml] * d;
+                            if constexpr (ml >= 0 && ml < T2) pl = h2[ml] * d;
+                        }
+                        static_for<0, Gm::NP>([&](auto pc) {
+                            constexpr int pp = decltype(pc)::value;
+                            constexpr int m = (T2 - 1) + 2 * pp - qq;
+                            constexpr bool va = m >= 0 && m < T2;
+                            constexpr bool vb = m + 1 >= 0 && m + 1 < T2;
+                            if constexpr (va && vb) {
+                                fa[pp] = fa[pp] + pr[pp];
+                            } else if constexpr (va) {
+                                fa[pp].x = fa[pp].x + pr[pp].x;
+                            } else if constexpr (vb) {
+                                fa[pp].y = fa[pp].y + pr[pp].y;
+                            }
+                        });
+                        if constexpr (L & 1) {
+                            constexpr int ml = (T2 - 1) + (L - 1) - qq;
+                            if constexpr (ml >= 0 && ml < T2) fl = fl + pl;
                         }
                     }
                 });
@@ -439,7 +507,8 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
 
 template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT>
 void launch_fused(hipStream_t s, const XT *x, uint64_t n, const float *hb, const float *h2,
-                  const float *h2p, float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w,
+                  const float *h2p, float cosphi2, float sinphi, float inv_sinphi, float *f_out, float *c_out,
+                  float *gm_out, uint64_t w,
                   uint64_t n_corr)
 {
     using Gm = FusedGeom<L, M, T1, T2, PW, NTHR>;
@@ -454,7 +523,7 @@ void launch_fused(hipStream_t s, const XT *x, uint64_t n, const float *hb, const
     }
     const unsigned tiles = static_cast<unsigned>((w + Gm::OWN_K - 1) / Gm::OWN_K);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(kFusedThreads), lds, s, x, n, reinterpret_cast<const f2 *>(hb), h2,
-                       reinterpret_cast<const f2 *>(h2p), cosphi2, sinphi,
+                       reinterpret_cast<const f2 *>(h2p), cosphi2, sinphi, inv_sinphi,
                        f_out, c_out, gm_out, w, n_corr);
 }
 
@@ -514,7 +583,7 @@ void fused_lowpass_pairs(const float *h2, uint32_t t2, float *h2p)
 
 bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
                      const void *x, bool pcm16, uint64_t n, const float *hb, const float *h2, const float *h2p,
-                     float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out,
+                     float cosphi2, float sinphi, float inv_sinphi, float *f_out, float *c_out, float *gm_out,
                      uint64_t w, uint64_t n_corr)
 {
     const float *xf = static_cast<const float *>(x);
@@ -522,20 +591,20 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
     if (pcm16 && (reinterpret_cast<uintptr_t>(x) & 3u)) return false;  // dword loads of sample pairs
     if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
         if (pcm16)
-            launch_fused<13, 50, 959, 37, 3, 256>(s, xi, n, hb, h2, h2p, cosphi2, sinphi, f_out, c_out, gm_out, w,
+            launch_fused<13, 50, 959, 37, 3, 256>(s, xi, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, c_out, gm_out, w,
                                                   n_corr);
         else
-            launch_fused<13, 50, 959, 37, 3, 256>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, f_out, c_out, gm_out, w,
+            launch_fused<13, 50, 959, 37, 3, 256>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, c_out, gm_out, w,
                                                   n_corr);
         return true;
     }
     if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3) {
         // twice the input per work sample: 128-thread workgroups keep the x tile at 51.8 KB
         if (pcm16)
-            launch_fused<13, 100, 1915, 37, 3, 128>(s, xi, n, hb, h2, h2p, cosphi2, sinphi, f_out, c_out, gm_out,
+            launch_fused<13, 100, 1915, 37, 3, 128>(s, xi, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, c_out, gm_out,
                                                     w, n_corr);
         else
-            launch_fused<13, 100, 1915, 37, 3, 128>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, f_out, c_out, gm_out,
+            launch_fused<13, 100, 1915, 37, 3, 128>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, c_out, gm_out,
                                                     w, n_corr);
         return true;
     }

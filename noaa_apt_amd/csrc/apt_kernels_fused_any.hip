@@ -27,6 +27,7 @@
 // past n, which the reference skips, dsp.rs:257; D[k <= 0], which the `i > j` guard of
 // dsp.rs:399 excludes and which is 0.0 anyway) leaves every bit unchanged.
 #include "apt_kernels.hpp"
+#include "apt_envelope.hpp"
 
 #include <type_traits>
 
@@ -72,12 +73,6 @@ __host__ __device__ constexpr bool sync_plus(int j)
     return (((j - pulse) / pulse) & 1) == 1;
 }
 
-__device__ __forceinline__ float envelope(float prev, float curr, float cosphi2, float sinphi)
-{
-    const float a = prev * prev + curr * curr;
-    const float b = prev * curr * cosphi2;
-    return __builtin_sqrtf(a - b) / sinphi;  // IEEE sqrt and divide (see the Makefile flags)
-}
 
 // T2C / PWC > 0: low-pass length and pixel width known at compile time (the standard profile:
 // 37 taps, pw = 3) — stages 3 and 4 are then fully unrolled in the packed "sample-stationary"
@@ -88,7 +83,7 @@ template <int NTHR, int KPT, typename XT, int T2C, int PWC>
 __global__ void __launch_bounds__(NTHR)
 k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ table /*[l][tpp]*/,
             const float *__restrict__ h2, const f2 *__restrict__ h2p /*[t2+1] (h2[k-1], h2[k])*/,
-            float cosphi2, float sinphi, float *__restrict__ f_out,
+            float cosphi2, float sinphi, float inv_sinphi, float *__restrict__ f_out,
             float *__restrict__ c_out, float *__restrict__ gm_out, uint64_t w, uint64_t n_corr, AnyGeom G)
 {
     extern __shared__ float lds[];
@@ -173,13 +168,35 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
     }
     __syncthreads();
 
-    // ---- stage 2
-    for (int i = 0; i < KPT; ++i) {
-        const int idx = tid + i * NTHR;
-        const int64_t k = t0 + idx;
-        float d = 0.f;
-        if (idx > 0 && k > 0 && k < static_cast<int64_t>(w)) d = envelope(A[idx - 1], A[idx], cosphi2, sinphi);
-        B[idx] = d;
+    // ---- stage 2: exactly rounded envelope, fast path when the whole wave is in range
+    {
+        float xr[KPT];
+        bool in_range = inv_sinphi != 0.f;
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = tid + i * NTHR;
+            const int64_t k = t0 + idx;
+            const bool live = idx > 0 && k > 0 && k < static_cast<int64_t>(w);
+            xr[i] = live ? envelope_radicand(A[idx - 1], A[idx], cosphi2) : 1.f;
+            in_range = in_range && envelope_in_range(xr[i]);
+        }
+        if (__all(in_range)) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const int idx = tid + i * NTHR;
+                const int64_t k = t0 + idx;
+                const bool live = idx > 0 && k > 0 && k < static_cast<int64_t>(w);
+                B[idx] = live ? envelope_fast(xr[i], sinphi, inv_sinphi) : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) {
+                const int idx = tid + i * NTHR;
+                const int64_t k = t0 + idx;
+                const bool live = idx > 0 && k > 0 && k < static_cast<int64_t>(w);
+                B[idx] = live ? envelope_general(xr[i], sinphi) : 0.f;
+            }
+        }
     }
     __syncthreads();
 
@@ -464,7 +481,7 @@ bool choose(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, Candi
 
 template <int NTHR, int KPT, int T2C, int PWC, typename XT>
 void launch_any(hipStream_t s, const XT *x, uint64_t n, const float *table, const float *h2, const float *h2p,
-                float cosphi2, float sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w, uint64_t n_corr,
+                float cosphi2, float sinphi, float inv_sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w, uint64_t n_corr,
                 const AnyGeom &g, size_t lds)
 {
     auto kern = k_fused_any<NTHR, KPT, XT, T2C, PWC>;
@@ -476,7 +493,7 @@ void launch_any(hipStream_t s, const XT *x, uint64_t n, const float *table, cons
     }
     const unsigned tiles = static_cast<unsigned>((w + g.own - 1) / g.own);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHR), lds, s, x, n, table, h2, reinterpret_cast<const f2 *>(h2p), cosphi2,
-                       sinphi, f_out, c_out,
+                       sinphi, inv_sinphi, f_out, c_out,
                        gm_out, w, n_corr, g);
 }
 
@@ -513,8 +530,8 @@ void fused_any_table(uint32_t l, const float *coeff, uint32_t t1, float *table)
 
 bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
                          const void *x, bool pcm16, uint64_t n, const float *table, const float *h2,
-                         const float *h2p, float cosphi2, float sinphi, float *f_out, float *c_out,
-                         float *gm_out, uint64_t w, uint64_t n_corr)
+                         const float *h2p, float cosphi2, float sinphi, float inv_sinphi, float *f_out,
+                         float *c_out, float *gm_out, uint64_t w, uint64_t n_corr)
 {
     Candidate c;
     AnyGeom g;
@@ -527,11 +544,11 @@ bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uin
 #define APT_ANY_LAUNCH(NT, KP, T2C, PWC)                                                                       \
     do {                                                                                                       \
         if (pcm16)                                                                                             \
-            launch_any<NT, KP, T2C, PWC>(s, xi, n, table, h2, h2p, cosphi2, sinphi, f_out, c_out, gm_out, w,   \
-                                         n_corr, g, lds);                                                      \
+            launch_any<NT, KP, T2C, PWC>(s, xi, n, table, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, c_out,  \
+                                         gm_out, w, n_corr, g, lds);                                           \
         else                                                                                                   \
-            launch_any<NT, KP, T2C, PWC>(s, xf, n, table, h2, h2p, cosphi2, sinphi, f_out, c_out, gm_out, w,   \
-                                         n_corr, g, lds);                                                      \
+            launch_any<NT, KP, T2C, PWC>(s, xf, n, table, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, c_out,  \
+                                         gm_out, w, n_corr, g, lds);                                           \
         return true;                                                                                           \
     } while (0)
 #define APT_ANY_CASE(NT, KP)                     \

@@ -6,6 +6,7 @@
 // for the fused specialised kernels in apt_kernels_fused.hip, and the path used when
 // the caller asks for the intermediate "steps" (Context::step).
 #include "apt_kernels.hpp"
+#include "apt_envelope.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -457,6 +458,40 @@ void gather_rows(hipStream_t s, const float *f, const uint32_t *peaks, const Res
     const unsigned gx = (spr / pw + 4 * kBlock - 1) / (4 * kBlock);
     hipLaunchKernelGGL(k_gather_rows, dim3(gx ? gx : 1, gy), dim3(kBlock), 0, s, f, peaks, res, spr,
                        pw, raw ? 1 : 0, rows, rows_cap);
+}
+
+
+// ---------------------------------------------------------------------------------
+// Exhaustive check of fast_divide (apt_envelope.hpp) for one divisor: every significand in the
+// binades [1, 2) and [2, 4) — the quotient's rounding only depends on the significands, and two
+// adjacent binades cover both relative positions of x's and c's significands.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_verify_fast_divide(float c, float rc, uint32_t *bad)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;  // 2^24 values
+    const float x = __uint_as_float(0x3F800000u + i);     // 1.0 ... 4.0
+    const float want = x / c;
+    const float got = fast_divide(x, c, rc);
+    if (__float_as_uint(want) != __float_as_uint(got)) atomicAdd(bad, 1u);
+}
+
+bool verify_fast_divide(hipStream_t s, float c, float rc)
+{
+    if (!(c == c) || !(rc == rc) || c == 0.f || rc == 0.f) return false;
+    // keep every intermediate of the check itself in the normal range
+    const float ac = c < 0.f ? -c : c;
+    if (!(ac > 1e-6f && ac < 1e6f)) return false;
+    uint32_t *d_bad = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&d_bad), sizeof(uint32_t)) != hipSuccess) return false;
+    uint32_t bad = 1;
+    bool ok = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), s) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_verify_fast_divide, dim3((1u << 24) / 256u), dim3(256), 0, s, c, rc, d_bad);
+        ok = hipMemcpyAsync(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipStreamSynchronize(s) == hipSuccess;
+    }
+    (void)hipFree(d_bad);
+    return ok && bad == 0;
 }
 
 }  // namespace apt::gpu

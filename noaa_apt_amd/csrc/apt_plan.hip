@@ -211,6 +211,12 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         plan->d_taps_f16.alloc(tab.size());
         hip_check(hipMemcpy(plan->d_taps_f16.ptr, tab.data(), tab.size() * 2, hipMemcpyHostToDevice), "hipMemcpy f16 taps");
     }
+    if (plan->fused != 0) {
+        // division by sin(phi) through its reciprocal: only if it is exactly rounded for every x
+        const float rc = 1.0f / plan->sinphi;
+        const char *off = std::getenv("APTGPU_GENERAL_ENVELOPE");  // tests: force the general code
+        if (!(off && off[0] == '1') && gpu::verify_fast_divide(nullptr, plan->sinphi, rc)) plan->inv_sinphi = rc;
+    }
     if (plan->fused == 2) {
         const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
         Signal tab(static_cast<size_t>(gpu::fused_any_table_floats(plan->l, t1)) + 16, 0.f);
@@ -353,11 +359,12 @@ int aptgpu_plan::enqueue(int i, const Input &in, float *d_rows, uint64_t rows_ca
             float *gm_out = (sync && work_is_multiple) ? sl.gm.ptr : nullptr;
             if (fused == 1)
                 fused_front_end(cur, l, m, t1, t2, pw, xin, pcm16, n, d_taps_branch.ptr, d_taps_lowpass.ptr,
-                                d_taps_lowpass_pairs.ptr, cosphi2, sinphi, sl.filtered.ptr, c_out, gm_out, w,
+                                d_taps_lowpass_pairs.ptr, cosphi2, sinphi, inv_sinphi, sl.filtered.ptr, c_out, gm_out, w,
                                 w - n_sync_taps);
             else
                 fused_any_front_end(cur, l, m, t1, t2, pw, xin, pcm16, n, d_taps_any.ptr, d_taps_lowpass.ptr,
-                                    d_taps_lowpass_pairs.ptr, cosphi2, sinphi, sl.filtered.ptr, c_out, gm_out, w, w - n_sync_taps);
+                                    d_taps_lowpass_pairs.ptr, cosphi2, sinphi, inv_sinphi, sl.filtered.ptr, c_out,
+                                    gm_out, w, w - n_sync_taps);
         });
     } else {
     if (!sl.resampled.ptr) {

@@ -409,3 +409,61 @@ def test_plan_device_resident_batch(ctx, oracle):
         assert_bitexact(d_out[i][:res[i].n_out].cpu().numpy(), want, f"batch {i}")
         assert plan.sync_positions(i).tolist() == st["sync_pos"].tolist()
     plan.close()
+
+
+# ------------------------------------------------------------------ exact fast envelope
+def _plan_inv_sinphi(profile, rate=48000):
+    torch = pytest.importorskip("torch")
+    x = torch.zeros(rate * 12, dtype=torch.float32, device="cuda:0")
+    plan = apt.Plan(apt.Settings.profile(profile), apt.Rate.hz(rate), True, max_samples=x.numel(), max_batch=1)
+    cap = int(plan.info.max_rows)
+    rows = torch.empty(cap * 2080, dtype=torch.float32, device="cuda:0")
+    plan.decode_device([x.data_ptr()], [x.numel()], [rows.data_ptr()], [cap])
+    plan.results(1)
+    v = float(plan.read_internal("inv_sinphi", np.float32, 1)[0])
+    plan.close()
+    return v
+
+
+@pytest.mark.parametrize("profile", ["standard", "fast", "slow"])
+def test_fast_exact_divide_is_verified_and_used(profile):
+    """The reciprocal-plus-correction divide is only switched on for a sin(phi) that passed the
+    exhaustive 2^24-significand check at plan creation; the three stock profiles do."""
+    s = apt.Settings.profile(profile)
+    phi = np.float32(2.0) * (np.float32(2.0) * np.float32(2400.0) / np.float32(s.work_rate) * np.float32(np.pi))
+    want = np.float32(1.0) / np.sin(phi, dtype=np.float32)
+    got = _plan_inv_sinphi(profile)
+    assert got != 0.0
+    assert abs(got - float(want)) <= 2e-7 * abs(float(want))
+
+
+@pytest.mark.parametrize("scale,what", [(1e-25, "denormal-range radicands"), (3e14, "radicands past 2^100"),
+                                        (1.0, "half digital silence")])
+def test_envelope_out_of_range_values_take_the_general_path(ctx, oracle, scale, what):
+    """Radicands outside [2^-96, 2^100] (and exact zeros) leave the fast exact envelope and go
+    through the general correctly rounded code, wave by wave: still bit-identical."""
+    x = synth_apt(48000, 14, seed=33)
+    if what == "half digital silence":
+        x = x.copy()
+        x[x.size // 3: 2 * x.size // 3] = 0.0
+    else:
+        x = (x * np.float32(scale)).astype(np.float32)
+    for sync in (True, False):
+        try:
+            want = oracle.decode(x, 48000, sync)
+        except Exception as e:  # "less than 5 sync frames" on both sides then
+            with pytest.raises(apt.InternalError, match=str(e)[:30]):
+                apt.decode(ctx, apt.Settings(), x, apt.Rate.hz(48000), sync)
+            continue
+        got = apt.decode(ctx, apt.Settings(), x, apt.Rate.hz(48000), sync)
+        assert_bitexact(got, want, f"{what} sync={sync}")
+
+
+def test_general_envelope_forced(oracle, monkeypatch):
+    """APTGPU_GENERAL_ENVELOPE=1 keeps the compiler's general sqrt / divide everywhere."""
+    monkeypatch.setenv("APTGPU_GENERAL_ENVELOPE", "1")
+    for rate in (48000, 11025):
+        x = synth_apt(rate, 14, seed=3)
+        got = apt.decode(apt.Context(device=0), apt.Settings(), x, apt.Rate.hz(rate), True)
+        assert_bitexact(got, oracle.decode(x, rate, True), f"general envelope {rate}")
+    assert _plan_inv_sinphi("standard") == 0.0
