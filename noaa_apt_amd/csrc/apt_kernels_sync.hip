@@ -64,7 +64,6 @@ k_group_max(const float *__restrict__ corr, uint64_t n_corr, float *__restrict__
 // ------------------------------------------------------------------ k_sync_nodes
 constexpr int kNodesThreads = 128;
 constexpr int kChunkGroups = 128;  // own groups per workgroup
-constexpr int kRMax = 416;         // md/GS <= 416  (work_rate <= 54080)
 constexpr int kSlotCap = 64;       // node terminals kept per chunk before "overflow"
 
 __global__ void __launch_bounds__(kNodesThreads)
