@@ -467,3 +467,68 @@ def test_general_envelope_forced(oracle, monkeypatch):
         got = apt.decode(apt.Context(device=0), apt.Settings(), x, apt.Rate.hz(rate), True)
         assert_bitexact(got, oracle.decode(x, rate, True), f"general envelope {rate}")
     assert _plan_inv_sinphi("standard") == 0.0
+
+
+# ------------------------------------------------------------------ threads / graph capture
+def test_decode_is_reentrant_across_threads(oracle):
+    """aptgpu_decode from several host threads at once (the GUI calls it from a worker thread,
+    gui/work.rs:174): every call owns its plan, stream and buffers."""
+    import threading
+    recs = [synth_apt(48000, 12 + i, seed=60 + i) for i in range(4)]
+    wants = [oracle.decode(r, 48000, True) for r in recs]
+    out, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                out[i] = apt.decode(apt.Context(device=0), apt.Settings(), recs[i], apt.Rate.hz(48000), True)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        assert_bitexact(out[i], wants[i], f"thread {i}")
+
+
+def test_plan_decode_captured_in_a_hip_graph(oracle):
+    """decode_device + join issue no host synchronisation, so the whole fork/join over the
+    plan's internal streams can be captured from ctx.stream into a graph and replayed."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    recs = [synth_apt(48000, 12 + i, seed=80 + i) for i in range(2)]
+    n = max(r.size for r in recs)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        plan = apt.Plan(apt.Settings(), apt.Rate.hz(48000), True, max_samples=n, max_batch=2,
+                        stream=stream.cuda_stream)
+        cap = int(plan.info.max_rows)
+        d_in = [torch.zeros(n, dtype=torch.float32, device=dev) for _ in recs]
+        d_rows = [torch.zeros(cap * 2080, dtype=torch.float32, device=dev) for _ in recs]
+        args = ([t.data_ptr() for t in d_in], [r.size for r in recs], [t.data_ptr() for t in d_rows], [cap] * 2)
+        plan.decode_device(*args)  # warm-up outside the capture (lazy allocations, attributes)
+        plan.join()
+        stream.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            plan.decode_device(*args)
+            plan.join()
+        for rep in range(2):
+            for t, r in zip(d_in, recs):
+                t[:r.size].copy_(torch.from_numpy(r if rep == 0 else r[::-1].copy()))
+            for t in d_rows:
+                t.zero_()
+            graph.replay()
+            stream.synchronize()
+            for i, r in enumerate(recs):
+                src = r if rep == 0 else r[::-1].copy()
+                try:
+                    want = oracle.decode(src, 48000, True)
+                except Exception:
+                    continue
+                assert_bitexact(d_rows[i][:want.size].cpu().numpy(), want, f"graph replay {rep} rec {i}")
+    plan.close()
