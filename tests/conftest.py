@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Build libaptgpu.so (hipcc cross-compiles without a GPU) when a fresh checkout has none:
+    the host-side tests (C-ABI symbols, FIR design, WAV header walk) load it."""
+    import noaa_apt_amd as apt
+    if not os.path.exists(apt.lib_path()):
+        apt.build()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU parity oracle (oracle/libaptoracle.so), built on demand."""
