@@ -22,6 +22,11 @@
 //   stage 4  C[k] = sum_{j<G} +-F[k+j]                    (decode.rs:225-233), same blocking
 //   stage 5  owned F and C -> HBM (coalesced), GM[g] = max of C over 52 positions
 //
+// LDS layout of A and B: logical index i lives at i + i/KPT (one pad word after every KPT), so a
+// thread's block of KPT consecutive outputs starts at an ODD multiple-of-words stride from its
+// neighbour's: the register-blocked stages read conflict-free (unpadded, a stride of 8 floats
+// put 64 lanes on 4 banks and made stage 4 three times slower than everything else together).
+//
 // Why zero-filling is exact: a running sum that starts at +0.0 can never be -0.0 (x + y is
 // -0.0 only if both are), so adding the +-0.0 product of a zero-filled sample (inputs at or
 // past n, which the reference skips, dsp.rs:257; D[k <= 0], which the `i > j` guard of
@@ -54,6 +59,13 @@ struct AnyGeom {
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+
+// padded LDS offset of logical element e relative to a block-aligned base (floor division)
+template <int KPT>
+__host__ __device__ constexpr int pad_ofs(int e)
+{
+    return e + (e >= 0 ? e / KPT : -((-e + KPT - 1) / KPT));
+}
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F &&f)
@@ -91,6 +103,7 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
     float *X = lds + G.off_x;
     float *A = lds + G.off_a;  // R, then F
     float *B = lds + G.off_b;  // D, then C
+    auto P = [](int i) { return i + i / KPT; };  // padded LDS index (i >= 0)
     const int tid = threadIdx.x;
     const int64_t o0 = static_cast<int64_t>(blockIdx.x) * G.own;  // first owned work sample
     const int64_t t0 = o0 - G.pre;                                // work sample at tile index 0
@@ -105,7 +118,15 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
     const uint32_t xrel0 = static_cast<uint32_t>(X0 - xs0);  // may wrap by -1..: used only with ceil >= 1 or rb == 0
 
     // ---- stage 0
-    for (uint32_t q = tid; q < G.l * G.tpp; q += NTHR) T[q] = table[q];
+    {
+        // the table is 16-byte aligned in HBM and in LDS: 16-byte copies, several in flight
+        const uint32_t nt = G.l * G.tpp, nt4 = nt / 4;
+        const float4 *t4 = reinterpret_cast<const float4 *>(table);
+        float4 *l4 = reinterpret_cast<float4 *>(T);
+#pragma unroll 4
+        for (uint32_t q = tid; q < nt4; q += NTHR) l4[q] = t4[q];
+        for (uint32_t q = 4 * nt4 + tid; q < nt; q += NTHR) T[q] = table[q];
+    }
     if constexpr (sizeof(XT) == 4) {
         const float *xf = reinterpret_cast<const float *>(x);
         if ((reinterpret_cast<uintptr_t>(xf) & 15u) == 0) {
@@ -160,10 +181,22 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
                     const uint32_t cnt = G.jl_a + (p < G.jl_b ? 1u : 0u);
                     const float *row = T + p * G.tpp;
                     const float *xs = X + (xrel0 + c);
-                    for (uint32_t j = 0; j < cnt; ++j) sum = sum + row[j] * xs[j];
+                    // batches of 8 taps: sixteen LDS reads in flight, then the eight MACs in tap order
+                    uint32_t j = 0;
+                    for (; j + 8 <= cnt; j += 8) {
+                        float tv[8], xv[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            tv[e] = row[j + e];
+                            xv[e] = xs[j + e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sum = sum + tv[e] * xv[e];
+                    }
+                    for (; j < cnt; ++j) sum = sum + row[j] * xs[j];
                 }
             }
-            A[idx] = sum;
+            A[P(idx)] = sum;
         }
     }
     __syncthreads();
@@ -177,7 +210,7 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
             const int idx = tid + i * NTHR;
             const int64_t k = t0 + idx;
             const bool live = idx > 0 && k > 0 && k < static_cast<int64_t>(w);
-            xr[i] = live ? envelope_radicand(A[idx - 1], A[idx], cosphi2) : 1.f;
+            xr[i] = live ? envelope_radicand(A[P(idx - 1)], A[P(idx)], cosphi2) : 1.f;
             in_range = in_range && envelope_in_range(xr[i]);
         }
         if (__all(in_range)) {
@@ -186,7 +219,7 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
                 const int idx = tid + i * NTHR;
                 const int64_t k = t0 + idx;
                 const bool live = idx > 0 && k > 0 && k < static_cast<int64_t>(w);
-                B[idx] = live ? envelope_fast(xr[i], sinphi, inv_sinphi) : 0.f;
+                B[P(idx)] = live ? envelope_fast(xr[i], sinphi, inv_sinphi) : 0.f;
             }
         } else {
 #pragma unroll
@@ -194,7 +227,7 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
                 const int idx = tid + i * NTHR;
                 const int64_t k = t0 + idx;
                 const bool live = idx > 0 && k > 0 && k < static_cast<int64_t>(w);
-                B[idx] = live ? envelope_general(xr[i], sinphi) : 0.f;
+                B[P(idx)] = live ? envelope_general(xr[i], sinphi) : 0.f;
             }
         }
     }
@@ -212,12 +245,16 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
             f2 fa[NP];
 #pragma unroll
             for (int pp = 0; pp < NP; ++pp) fa[pp] = (f2){0.f, 0.f};
-            const float *src = B + b0;
+            const float *src = B + P(b0);  // b0 is a multiple of KPT: element e sits at pad(e)
             static_for<0, (DW + CH - 1) / CH>([&](auto cc) {
                 constexpr int hi = KPT - 1 - decltype(cc)::value * CH;
                 float dv[CH];
-#pragma unroll
-                for (int q = 0; q < CH; ++q) dv[q] = (hi - q >= -(T2C - 1)) ? src[hi - q] : 0.f;
+                static_for<0, CH>([&](auto qq) {
+                    constexpr int q = decltype(qq)::value;
+                    constexpr int e = hi - q;
+                    if constexpr (e >= -(T2C - 1)) dv[q] = src[pad_ofs<KPT>(e)];
+                    else dv[q] = 0.f;
+                });
                 static_for<0, CH>([&](auto ee) {
                     constexpr int e = hi - decltype(ee)::value;
                     if constexpr (e >= -(T2C - 1)) {
@@ -241,8 +278,8 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
             });
 #pragma unroll
             for (int pp = 0; pp < NP; ++pp) {
-                A[b0 + 2 * pp] = fa[pp].x;
-                A[b0 + 2 * pp + 1] = fa[pp].y;
+                A[P(b0) + 2 * pp] = fa[pp].x;
+                A[P(b0) + 2 * pp + 1] = fa[pp].y;
             }
         }
     } else
@@ -253,17 +290,11 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
 #pragma unroll
             for (int u = 0; u < KPT; ++u) acc[u] = 0.f;
             for (uint32_t j0 = 0; j0 < G.t2; j0 += KPT) {
-                // 2*KPT floats from a 16-byte aligned address (b0, j0 and KPT are multiples of 4)
+                // 2*KPT logical elements from a block-aligned base (b0, j0 multiples of KPT)
                 float win[2 * KPT];
-                const float4 *src = reinterpret_cast<const float4 *>(B + (b0 - static_cast<int>(j0) - KPT));
+                const float *src = B + P(b0 - static_cast<int>(j0) - KPT);
 #pragma unroll
-                for (int e = 0; e < 2 * KPT / 4; ++e) {
-                    const float4 v = src[e];
-                    win[4 * e] = v.x;
-                    win[4 * e + 1] = v.y;
-                    win[4 * e + 2] = v.z;
-                    win[4 * e + 3] = v.w;
-                }
+                for (int e = 0; e < 2 * KPT; ++e) win[e] = src[e + e / KPT];
 #pragma unroll
                 for (int jj = 0; jj < KPT; ++jj) {
                     if (j0 + jj < G.t2) {
@@ -275,7 +306,7 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
             }
             // A (R) was last read in stage 2, before the barrier above: safe to overwrite with F
 #pragma unroll
-            for (int u = 0; u < KPT; ++u) A[b0 + u] = acc[u];
+            for (int u = 0; u < KPT; ++u) A[P(b0) + u] = acc[u];
         }
     }
     __syncthreads();
@@ -283,9 +314,9 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
     // ---- stage 5a: owned F -> HBM
     for (uint32_t q = tid * 4; q < G.own; q += NTHR * 4) {
         const uint64_t k = static_cast<uint64_t>(o0) + q;
-        const float *src = A + G.pre + q;
+        const float *src = A + P(static_cast<int>(G.pre + q));  // 4 | KPT: the quad stays inside one block
         if (k + 3 < w) {
-            *reinterpret_cast<float4 *>(f_out + k) = *reinterpret_cast<const float4 *>(src);
+            *reinterpret_cast<float4 *>(f_out + k) = make_float4(src[0], src[1], src[2], src[3]);
         } else {
             for (int e = 0; e < 4; ++e)
                 if (k + e < w) f_out[k + e] = src[e];
@@ -306,12 +337,15 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
             f2 ca[NP];
 #pragma unroll
             for (int pp = 0; pp < NP; ++pp) ca[pp] = (f2){0.f, 0.f};
-            const float *src = A + b0;
+            const float *src = A + P(b0);
             static_for<0, (FW + CH - 1) / CH>([&](auto cc) {
                 constexpr int q0 = decltype(cc)::value * CH;
                 float fv[CH];
-#pragma unroll
-                for (int q = 0; q < CH; ++q) fv[q] = (q0 + q < FW) ? src[q0 + q] : 0.f;
+                static_for<0, CH>([&](auto qq) {
+                    constexpr int q = decltype(qq)::value;
+                    if constexpr (q0 + q < FW) fv[q] = src[pad_ofs<KPT>(q0 + q)];
+                    else fv[q] = 0.f;
+                });
                 static_for<0, CH>([&](auto ee) {
                     constexpr int e = q0 + decltype(ee)::value;
                     if constexpr (e < FW) {
@@ -335,8 +369,8 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
             });
 #pragma unroll
             for (int pp = 0; pp < NP; ++pp) {
-                B[b0 + 2 * pp] = ca[pp].x;
-                B[b0 + 2 * pp + 1] = ca[pp].y;
+                B[P(b0) + 2 * pp] = ca[pp].x;
+                B[P(b0) + 2 * pp + 1] = ca[pp].y;
             }
         }
     } else
@@ -348,15 +382,9 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
             for (int u = 0; u < KPT; ++u) acc[u] = 0.f;
             for (uint32_t j0 = 0; j0 < G.g; j0 += KPT) {
                 float win[2 * KPT];
-                const float4 *src = reinterpret_cast<const float4 *>(A + (b0 + static_cast<int>(j0)));
+                const float *src = A + P(b0 + static_cast<int>(j0));
 #pragma unroll
-                for (int e = 0; e < 2 * KPT / 4; ++e) {
-                    const float4 v = src[e];
-                    win[4 * e] = v.x;
-                    win[4 * e + 1] = v.y;
-                    win[4 * e + 2] = v.z;
-                    win[4 * e + 3] = v.w;
-                }
+                for (int e = 0; e < 2 * KPT; ++e) win[e] = src[e + e / KPT];
                 const uint64_t signs = G.sign[j0 >> 6] >> (j0 & 63);  // KPT divides 64: no straddling
 #pragma unroll
                 for (int jj = 0; jj < KPT; ++jj) {
@@ -374,7 +402,7 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
                 }
             }
 #pragma unroll
-            for (int u = 0; u < KPT; ++u) B[b0 + u] = acc[u];
+            for (int u = 0; u < KPT; ++u) B[P(b0) + u] = acc[u];
         }
     }
     __syncthreads();
@@ -382,9 +410,9 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
     // ---- stage 5b: owned C -> HBM, group maxima
     for (uint32_t q = tid * 4; q < G.own; q += NTHR * 4) {
         const uint64_t k = static_cast<uint64_t>(o0) + q;
-        const float *src = B + G.pre + q;
+        const float *src = B + P(static_cast<int>(G.pre + q));
         if (k + 3 < n_corr) {
-            *reinterpret_cast<float4 *>(c_out + k) = *reinterpret_cast<const float4 *>(src);
+            *reinterpret_cast<float4 *>(c_out + k) = make_float4(src[0], src[1], src[2], src[3]);
         } else {
             for (int e = 0; e < 4; ++e)
                 if (k + e < n_corr) c_out[k + e] = src[e];
@@ -393,14 +421,16 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
     for (uint32_t g = tid; g < G.own / kGS; g += NTHR) {
         const uint64_t k = static_cast<uint64_t>(o0) + static_cast<uint64_t>(g) * kGS;
         if (k >= n_corr) break;
-        const float *src = B + G.pre + g * kGS;
+        const int base = static_cast<int>(G.pre + g * kGS);
+        float cv[kGS];
+#pragma unroll
+        for (int o = 0; o < kGS; ++o) cv[o] = B[P(base + o)];  // all 52 reads in flight
         float mx = kNegInfAny;
+#pragma unroll
         for (int o = 0; o < kGS; ++o) {
-            if (k + o < n_corr) {
-                float v = src[o];
-                if (k + o == 0 && !(v > 0.f)) v = 0.f;  // the picker starts from the peak (0, 0.)
-                mx = fmaxf(mx, v);
-            }
+            float v = cv[o];
+            if (k + o == 0 && !(v > 0.f)) v = 0.f;  // the picker starts from the peak (0, 0.)
+            mx = (k + o < n_corr) ? fmaxf(mx, v) : mx;
         }
         gm_out[static_cast<uint64_t>(o0) / kGS + g] = mx;
     }
@@ -428,15 +458,17 @@ bool make_geom(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, in
     g.pulse = 2 * pw;
     g.kt = static_cast<uint32_t>(nthr * kpt);
     if (38 * pw > 256) return false;  // sign bitmap
-    g.pre = (t2 + 2 * static_cast<uint32_t>(kpt) + 3u) & ~3u;
+    g.pre = (t2 + 2 * static_cast<uint32_t>(kpt) + static_cast<uint32_t>(kpt) - 1) / static_cast<uint32_t>(kpt) *
+            static_cast<uint32_t>(kpt);  // multiple of KPT (and of 4)
     if (g.kt < g.pre + g.g + kGS) return false;
     g.own = (g.kt - g.pre - (g.g - 1)) / kGS * kGS;
     if (g.own == 0) return false;
     g.xt = (static_cast<uint32_t>((static_cast<uint64_t>(g.kt) * m + l - 1) / l) + per_phase + 8 + 3) & ~3u;
     const uint32_t slack = 64;
     g.off_x = (l * g.tpp + 3u) & ~3u;
+    const uint32_t ab_len = ((g.kt + slack) + (g.kt + slack) / static_cast<uint32_t>(kpt) + 8u) & ~3u;  // padded
     g.off_a = g.off_x + g.xt;
-    g.off_b = g.off_a + g.kt + slack;
+    g.off_b = g.off_a + ab_len;
     g.step_q = static_cast<uint32_t>((static_cast<uint64_t>(nthr) * m) / l);
     g.step_r = static_cast<uint32_t>((static_cast<uint64_t>(nthr) * m) % l);
     g.jl_a = g.jlim / l;
@@ -445,7 +477,7 @@ bool make_geom(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, in
         const bool plus = j >= g.pulse && j < 15 * g.pulse && (((j - g.pulse) / g.pulse) & 1) == 1;
         if (plus) g.sign[j >> 6] |= 1ull << (j & 63);
     }
-    const size_t floats = static_cast<size_t>(g.off_b) + g.kt + slack;
+    const size_t floats = static_cast<size_t>(g.off_b) + ab_len;
     *lds_bytes = floats * sizeof(float);
     *out = g;
     return *lds_bytes <= kLdsLimit;
@@ -540,7 +572,9 @@ bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uin
     if (pcm16 && (reinterpret_cast<uintptr_t>(x) & 1u)) return false;
     const float *xf = static_cast<const float *>(x);
     const int16_t *xi = static_cast<const int16_t *>(x);
-    const bool standard = t2 == 37 && pw == 3;  // the standard profile's W-rate stages, any input rate
+    // the W-rate stages of the three stock profiles (default_settings.toml:108-140) at any input
+    // rate are instantiated with compile-time lengths; anything else takes the run-time loops
+    const int prof = (t2 == 37 && pw == 3) ? 1 : (t2 == 43 && pw == 4) ? 2 : (t2 == 61 && pw == 5) ? 3 : 0;
 #define APT_ANY_LAUNCH(NT, KP, T2C, PWC)                                                                       \
     do {                                                                                                       \
         if (pcm16)                                                                                             \
@@ -553,7 +587,9 @@ bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uin
     } while (0)
 #define APT_ANY_CASE(NT, KP)                     \
     if (c.nthr == NT && c.kpt == KP) {           \
-        if (standard) APT_ANY_LAUNCH(NT, KP, 37, 3); \
+        if (prof == 1) APT_ANY_LAUNCH(NT, KP, 37, 3); \
+        if (prof == 2) APT_ANY_LAUNCH(NT, KP, 43, 4); \
+        if (prof == 3) APT_ANY_LAUNCH(NT, KP, 61, 5); \
         APT_ANY_LAUNCH(NT, KP, 0, 0);            \
     }
     APT_ANY_CASE(256, 8)
