@@ -106,3 +106,22 @@ def test_product_does_not_touch_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(ROOT, "noaa_apt_amd", fn)).read()
             assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_c_example_compiles_against_the_header(tmp_path):
+    """examples/aptgpu_decode.c is plain C99: the header must be C-clean (-pedantic) and the
+    library must link without Python or PyTorch."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = tmp_path / "aptgpu_decode"
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-pedantic", "-Werror",
+                           "-I", os.path.join(root, "include"), "-o", str(exe),
+                           os.path.join(root, "examples", "aptgpu_decode.c"),
+                           "-L", os.path.dirname(apt.lib_path()), "-laptgpu",
+                           "-Wl,-rpath," + os.path.dirname(apt.lib_path()), "-Wl,-rpath,/opt/rocm/lib"])
+    # usage message without arguments (no GPU needed)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage:" in r.stderr

@@ -246,3 +246,34 @@ def test_resample_wav_files_and_errors(ow, tmp_path):
         apt.resample_wav(None, s, make_wav(np.zeros(1000, np.int16), 99371), None, 93911)
     with pytest.raises(apt.IoError):
         apt.resample_wav(None, s, str(tmp_path / "nope.wav"), str(dst), 8000)
+
+
+def test_c_example_wav_to_pgm(oracle, ow, tmp_path):
+    """The plain-C caller (examples/aptgpu_decode.c): WAV file in, PGM out, identical to the
+    oracle's decode -> 98 % contrast -> u8 image."""
+    import os
+    import shutil
+    import subprocess
+    from oracle import image_binding as oi
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "aptgpu_decode"
+    libdir = os.path.dirname(apt.lib_path())
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-I", os.path.join(root, "include"), "-o", str(exe),
+                           os.path.join(root, "examples", "aptgpu_decode.c"), "-L", libdir, "-laptgpu",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    x = synth_apt(11025, 130, seed=12)
+    wav = tmp_path / "pass.wav"
+    wav.write_bytes(make_wav(_pcm16(x), 11025))
+    for contrast, kind in (("percent", oi.CONTRAST_PERCENT), ("telemetry", oi.CONTRAST_TELEMETRY)):
+        pgm = tmp_path / f"{contrast}.pgm"
+        r = subprocess.run([str(exe), str(wav), str(pgm), contrast], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "Resampling to 12480" in r.stderr and "Generating image" in r.stderr
+        rows = oracle.decode(ow.load_wav(wav.read_bytes())[0], 11025, True)
+        want, lo, hi = oi.process_gray(rows, kind, 0.98)
+        data = pgm.read_bytes()
+        header = f"P5\n2080 {rows.size // 2080}\n255\n".encode()
+        assert data.startswith(header)
+        assert data[len(header):] == want.tobytes()
