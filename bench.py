@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--inputs", type=int, default=4,
                     help="distinct recordings resident in HBM, decoded round-robin (4 x 115 MB exceeds "
                          "the 256 MB Infinity Cache, so every step reads its input from HBM)")
+    ap.add_argument("--user-stream", action="store_true",
+                    help="experiment: give the plan torch's stream as ctx.stream (every call then waits for "
+                         "an event recorded there; the inputs are synchronised before timing anyway)")
     ap.add_argument("--no-sync", action="store_true",
                     help="experiment: decode(sync=false) — front end + final resample only, no peak picker")
     ap.add_argument("--no-extras", action="store_true",
@@ -86,9 +89,10 @@ def main():
         d_x = d_xs[0]
         mode = {"strict": apt.MODE_STRICT, "generic": apt.MODE_GENERIC, "fp16taps": apt.MODE_FP16_TAPS}[args.mode]
         plan = apt.Plan(settings, rate, not args.no_sync, max_samples=n, max_batch=1, device=local_rank,
-                        mode=mode, stream=stream.cuda_stream)
+                        mode=mode, stream=stream.cuda_stream if args.user_stream else 0)
         cap = int(plan.info.max_rows)
         d_rows = torch.empty(cap * 2080, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()  # inputs are resident before anything is enqueued on the plan's streams
         sigs, nn, out, caps = [[d.data_ptr()] for d in d_xs], [n], [d_rows.data_ptr()], [cap]
         counter = [0]
 
