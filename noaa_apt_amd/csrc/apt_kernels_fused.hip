@@ -25,6 +25,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <type_traits>
 
 #pragma clang fp contract(off)
@@ -96,6 +97,15 @@ __host__ __device__ constexpr bool branch_uses(int b, int q)
     return i >= 0 && branch_phase<L, M>(b) + i * L < T1;
 }
 
+// first branch that uses window sample 2c or 2c+1 (fp16 stage 1 works on sample pairs); L if none
+template <int L, int M, int T1>
+__host__ __device__ constexpr int first_branch_of_pair(int c)
+{
+    for (int b = 0; b < L; ++b)
+        if (branch_uses<L, M, T1>(b, 2 * c) || branch_uses<L, M, T1>(b, 2 * c + 1)) return b;
+    return L;
+}
+
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // sign of the sync template at index j (decode.rs:188-198): + inside the seven high pulses
@@ -109,11 +119,17 @@ __host__ __device__ constexpr bool sync_plus(int j)
 
 // XT = float: the f32 Signal; XT = int16_t: mono PCM16 straight from the WAV data chunk
 // (`*x as f32`, wav.rs:37), which halves the compulsory input bytes.
-template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT>
+// F16 (APTGPU_MODE_FP16_TAPS, BASELINE config 5): stage 1 only runs on fp16 taps (power-of-two
+// prescaled) and fp16-rounded samples through v_dot2_f32_f16 with f32 accumulation — one
+// instruction per two taps of one output instead of a packed mul + add per tap of two outputs,
+// about half the stage-1 instructions; `hs` then holds [ceil(WIN/2)][16] half2 tap pairs.
+// Tolerance-based, not bit-exact; every other stage stays strict.
+template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, bool F16>
 __global__ void __launch_bounds__(NTHR, (APT_FUSED_MIN_WAVES * NTHR + 255) / 256)
 k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][PS] tap pairs*/,
         const float *__restrict__ h2 /*[T2]*/, const f2 *__restrict__ h2p /*[T2+1] (h2[m-1], h2[m])*/,
         float cosphi2, float sinphi, float inv_sinphi /* verified RN(1/sinphi), or 0 */,
+        float f16_unscale /* 2^-s of the fp16 tap prescale (F16 only) */,
         float *__restrict__ f_out, float *__restrict__ c_out, float *__restrict__ gm_out,
         uint64_t w, uint64_t n_corr)
 {
@@ -185,6 +201,56 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
     const int kq = tid * L;        // this thread's first work sample, tile-relative
     const int kt = kq - k_lo;      // ... and as a global work-sample index clamped to int
     float r[L];
+    if constexpr (F16) {
+        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+        constexpr int NQP = (Gm::WIN + 1) / 2;  // window sample pairs
+        const float *src = P + tid * M;
+        const uint32_t *ht = reinterpret_cast<const uint32_t *>(hs);  // [NQP][16] half2 bit patterns
+        float acc[L];
+#pragma unroll
+        for (int b = 0; b < L; ++b) acc[b] = 0.f;
+        uint4 tb[2][4];  // tap pairs of the sample pair in use / in flight (16 SGPRs each)
+        float xa[2], xb[2];
+        static_assert(L <= 16, "one 16-dword table row per sample pair");
+        auto dot2 = [](float &a, uint32_t tap_pair /*SGPR*/, h2v x_pair) {
+            asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(a) : "s"(tap_pair), "v"(x_pair));
+        };
+        auto tapw = [&](int buf, int b) -> uint32_t {
+            const uint4 v = tb[buf][b >> 2];
+            return (b & 3) == 0 ? v.x : (b & 3) == 1 ? v.y : (b & 3) == 2 ? v.z : v.w;
+        };
+        auto issue = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int buf = c & 1;
+            xa[buf] = src[2 * c];
+            xb[buf] = (2 * c + 1 < Gm::WIN) ? src[2 * c + 1] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tb[buf][k] = reinterpret_cast<const uint4 *>(ht)[c * 4 + k];
+        };
+        issue(std::integral_constant<int, 0>{});
+        static_for<0, NQP>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int buf = c & 1;
+            const h2v xh = {static_cast<_Float16>(xa[buf]), static_cast<_Float16>(xb[buf])};
+            // the first dot forces the wait for the loads issued one pair ago
+            // (asm volatile pins the dots between the scheduling barriers: as plain intrinsics the
+            // compiler sank all 793 of them behind the loads and spilled 750 SGPRs)
+            // only the branches whose taps reach one of the two samples (the others hold zeros)
+            constexpr int b0 = first_branch_of_pair<L, M, T1>(c);
+            if constexpr (b0 < L) dot2(acc[b0], tapw(buf, b0), xh);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (c + 1 < NQP) issue(std::integral_constant<int, c + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, L>([&](auto bb) {
+                constexpr int b = decltype(bb)::value;
+                if constexpr (b > b0 && (branch_uses<L, M, T1>(b, 2 * c) || branch_uses<L, M, T1>(b, 2 * c + 1)))
+                    dot2(acc[b], tapw(buf, b), xh);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int b = 0; b < L; ++b) r[b] = (kq + b < k_lo || kq + b >= k_hi) ? 0.f : acc[b] * f16_unscale;
+    } else
     {
         // Software pipeline over chunks of CH window samples: SMEM returns out of order, so the
         // only usable wait is lgkmcnt(0).  Each chunk therefore (1) consumes its first tap —
@@ -505,16 +571,16 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
     }
 }
 
-template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT>
+template <int L, int M, int T1, int T2, int PW, int NTHR, bool F16 = false, typename XT>
 void launch_fused(hipStream_t s, const XT *x, uint64_t n, const float *hb, const float *h2,
-                  const float *h2p, float cosphi2, float sinphi, float inv_sinphi, float *f_out, float *c_out,
-                  float *gm_out, uint64_t w,
+                  const float *h2p, float cosphi2, float sinphi, float inv_sinphi, float f16_unscale, float *f_out,
+                  float *c_out, float *gm_out, uint64_t w,
                   uint64_t n_corr)
 {
     using Gm = FusedGeom<L, M, T1, T2, PW, NTHR>;
     constexpr int kFusedThreads = NTHR;
     const size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
-    auto kern = k_fused<L, M, T1, T2, PW, NTHR, XT>;
+    auto kern = k_fused<L, M, T1, T2, PW, NTHR, XT, F16>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -523,7 +589,7 @@ void launch_fused(hipStream_t s, const XT *x, uint64_t n, const float *hb, const
     }
     const unsigned tiles = static_cast<unsigned>((w + Gm::OWN_K - 1) / Gm::OWN_K);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(kFusedThreads), lds, s, x, n, reinterpret_cast<const f2 *>(hb), h2,
-                       reinterpret_cast<const f2 *>(h2p), cosphi2, sinphi, inv_sinphi,
+                       reinterpret_cast<const f2 *>(h2p), cosphi2, sinphi, inv_sinphi, f16_unscale,
                        f_out, c_out, gm_out, w, n_corr);
 }
 
@@ -581,30 +647,84 @@ void fused_lowpass_pairs(const float *h2, uint32_t t2, float *h2p)
     }
 }
 
+uint32_t fused_f16_table_dwords(uint32_t l, uint32_t m, uint32_t t1)
+{
+    const uint32_t tp = (t1 + l - 1) / l;
+    const uint32_t clast = ((l - 1) * m + l - 1) / l;
+    return ((clast + tp + 1) / 2) * 16;
+}
+
+// host: [ceil(WIN/2)][16] half2 bit patterns — entry (qp, b) = taps of branch b at window samples
+// (2qp, 2qp+1), prescaled by a power of two into the fp16 normal range; returns 2^-s
+float fused_f16_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, uint32_t *table)
+{
+    const uint32_t tp = (t1 + l - 1) / l;
+    const uint32_t clast = ((l - 1) * m + l - 1) / l;
+    const uint32_t win = clast + tp;
+    auto tap = [&](uint32_t b, uint32_t q) -> float {
+        const uint32_t cb = (b * m + l - 1) / l;
+        const uint32_t pb = cb * l - b * m;
+        if (q < cb || q >= win) return 0.f;
+        const uint64_t j = pb + static_cast<uint64_t>(q - cb) * l;
+        return j < t1 ? coeff[j] : 0.f;
+    };
+    float mx = 0.f;
+    for (uint32_t j = 0; j < t1; ++j) mx = fmaxf(mx, fabsf(coeff[j]));
+    int e = 0;
+    if (mx > 0.f) (void)frexpf(mx, &e);
+    const int sh = -e + 1;  // scaled maximum in [1, 2)
+    const float scale = ldexpf(1.f, sh);
+    auto bits = [](float v) -> uint32_t {
+        const _Float16 h = static_cast<_Float16>(v);
+        uint16_t u;
+        __builtin_memcpy(&u, &h, 2);
+        return u;
+    };
+    const uint32_t nqp = (win + 1) / 2;
+    for (uint32_t qp = 0; qp < nqp; ++qp)
+        for (uint32_t b = 0; b < 16; ++b)
+            table[qp * 16 + b] = b < l ? (bits(tap(b, 2 * qp) * scale) | (bits(tap(b, 2 * qp + 1) * scale) << 16)) : 0u;
+    return ldexpf(1.f, -sh);
+}
+
+bool fused_f16_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
+{
+    return l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3;
+}
+
 bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
                      const void *x, bool pcm16, uint64_t n, const float *hb, const float *h2, const float *h2p,
-                     float cosphi2, float sinphi, float inv_sinphi, float *f_out, float *c_out, float *gm_out,
-                     uint64_t w, uint64_t n_corr)
+                     float cosphi2, float sinphi, float inv_sinphi, float f16_unscale, float *f_out, float *c_out,
+                     float *gm_out, uint64_t w, uint64_t n_corr)
 {
     const float *xf = static_cast<const float *>(x);
     const int16_t *xi = static_cast<const int16_t *>(x);
     if (pcm16 && (reinterpret_cast<uintptr_t>(x) & 3u)) return false;  // dword loads of sample pairs
     if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
+        if (f16_unscale != 0.f) {  // fp16-tap stage 1: hb is the half2 table of fused_f16_branch_taps
+            if (pcm16)
+                launch_fused<13, 50, 959, 37, 3, 256, true>(s, xi, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi,
+                                                            f16_unscale, f_out, c_out, gm_out, w, n_corr);
+            else
+                launch_fused<13, 50, 959, 37, 3, 256, true>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi,
+                                                            f16_unscale, f_out, c_out, gm_out, w, n_corr);
+            return true;
+        }
         if (pcm16)
-            launch_fused<13, 50, 959, 37, 3, 256>(s, xi, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, c_out, gm_out, w,
-                                                  n_corr);
+            launch_fused<13, 50, 959, 37, 3, 256>(s, xi, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, f_out, c_out,
+                                                  gm_out, w, n_corr);
         else
-            launch_fused<13, 50, 959, 37, 3, 256>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, c_out, gm_out, w,
-                                                  n_corr);
+            launch_fused<13, 50, 959, 37, 3, 256>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, f_out, c_out,
+                                                  gm_out, w, n_corr);
         return true;
     }
     if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3) {
         // twice the input per work sample: 128-thread workgroups keep the x tile at 51.8 KB
         if (pcm16)
-            launch_fused<13, 100, 1915, 37, 3, 128>(s, xi, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, c_out, gm_out,
+            launch_fused<13, 100, 1915, 37, 3, 128>(s, xi, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, f_out, c_out, gm_out,
                                                     w, n_corr);
         else
-            launch_fused<13, 100, 1915, 37, 3, 128>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, c_out, gm_out,
+            launch_fused<13, 100, 1915, 37, 3, 128>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, f_out, c_out, gm_out,
                                                     w, n_corr);
         return true;
     }

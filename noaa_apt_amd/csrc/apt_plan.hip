@@ -203,8 +203,14 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
             plan->fused = 1;
         else if (eligible && gpu::fused_any_supported(plan->l, plan->m, t1, t2, plan->pw))
             plan->fused = 2;
+        // fp16-tap mode inside the specialised fused kernel where one exists (else the generic kernel)
+        if (plan->mode == APTGPU_MODE_FP16_TAPS && plan->l > 1 && plan->work_is_multiple &&
+            gpu::fused_f16_supported(plan->l, plan->m, t1, t2, plan->pw)) {
+            plan->fused = 1;
+            plan->fused_f16 = true;
+        }
     }
-    if (plan->mode == APTGPU_MODE_FP16_TAPS && plan->l > 1) {
+    if (plan->mode == APTGPU_MODE_FP16_TAPS && plan->l > 1) {  // (also the unfused step-export path of the fused fp16 mode)
         const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
         std::vector<uint16_t> tab(static_cast<size_t>(plan->l) * gpu::f16taps_pairs_per_phase(plan->l, t1) * 2 + 8, 0);
         plan->f16_unscale = gpu::f16taps_pack(plan->l, plan->taps_resample.data(), t1, tab.data());
@@ -230,7 +236,15 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     if (plan->fused == 1) {
         const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
         Signal hs(static_cast<size_t>(gpu::fused_tap_table_floats(plan->l, plan->m, t1)) + 16, 0.f);
-        gpu::fused_branch_taps(plan->l, plan->m, plan->taps_resample.data(), t1, hs.data());
+        if (plan->fused_f16) {
+            // same buffer, different content: half2 tap pairs as raw dwords
+            std::vector<uint32_t> tab(gpu::fused_f16_table_dwords(plan->l, plan->m, t1) + 16, 0u);
+            plan->f16_unscale = gpu::fused_f16_branch_taps(plan->l, plan->m, plan->taps_resample.data(), t1, tab.data());
+            hs.assign(tab.size(), 0.f);
+            std::memcpy(hs.data(), tab.data(), tab.size() * sizeof(uint32_t));
+        } else {
+            gpu::fused_branch_taps(plan->l, plan->m, plan->taps_resample.data(), t1, hs.data());
+        }
         upload(plan->d_taps_branch, hs);
         Signal h2p(2 * (plan->taps_lowpass.size() + 1) + 16, 0.f);
         gpu::fused_lowpass_pairs(plan->taps_lowpass.data(), static_cast<uint32_t>(plan->taps_lowpass.size()),
@@ -359,7 +373,8 @@ int aptgpu_plan::enqueue(int i, const Input &in, float *d_rows, uint64_t rows_ca
             float *gm_out = (sync && work_is_multiple) ? sl.gm.ptr : nullptr;
             if (fused == 1)
                 fused_front_end(cur, l, m, t1, t2, pw, xin, pcm16, n, d_taps_branch.ptr, d_taps_lowpass.ptr,
-                                d_taps_lowpass_pairs.ptr, cosphi2, sinphi, inv_sinphi, sl.filtered.ptr, c_out, gm_out, w,
+                                d_taps_lowpass_pairs.ptr, cosphi2, sinphi, inv_sinphi,
+                                fused_f16 ? f16_unscale : 0.f, sl.filtered.ptr, c_out, gm_out, w,
                                 w - n_sync_taps);
             else
                 fused_any_front_end(cur, l, m, t1, t2, pw, xin, pcm16, n, d_taps_any.ptr, d_taps_lowpass.ptr,

@@ -117,6 +117,7 @@ struct aptgpu_plan {
     uint32_t max_rows = 0;
     int max_batch = 1;
     float inv_sinphi = 0.f;  // RN(1/sinphi) if the fast exact divide verified for it, else 0 (apt_envelope.hpp)
+    bool fused_f16 = false;  // APTGPU_MODE_FP16_TAPS served by the specialised fused kernel (fp16 stage 1)
     int fused = 0;  // 0 unfused generic kernels, 1 compile-time specialised k_fused, 2 run-time k_fused_any
     // the front end is launched as this many consecutive tile ranges: each kernel boundary lets
     // the previous recording's single-workgroup orbit kernel (147 KB of LDS) grab a CU

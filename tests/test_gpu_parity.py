@@ -281,7 +281,8 @@ def test_decode_fp16_taps_mode(oracle, rate, seed):
     want, st = oracle.decode(x, rate, True, want_steps=True)
     c = apt.Context(device=0, mode=apt.MODE_FP16_TAPS)
     got, stats = apt.decode(c, apt.Settings(), x, apt.Rate.hz(rate), True, return_stats=True)
-    assert stats.fused == 0 and stats.n_sync == st["sync_pos"].size
+    # 48 kHz standard: fp16 stage 1 inside the specialised fused kernel; other rates: generic kernel
+    assert stats.fused == (1 if rate == 48000 else 0) and stats.n_sync == st["sync_pos"].size
     assert got.shape == want.shape
     err = np.max(np.abs(got - want)) / np.max(np.abs(want))
     assert err <= 2e-3, err
