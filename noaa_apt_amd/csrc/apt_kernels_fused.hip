@@ -61,7 +61,9 @@ __host__ __device__ constexpr int branch_phase(int b)  // p_b = c_b*L - b*M
     return branch_first<L, M>(b) * L - b * M;
 }
 
-template <int L, int M, int T1, int T2, int PW, int NTHR>
+// XB: bytes per input sample in the LDS tile (4: f32 Signal; 2: PCM16 kept as int16 — exact, and
+// half the tile, so the other regions set the footprint and 4 instead of 3 workgroups fit a CU)
+template <int L, int M, int T1, int T2, int PW, int NTHR, int XB = 4>
 struct FusedGeom {
     static constexpr int kFusedThreads = NTHR;
     static constexpr int kOwnThreads = NTHR - kPreThreads - kPostThreads;
@@ -75,10 +77,11 @@ struct FusedGeom {
     static constexpr int XT_PAD = (XT + 3) & ~3;
     static constexpr int G = 38 * PW;                                 // sync template length
     static constexpr int FWIN = L + G - 1;                            // F window per thread
-    // one LDS region: the x tile, then R/F at [0, TILE_K+G), D at D_OFF, C at C_OFF
+    // one LDS region: the x tile, then R/F at [0, TILE_K+G), D and later C at D_OFF
     static constexpr int D_OFF = (TILE_K + G + 3) & ~3;
-    static constexpr int C_OFF = D_OFF + TILE_K;
-    static constexpr int LDS_FLOATS = XT_PAD > (C_OFF + TILE_K) ? XT_PAD : (C_OFF + TILE_K);
+    static constexpr int C_OFF = D_OFF;  // C staging reuses D's region: D is dead once F is in P
+    static constexpr int XT_LDS = XB == 2 ? (XT_PAD / 2 + 4) : XT_PAD;  // floats of LDS under the x tile
+    static constexpr int LDS_FLOATS = XT_LDS > (C_OFF + TILE_K) ? XT_LDS : (C_OFF + TILE_K);
     static constexpr int GS = 4 * L;                                  // correlation group size
     static constexpr int NP = L / 2;                                  // accumulator pairs (+1 single if L odd)
     static constexpr int PS = NP;                                     // f2 tap entries per window sample
@@ -125,7 +128,7 @@ __host__ __device__ constexpr bool sync_plus(int j)
 // about half the stage-1 instructions; `hs` then holds [ceil(WIN/2)][16] half2 tap pairs.
 // Tolerance-based, not bit-exact; every other stage stays strict.
 template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, bool F16>
-__global__ void __launch_bounds__(NTHR, (APT_FUSED_MIN_WAVES * NTHR + 255) / 256)
+__global__ void __launch_bounds__(NTHR, ((sizeof(XT) == 2 ? 4 : APT_FUSED_MIN_WAVES) * NTHR + 255) / 256)
 k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][PS] tap pairs*/,
         const float *__restrict__ h2 /*[T2]*/, const f2 *__restrict__ h2p /*[T2+1] (h2[m-1], h2[m])*/,
         float cosphi2, float sinphi, float inv_sinphi /* verified RN(1/sinphi), or 0 */,
@@ -133,7 +136,7 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
         float *__restrict__ f_out, float *__restrict__ c_out, float *__restrict__ gm_out,
         uint64_t w, uint64_t n_corr)
 {
-    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR>;
+    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
     constexpr int kFusedThreads = NTHR;
     constexpr int kOwnThreads = Gm::kOwnThreads;
     extern __shared__ float lds[];
@@ -171,24 +174,25 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
             *reinterpret_cast<float4 *>(P + q) = v;
         }
     } else {
-        // PCM16: x is 4-byte aligned and xs0, q are even, so sample pairs load as one dword
+        // PCM16: the tile stays int16 in LDS (`*x as f32` happens when stage 1 reads it).  x is
+        // 4-byte aligned and xs0, q are even, so sample pairs move as dwords.
         const int16_t *xt = x + xs0;
+        uint32_t *X32 = reinterpret_cast<uint32_t *>(lds);
         for (int q = tid * 4; q < Gm::XT_PAD; q += kFusedThreads * 4) {
-            float4 v;
+            uint32_t a, b;
             if (q >= x_lo && q + 3 < x_hi) {
                 const uint32_t *pp = reinterpret_cast<const uint32_t *>(xt + q);
-                const uint32_t a = pp[0], b = pp[1];
-                v.x = static_cast<float>(static_cast<int16_t>(a & 0xffffu));
-                v.y = static_cast<float>(static_cast<int16_t>(a >> 16));
-                v.z = static_cast<float>(static_cast<int16_t>(b & 0xffffu));
-                v.w = static_cast<float>(static_cast<int16_t>(b >> 16));
+                a = pp[0];
+                b = pp[1];
             } else {
-                v.x = (q >= x_lo && q < x_hi) ? static_cast<float>(xt[q]) : 0.f;
-                v.y = (q + 1 >= x_lo && q + 1 < x_hi) ? static_cast<float>(xt[q + 1]) : 0.f;
-                v.z = (q + 2 >= x_lo && q + 2 < x_hi) ? static_cast<float>(xt[q + 2]) : 0.f;
-                v.w = (q + 3 >= x_lo && q + 3 < x_hi) ? static_cast<float>(xt[q + 3]) : 0.f;
+                auto at = [&](int i) -> uint32_t {
+                    return (i >= x_lo && i < x_hi) ? static_cast<uint32_t>(static_cast<uint16_t>(xt[i])) : 0u;
+                };
+                a = at(q) | (at(q + 1) << 16);
+                b = at(q + 2) | (at(q + 3) << 16);
             }
-            *reinterpret_cast<float4 *>(P + q) = v;
+            X32[q / 2] = a;
+            X32[q / 2 + 1] = b;
         }
     }
     __syncthreads();
@@ -204,7 +208,10 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
     if constexpr (F16) {
         typedef _Float16 h2v __attribute__((ext_vector_type(2)));
         constexpr int NQP = (Gm::WIN + 1) / 2;  // window sample pairs
-        const float *src = P + tid * M;
+        auto xsrc = [&](int q) -> float {
+            if constexpr (sizeof(XT) == 2) return static_cast<float>(reinterpret_cast<const int16_t *>(lds)[tid * M + q]);
+            else return P[tid * M + q];
+        };
         const uint32_t *ht = reinterpret_cast<const uint32_t *>(hs);  // [NQP][16] half2 bit patterns
         float acc[L];
 #pragma unroll
@@ -222,8 +229,8 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
         auto issue = [&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int buf = c & 1;
-            xa[buf] = src[2 * c];
-            xb[buf] = (2 * c + 1 < Gm::WIN) ? src[2 * c + 1] : 0.f;
+            xa[buf] = xsrc(2 * c);
+            xb[buf] = (2 * c + 1 < Gm::WIN) ? xsrc(2 * c + 1) : 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) tb[buf][k] = reinterpret_cast<const uint4 *>(ht)[c * 4 + k];
         };
@@ -258,7 +265,10 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
         // the loads of the NEXT chunk, (3) computes the rest under their latency.
         constexpr int CH = 2;
         constexpr int NCH = (Gm::WIN + CH - 1) / CH;
-        const float *src = P + tid * M;
+        auto xsrc = [&](int q) -> float {
+            if constexpr (sizeof(XT) == 2) return static_cast<float>(reinterpret_cast<const int16_t *>(lds)[tid * M + q]);
+            else return P[tid * M + q];
+        };
         f2 acc[Gm::NP > 0 ? Gm::NP : 1];
         float accl = 0.f;
 #pragma unroll
@@ -273,7 +283,7 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
                 const int q = c * CH + e;
-                xb[buf][e] = (q < Gm::WIN) ? src[q] : 0.f;
+                xb[buf][e] = (q < Gm::WIN) ? xsrc(q) : 0.f;
                 if constexpr (L & 1) tl[buf][e] = (q < Gm::WIN) ? hl[q] : 0.f;
 #pragma unroll
                 for (int k = 0; k < Gm::PS; ++k)
@@ -577,7 +587,7 @@ void launch_fused(hipStream_t s, const XT *x, uint64_t n, const float *hb, const
                   float *c_out, float *gm_out, uint64_t w,
                   uint64_t n_corr)
 {
-    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR>;
+    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
     constexpr int kFusedThreads = NTHR;
     const size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
     auto kern = k_fused<L, M, T1, T2, PW, NTHR, XT, F16>;
