@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--inputs", type=int, default=4,
                     help="distinct recordings resident in HBM, decoded round-robin (4 x 115 MB exceeds "
                          "the 256 MB Infinity Cache, so every step reads its input from HBM)")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="recordings per decode_device call (BASELINE config 4's per-GPU share is "
+                         "--seconds 900 --batch 32); a step is then one call, `value` counts all its samples")
     ap.add_argument("--user-stream", action="store_true",
                     help="experiment: give the plan torch's stream as ctx.stream (every call then waits for "
                          "an event recorded there; the inputs are synchronised before timing anyway)")
@@ -79,7 +82,7 @@ def main():
 
     # ---- synthetic recording (seeded per rank), moved to HBM before any timing
     # recording 0 is the one checked against the oracle; the others differ in seed (noise, image)
-    n_inputs = max(1, args.inputs)
+    n_inputs = max(1, args.inputs, args.batch)
     xs = [synth_apt(args.rate, args.seconds, seed=2 + rank + 1000 * j) for j in range(n_inputs)]
     x = xs[0]
     n = x.size
@@ -88,12 +91,16 @@ def main():
         d_xs = [torch.from_numpy(v).to(dev) for v in xs]
         d_x = d_xs[0]
         mode = {"strict": apt.MODE_STRICT, "generic": apt.MODE_GENERIC, "fp16taps": apt.MODE_FP16_TAPS}[args.mode]
-        plan = apt.Plan(settings, rate, not args.no_sync, max_samples=n, max_batch=1, device=local_rank,
+        B = max(1, args.batch)
+        plan = apt.Plan(settings, rate, not args.no_sync, max_samples=n, max_batch=B, device=local_rank,
                         mode=mode, stream=stream.cuda_stream if args.user_stream else 0)
         cap = int(plan.info.max_rows)
-        d_rows = torch.empty(cap * 2080, dtype=torch.float32, device=dev)
+        d_rows_all = [torch.empty(cap * 2080, dtype=torch.float32, device=dev) for _ in range(B)]
+        d_rows = d_rows_all[0]
         torch.cuda.synchronize()  # inputs are resident before anything is enqueued on the plan's streams
-        sigs, nn, out, caps = [[d.data_ptr()] for d in d_xs], [n], [d_rows.data_ptr()], [cap]
+        # call j decodes the B recordings j, j+1, ... (mod n_inputs); recording 0 of call 0 is checked
+        sigs = [[d_xs[(j + b) % n_inputs].data_ptr() for b in range(B)] for j in range(n_inputs)]
+        nn, out, caps = [n] * B, [t.data_ptr() for t in d_rows_all], [cap] * B
         counter = [0]
 
         def step(j=None):
@@ -140,7 +147,7 @@ def main():
 
         # ---- extra legs (not part of `value`): the rows either side of the decode path
         extras = {}
-        if not args.no_extras and not args.no_sync and args.mode == "strict" and res.status == 0:
+        if not args.no_extras and not args.no_sync and args.mode == "strict" and res.status == 0 and B == 1:
             k2 = max(8, min(args.steps, 100))
 
             def timed_loop(fn):
@@ -199,7 +206,7 @@ def main():
 
     from noaa_apt_amd import shard
     # whole-job figures: MAX elapsed over ranks, SUM of samples over ranks (no other collective)
-    elapsed, total_samples_per_step = shard.reduce_job(t1 - t0, float(n), device=dev)
+    elapsed, total_samples_per_step = shard.reduce_job(t1 - t0, float(n) * max(1, args.batch), device=dev)
 
     if res.status != 0:
         raise SystemExit(f"decode failed on rank {rank}: status {res.status} reason {res.reason}")
@@ -209,7 +216,7 @@ def main():
         value = total_samples_per_step * args.steps / elapsed / 1e6
         # algorithmic bytes of one recording: every input f32 read once, every output pixel
         # written once: 4*N_in + 4*2080*rows
-        b_alg = 4.0 * n + 4.0 * 2080.0 * res.n_rows
+        b_alg = (4.0 * n + 4.0 * 2080.0 * res.n_rows) * max(1, args.batch)  # per call (= per front-end launch)
         src = dom_times if dom_times else ktimes
         dom = max(src.items(), key=lambda kv: kv[1][0]) if src else ("none", (0.0, 0))
         dom_ms = dom[1][0]
@@ -247,6 +254,7 @@ def main():
                             f"{plan.info.n_lowpass_taps}-tap low-pass -> sync correlation + peak "
                             f"picker -> {res.n_rows} rows x 2080 px",
                 "parallelism": f"{world} independent recordings, one per GPU, no collectives",
+                "recordings_per_call": max(1, args.batch),
                 "mode": args.mode,
                 "rows": int(res.n_rows),
                 "n_sync": int(res.n_sync),

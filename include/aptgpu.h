@@ -171,7 +171,9 @@ int aptgpu_plan_get_info(const aptgpu_plan *plan, aptgpu_plan_info *info);
  * The plan spreads recordings round-robin over six in-order streams (also
  * across consecutive calls; APTGPU_STREAMS overrides the depth), so front ends
  * of later recordings overlap the peak picker and row gather of earlier ones;
- * it owns max(max_batch + 1, depth) workspace slots.  If
+ * it owns max(max_batch + 1, depth) workspace slots.  Calls with count >= 2 on a
+ * plan created with max_batch >= 2 run ONE front-end launch for all recordings
+ * (such plans own 2*max_batch slots and use 3 chain streams).  If
  * ctx.stream was given at plan creation the work is ordered AFTER what is
  * already enqueued on ctx.stream (inputs may be produced there); to order
  * ctx.stream after the decode, call aptgpu_plan_join().  Outcome per recording

@@ -73,8 +73,14 @@ void aptgpu_plan_destroy(aptgpu_plan *plan)
 {
     if (!plan) return;
     (void)hipSetDevice(plan->device);
+    if (plan->stream_front) (void)hipStreamSynchronize(plan->stream_front);
     for (hipStream_t st : plan->streams) (void)hipStreamSynchronize(st);
     if (plan->ev_user) (void)hipEventDestroy(plan->ev_user);
+    if (plan->ev_front) (void)hipEventDestroy(plan->ev_front);
+    for (auto &sl : plan->slots)
+        if (sl.ev_free) (void)hipEventDestroy(sl.ev_free);
+    if (plan->h_batch) (void)hipHostFree(plan->h_batch);
+    if (plan->stream_front) (void)hipStreamDestroy(plan->stream_front);
     for (hipStream_t st : plan->streams) (void)hipStreamDestroy(st);
     delete plan;
 }
@@ -112,6 +118,16 @@ int aptgpu_plan_decode_device(aptgpu_plan *plan, int count, const float *const *
             if (n[i] > plan->max_samples)
                 throw Error{ErrorKind::Invalid, "recording longer than the plan's max_samples"};
         plan->begin_call(count);
+        if (count >= 2) {  // one front-end launch for the whole call where the geometry allows it
+            std::vector<aptgpu_plan::Input> ins(static_cast<size_t>(count));
+            std::vector<uint64_t> caps(static_cast<size_t>(count));
+            for (int i = 0; i < count; ++i) {
+                ins[static_cast<size_t>(i)].ptr = d_signals[i];
+                ins[static_cast<size_t>(i)].n = n[i];
+                caps[static_cast<size_t>(i)] = static_cast<uint64_t>(rows_cap[i]) * 2080u;
+            }
+            if (plan->enqueue_batch(count, ins.data(), d_rows, caps.data())) return APTGPU_OK;
+        }
         for (int i = 0; i < count; ++i)
             plan->enqueue(i, d_signals[i], n[i], d_rows[i], rows_cap[i] * 2080u, false);
         return APTGPU_OK;

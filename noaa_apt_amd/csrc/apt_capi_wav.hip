@@ -296,15 +296,21 @@ int aptgpu_plan_decode_device_wav(aptgpu_plan *plan, int count, const void *cons
         }
         apt::hip_check(hipSetDevice(plan->device), "hipSetDevice");
         plan->begin_call(count);
+        std::vector<aptgpu_plan::Input> ins(static_cast<size_t>(count));
+        std::vector<uint64_t> caps(static_cast<size_t>(count));
         for (int i = 0; i < count; ++i) {
-            aptgpu_plan::Input in;
+            aptgpu_plan::Input &in = ins[static_cast<size_t>(i)];
             in.ptr = d_data[i];
             in.n = specs[i].n_frames;
             in.channels = specs[i].channels;
             in.bytes_per_sample = specs[i].bytes_per_sample;
             in.codec = specs[i].codec;
-            plan->enqueue(i, in, d_rows[i], static_cast<uint64_t>(rows_cap[i]) * 2080u, false);
+            caps[static_cast<size_t>(i)] = static_cast<uint64_t>(rows_cap[i]) * 2080u;
         }
+        // all aligned mono PCM16: one front-end launch for the whole call
+        if (count >= 2 && plan->enqueue_batch(count, ins.data(), d_rows, caps.data())) return APTGPU_OK;
+        for (int i = 0; i < count; ++i)
+            plan->enqueue(i, ins[static_cast<size_t>(i)], d_rows[i], caps[static_cast<size_t>(i)], false);
         return APTGPU_OK;
     });
 }

@@ -71,6 +71,13 @@ uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1);
 void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, float *hs);
 // host: stage-3 tap pairs h2p[k] = (h2[k-1], h2[k]), k = 0 .. t2  (2*(t2+1) floats)
 void fused_lowpass_pairs(const float *h2, uint32_t t2, float *h2p);
+// One recording of a batched front-end launch (device-resident array, blockIdx.y selects).
+struct FusedRec {
+    const void *x;
+    uint64_t n;
+    float *f_out, *c_out, *gm_out;
+    uint64_t w, n_corr;
+};
 // fp16-tap stage 1 (APTGPU_MODE_FP16_TAPS): table size in dwords, host-side table builder (returns
 // the power-of-two unscale factor), availability
 uint32_t fused_f16_table_dwords(uint32_t l, uint32_t m, uint32_t t1);
@@ -83,6 +90,13 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
                      const void *x, bool pcm16, uint64_t n, const float *hs, const float *h2, const float *h2p,
                      float cosphi2, float sinphi, float inv_sinphi /* verified RN(1/sinphi) or 0, apt_envelope.hpp */,
                      float f16_unscale /* 0: strict; else hs is the fp16 table and this its 2^-s */, float *f_out, float *c_out, float *gm_out, uint64_t w, uint64_t n_corr);
+
+// Batched form: ONE launch over `count` recordings described by d_batch (in HBM, written before the
+// launch on the same stream); grid.x covers the longest recording (max_w work samples).
+bool fused_front_end_batch(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
+                           bool pcm16, const FusedRec *d_batch, int count, uint64_t max_w, const float *hs,
+                           const float *h2, const float *h2p, float cosphi2, float sinphi, float inv_sinphi,
+                           float f16_unscale);
 
 // ---- fused front end for any rate / profile (apt_kernels_fused_any.hip) -------------
 // run-time parameters, taps phase-major in LDS; same outputs as fused_front_end

@@ -134,11 +134,23 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
         float cosphi2, float sinphi, float inv_sinphi /* verified RN(1/sinphi), or 0 */,
         float f16_unscale /* 2^-s of the fp16 tap prescale (F16 only) */,
         float *__restrict__ f_out, float *__restrict__ c_out, float *__restrict__ gm_out,
-        uint64_t w, uint64_t n_corr)
+        uint64_t w, uint64_t n_corr, const FusedRec *__restrict__ batch /* nullptr: the arguments above */)
 {
     using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
     constexpr int kFusedThreads = NTHR;
     constexpr int kOwnThreads = Gm::kOwnThreads;
+    if (batch != nullptr) {
+        // batched launch: blockIdx.y picks the recording; its tiles are blockIdx.x < ceil(w / OWN_K)
+        const FusedRec rec = batch[blockIdx.y];
+        x = static_cast<const XT *>(rec.x);
+        n = rec.n;
+        f_out = rec.f_out;
+        c_out = rec.c_out;
+        gm_out = rec.gm_out;
+        w = rec.w;
+        n_corr = rec.n_corr;
+        if (static_cast<uint64_t>(blockIdx.x) * Gm::OWN_K >= w) return;
+    }
     extern __shared__ float lds[];
     float *P = lds;                  // x tile -> R -> F
     float *Q = lds + Gm::D_OFF;      // D (inside the dead part of the x tile)
@@ -585,7 +597,7 @@ template <int L, int M, int T1, int T2, int PW, int NTHR, bool F16 = false, type
 void launch_fused(hipStream_t s, const XT *x, uint64_t n, const float *hb, const float *h2,
                   const float *h2p, float cosphi2, float sinphi, float inv_sinphi, float f16_unscale, float *f_out,
                   float *c_out, float *gm_out, uint64_t w,
-                  uint64_t n_corr)
+                  uint64_t n_corr, const FusedRec *d_batch = nullptr, int count = 1)
 {
     using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
     constexpr int kFusedThreads = NTHR;
@@ -598,9 +610,9 @@ void launch_fused(hipStream_t s, const XT *x, uint64_t n, const float *hb, const
         attr_set = true;
     }
     const unsigned tiles = static_cast<unsigned>((w + Gm::OWN_K - 1) / Gm::OWN_K);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(kFusedThreads), lds, s, x, n, reinterpret_cast<const f2 *>(hb), h2,
-                       reinterpret_cast<const f2 *>(h2p), cosphi2, sinphi, inv_sinphi, f16_unscale,
-                       f_out, c_out, gm_out, w, n_corr);
+    hipLaunchKernelGGL(kern, dim3(tiles, static_cast<unsigned>(count)), dim3(kFusedThreads), lds, s, x, n,
+                       reinterpret_cast<const f2 *>(hb), h2, reinterpret_cast<const f2 *>(h2p), cosphi2, sinphi,
+                       inv_sinphi, f16_unscale, f_out, c_out, gm_out, w, n_corr, d_batch);
 }
 
 }  // namespace
@@ -736,6 +748,46 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
         else
             launch_fused<13, 100, 1915, 37, 3, 128>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, f_out, c_out, gm_out,
                                                     w, n_corr);
+        return true;
+    }
+    return false;
+}
+
+bool fused_front_end_batch(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
+                           bool pcm16, const FusedRec *d_batch, int count, uint64_t max_w, const float *hb,
+                           const float *h2, const float *h2p, float cosphi2, float sinphi, float inv_sinphi,
+                           float f16_unscale)
+{
+    if (count <= 0 || d_batch == nullptr) return false;
+    const float *xf = nullptr;
+    const int16_t *xi = nullptr;
+    if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
+        if (f16_unscale != 0.f) {
+            if (pcm16)
+                launch_fused<13, 50, 959, 37, 3, 256, true>(s, xi, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi,
+                                                            f16_unscale, nullptr, nullptr, nullptr, max_w, 0, d_batch,
+                                                            count);
+            else
+                launch_fused<13, 50, 959, 37, 3, 256, true>(s, xf, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi,
+                                                            f16_unscale, nullptr, nullptr, nullptr, max_w, 0, d_batch,
+                                                            count);
+            return true;
+        }
+        if (pcm16)
+            launch_fused<13, 50, 959, 37, 3, 256>(s, xi, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, nullptr,
+                                                  nullptr, nullptr, max_w, 0, d_batch, count);
+        else
+            launch_fused<13, 50, 959, 37, 3, 256>(s, xf, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, nullptr,
+                                                  nullptr, nullptr, max_w, 0, d_batch, count);
+        return true;
+    }
+    if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3) {
+        if (pcm16)
+            launch_fused<13, 100, 1915, 37, 3, 128>(s, xi, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, nullptr,
+                                                    nullptr, nullptr, max_w, 0, d_batch, count);
+        else
+            launch_fused<13, 100, 1915, 37, 3, 128>(s, xf, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, nullptr,
+                                                    nullptr, nullptr, max_w, 0, d_batch, count);
         return true;
     }
     return false;

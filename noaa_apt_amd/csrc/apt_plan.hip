@@ -259,16 +259,34 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     // queued that the tail of one is always filled by the head of the next, whatever the
     // latency of the picker chain behind it.
     if (depth <= 0) {
+        // batch-capable plans run ONE front-end launch per call on a stream of its own and fan the
+        // per-recording chains out over 3 streams (front + 3 = the 4 hardware queues; measured at
+        // config 4's per-GPU share, 32 x 15 min: 1 chain stream 0.178, 2-4: 0.143, 6: 0.171 ms per
+        // recording; the recording-by-recording pipeline with 6 streams: 0.154 ms)
         const char *e = std::getenv("APTGPU_STREAMS");
-        depth = e ? std::atoi(e) : 6;
+        depth = e ? std::atoi(e) : (max_batch >= 2 ? 3 : 6);
     }
     depth = std::max(1, std::min(depth, 16));
-    plan->slots.resize(std::max<size_t>(static_cast<size_t>(max_batch) + (depth > 1 ? 1 : 0),
+    plan->slots.resize(std::max<size_t>(max_batch >= 2 ? 2 * static_cast<size_t>(max_batch)
+                                                       : static_cast<size_t>(max_batch) + (depth > 1 ? 1 : 0),
                                         static_cast<size_t>(depth)));
     plan->streams.resize(static_cast<size_t>(depth));
     for (auto &st : plan->streams)
         hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
     plan->stream = plan->streams[0];
+    if (max_batch >= 2) {
+        // lowest priority: HIP keeps a separate hardware queue per priority level, so the batched
+        // launch never sits in an in-order queue in front of (or behind) a chain stream's kernels,
+        // and the small chain kernels are dispatched ahead of its thousands of workgroups
+        int prio_least = 0, prio_greatest = 0;
+        hip_check(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest), "hipDeviceGetStreamPriorityRange");
+        hip_check(hipStreamCreateWithPriority(&plan->stream_front, hipStreamNonBlocking, prio_least),
+                  "hipStreamCreateWithPriority");
+        hip_check(hipEventCreateWithFlags(&plan->ev_front, hipEventDisableTiming), "hipEventCreate");
+        plan->d_batch.alloc(static_cast<size_t>(max_batch));
+        for (auto &sl : plan->slots)
+            hip_check(hipEventCreateWithFlags(&sl.ev_free, hipEventDisableTiming), "hipEventCreate");
+    }
     const uint64_t w = plan->max_work_len;
     for (auto &sl : plan->slots) {
         // (resampled / demodulated are only needed by the unfused kernels: allocated on first use)
@@ -290,6 +308,9 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     }
     plan->d_results.alloc(plan->slots.size());
     hip_check(hipMemset(plan->d_results.ptr, 0, sizeof(gpu::Result) * plan->slots.size()), "hipMemset");
+    // the uploads and memsets above went through the null stream, which the plan's non-blocking
+    // streams do not wait for: make them land before the first decode can be enqueued
+    hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
     return plan.release();
 }
 
@@ -320,14 +341,16 @@ void aptgpu_plan::begin_call(int count)
 
 void aptgpu_plan::sync_all()
 {
+    if (stream_front) apt::hip_check(hipStreamSynchronize(stream_front), "hipStreamSynchronize");
     for (hipStream_t st : streams) apt::hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
 }
 
-int aptgpu_plan::enqueue(int i, const Input &in, float *d_rows, uint64_t rows_cap_floats, bool keep_steps)
+int aptgpu_plan::enqueue(int i, const Input &in, float *d_rows, uint64_t rows_cap_floats, bool keep_steps,
+                         int forced_slot, bool front_done)
 {
     using namespace apt::gpu;
     const uint64_t n = in.n;
-    const int slot = static_cast<int>(seq++ % slots.size());
+    const int slot = forced_slot >= 0 ? forced_slot : static_cast<int>(seq++ % slots.size());
     if (static_cast<size_t>(i) < last_slots.size()) last_slots[static_cast<size_t>(i)] = slot;
     Slot &sl = slots[static_cast<size_t>(slot)];
     Result *res = d_results.ptr + slot;
@@ -335,7 +358,17 @@ int aptgpu_plan::enqueue(int i, const Input &in, float *d_rows, uint64_t rows_ca
     // everything of this recording runs in order on the slot's own stream; the recording that
     // reuses the slot is enqueued on the same stream, so no hand-over events are needed
     hipStream_t cur = streams[static_cast<size_t>(slot) % streams.size()];
-    if (user_stream) apt::hip_check(hipStreamWaitEvent(cur, ev_user, 0), "hipStreamWaitEvent");
+    if (user_stream && !front_done) apt::hip_check(hipStreamWaitEvent(cur, ev_user, 0), "hipStreamWaitEvent");
+    // batch-capable plans: tell the batched front end when this slot's chain is over
+    struct FreeMark {
+        aptgpu_plan *p;
+        Slot &sl;
+        hipStream_t st;
+        ~FreeMark()
+        {
+            if (p->stream_front && sl.ev_free && hipEventRecord(sl.ev_free, st) == hipSuccess) sl.ev_free_recorded = true;
+        }
+    } free_mark{this, sl, cur};
     auto timed = [&](const char *name, auto &&launch) {
         const bool dominant = !std::strcmp(name, "fused_front_end") || !std::strcmp(name, "resample_generic") ||
                               !std::strcmp(name, "resample_f16taps");
@@ -363,7 +396,9 @@ int aptgpu_plan::enqueue(int i, const Input &in, float *d_rows, uint64_t rows_ca
         });
         d_signal = sl.ingest.ptr;
     }
-    if (use_fused) {
+    if (use_fused && front_done) {
+        // the batched launch of enqueue_batch() has produced F, C and GM for this slot already
+    } else if (use_fused) {
         // 1-3 fused: resample -> envelope -> low-pass in one launch (apt_kernels_fused.hip)
         timed("fused_front_end", [&] {
             const uint32_t t1 = static_cast<uint32_t>(taps_resample.size());
@@ -481,8 +516,9 @@ void aptgpu_plan::enqueue_image(int i, const float *d_rows, uint64_t rows_cap_fl
     const uint64_t ws_cap = std::max<uint64_t>(static_cast<uint64_t>(max_rows) * 2080u,
                                                out_len_nosync(work_len_for(max_samples)) + 16);
     if (!d_image_results.ptr) {
+        // (no memset: a null-stream memset is not ordered with the plan's non-blocking streams and
+        // could land after the kernels below; the first kernel of every variant resets its record)
         d_image_results.alloc(slots.size());
-        apt::hip_check(hipMemset(d_image_results.ptr, 0, sizeof(ImageResult) * slots.size()), "hipMemset");
     }
     if (!sl.image_ws.ptr) sl.image_ws.alloc(image_ws_bytes(ws_cap));
     hipStream_t cur = stream_of(i);
@@ -502,4 +538,57 @@ void aptgpu_plan::enqueue_image(int i, const float *d_rows, uint64_t rows_cap_fl
     else
         timed("image_minmax", [&] { image_minmax(cur, d_rows, res, 0, cap, ws, out); });
     timed("image_map_u8", [&] { image_map_u8(cur, d_rows, res, 0, cap, ws, rotate, d_image, out); });
+}
+
+// ------------------------------------------------------------------ batched front end
+bool aptgpu_plan::enqueue_batch(int count, const Input *ins, float *const *d_rows, const uint64_t *rows_cap_floats)
+{
+    using namespace apt::gpu;
+    if (fused != 1 || !stream_front || count < 2 || count > max_batch) return false;
+    const bool pcm16 = ins[0].codec == static_cast<int>(apt::WavCodec::I16);
+    for (int i = 0; i < count; ++i) {
+        const Input &in = ins[i];
+        const bool is_pcm = in.codec == static_cast<int>(apt::WavCodec::I16) && in.channels == 1 &&
+                            (reinterpret_cast<uintptr_t>(in.ptr) & 3u) == 0;
+        if (pcm16 ? !is_pcm : in.codec >= 0) return false;          // one input kind per launch
+        if (work_len_for(in.n) < 10ull * spr) return false;         // error paths stay per recording
+    }
+    if (!h_batch)
+        apt::hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_batch),
+                                     4 * static_cast<size_t>(max_batch) * sizeof(FusedRec), hipHostMallocDefault),
+                       "hipHostMalloc");
+    FusedRec *recs = h_batch + (batch_calls++ % 4) * static_cast<size_t>(max_batch);
+    std::vector<int> slot(static_cast<size_t>(count));
+    uint64_t max_w = 0;
+    const bool want_sync = sync && work_is_multiple;
+    for (int i = 0; i < count; ++i) {
+        slot[static_cast<size_t>(i)] = static_cast<int>(seq++ % slots.size());
+        last_slots[static_cast<size_t>(i)] = slot[static_cast<size_t>(i)];
+        Slot &sl = slots[static_cast<size_t>(slot[static_cast<size_t>(i)])];
+        // the launch overwrites this slot: its previous chain must be over
+        if (sl.ev_free_recorded) apt::hip_check(hipStreamWaitEvent(stream_front, sl.ev_free, 0), "hipStreamWaitEvent");
+        const uint64_t w = work_len_for(ins[i].n);
+        max_w = std::max(max_w, w);
+        recs[i] = FusedRec{ins[i].ptr, ins[i].n, sl.filtered.ptr, want_sync ? sl.correlation.ptr : nullptr,
+                           want_sync ? sl.gm.ptr : nullptr, w, w - n_sync_taps};
+    }
+    if (user_stream) apt::hip_check(hipStreamWaitEvent(stream_front, ev_user, 0), "hipStreamWaitEvent");
+    apt::hip_check(hipMemcpyAsync(d_batch.ptr, recs, static_cast<size_t>(count) * sizeof(FusedRec),
+                                  hipMemcpyHostToDevice, stream_front),
+                   "hipMemcpyAsync batch records");
+    timer.begin(stream_front, "fused_front_end", true);
+    const bool ok = fused_front_end_batch(stream_front, l, m, static_cast<uint32_t>(taps_resample.size()),
+                                          static_cast<uint32_t>(taps_lowpass.size()), pw, pcm16, d_batch.ptr, count,
+                                          max_w, d_taps_branch.ptr, d_taps_lowpass.ptr, d_taps_lowpass_pairs.ptr,
+                                          cosphi2, sinphi, inv_sinphi, fused_f16 ? f16_unscale : 0.f);
+    timer.end(stream_front);
+    if (!ok) throw apt::Error{apt::ErrorKind::Internal, "batched front end: no kernel for this geometry"};
+    apt::hip_check(hipEventRecord(ev_front, stream_front), "hipEventRecord");
+    for (int i = 0; i < count; ++i) {
+        const int sidx = slot[static_cast<size_t>(i)];
+        hipStream_t cur = streams[static_cast<size_t>(sidx) % streams.size()];
+        apt::hip_check(hipStreamWaitEvent(cur, ev_front, 0), "hipStreamWaitEvent");
+        enqueue(i, ins[i], d_rows[i], rows_cap_floats[i], false, sidx, true);
+    }
+    return true;
 }

@@ -89,6 +89,17 @@ struct aptgpu_plan {
     // latency-bound picker/gather of recording i without any cross-stream events, and a slot
     // is only ever reused by a later recording on its own stream (in-order => no hazards).
     std::vector<hipStream_t> streams;
+    // Batched calls (count >= 2, specialised fused kernel): ONE front-end launch over all
+    // recordings on `stream_front`, then every recording's picker/gather chain on its slot's
+    // stream.  Slot hand-over between the two uses one event per slot (recorded when a chain
+    // ends; the batched launch waits for the slots it is about to overwrite) and one event per
+    // call (chains wait for the front end).  Plans with max_batch >= 2 own 2*max_batch slots so
+    // that the front end of call j+1 overlaps the chains of call j.
+    hipStream_t stream_front = nullptr;
+    hipEvent_t ev_front = nullptr;
+    apt::DeviceBuffer<apt::gpu::FusedRec> d_batch;
+    apt::gpu::FusedRec *h_batch = nullptr;  // pinned ring: 4 calls x max_batch records
+    uint64_t batch_calls = 0;
     hipStream_t stream = nullptr;       // = streams[0] (host-API helpers, timing collection)
     hipStream_t user_stream = nullptr;  // ctx.stream: inputs are ordered after it (may be null)
     hipEvent_t ev_user = nullptr;
@@ -134,6 +145,8 @@ struct aptgpu_plan {
         apt::DeviceBuffer<float> gm;          // per-group maxima of the correlation
         apt::DeviceBuffer<uint64_t> words;    // 52-bit terminal words
         apt::DeviceBuffer<uint32_t> slot_nt, slot_cnt, flags, orbit_ws;
+        hipEvent_t ev_free = nullptr;      // batch-capable plans: the chain using this slot has finished
+        bool ev_free_recorded = false;
         apt::DeviceBuffer<char> image_ws;  // scratch of the image stage, allocated on first use
         apt::DeviceBuffer<float> ingest;   // WAV -> f32 staging when the fused PCM16 path does not apply
     };
@@ -166,7 +179,11 @@ struct aptgpu_plan {
         uint32_t channels = 1, bytes_per_sample = 4;
         int codec = -1;
     };
-    int enqueue(int i, const Input &in, float *d_rows, uint64_t rows_cap_floats, bool keep_steps);
+    int enqueue(int i, const Input &in, float *d_rows, uint64_t rows_cap_floats, bool keep_steps,
+                int forced_slot = -1, bool front_done = false);
+    // one front-end launch for all `count` recordings; false when the call has to go recording by
+    // recording (no specialised kernel, mixed input kinds, a recording that must report an error)
+    bool enqueue_batch(int count, const Input *ins, float *const *d_rows, const uint64_t *rows_cap_floats);
     int enqueue(int i, const float *d_signal, uint64_t n, float *d_rows, uint64_t rows_cap_floats,
                 bool keep_steps)
     {
