@@ -176,8 +176,11 @@ int aptgpu_plan_get_info(const aptgpu_plan *plan, aptgpu_plan_info *info);
  * (such plans own 2*max_batch slots and use 3 chain streams).  If
  * ctx.stream was given at plan creation the work is ordered AFTER what is
  * already enqueued on ctx.stream (inputs may be produced there); to order
- * ctx.stream after the decode, call aptgpu_plan_join().  Outcome per recording
- * lands in the plan's result records. */
+ * ctx.stream after the decode, call aptgpu_plan_join().  Recordings of different
+ * calls run on different internal streams: a call that reuses the output buffers of
+ * an earlier call is only ordered after it if aptgpu_plan_join() / _synchronize() /
+ * _results() came in between.  Outcome per recording lands in the plan's result
+ * records. */
 int aptgpu_plan_decode_device(aptgpu_plan *plan, int count, const float *const *d_signals,
                               const size_t *n, float *const *d_rows, const size_t *rows_cap,
                               char *err, size_t err_cap);
