@@ -93,6 +93,7 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
 
 // Batched form: ONE launch over `count` recordings described by d_batch (in HBM, written before the
 // launch on the same stream); grid.x covers the longest recording (max_w work samples).
+bool fused_batch_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
 bool fused_front_end_batch(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
                            bool pcm16, const FusedRec *d_batch, int count, uint64_t max_w, const float *hs,
                            const float *h2, const float *h2p, float cosphi2, float sinphi, float inv_sinphi,

@@ -127,7 +127,9 @@ __host__ __device__ constexpr bool sync_plus(int j)
 // instruction per two taps of one output instead of a packed mul + add per tap of two outputs,
 // about half the stage-1 instructions; `hs` then holds [ceil(WIN/2)][16] half2 tap pairs.
 // Tolerance-based, not bit-exact; every other stage stays strict.
-template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, bool F16>
+// BATCH: one launch over several recordings (blockIdx.y); a separate instantiation, because the extra
+// pointer and prologue cost the single-recording kernel 10 % through SGPR pressure in its hot loops.
+template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, bool F16, bool BATCH>
 __global__ void __launch_bounds__(NTHR, ((sizeof(XT) == 2 ? 4 : APT_FUSED_MIN_WAVES) * NTHR + 255) / 256)
 k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][PS] tap pairs*/,
         const float *__restrict__ h2 /*[T2]*/, const f2 *__restrict__ h2p /*[T2+1] (h2[m-1], h2[m])*/,
@@ -139,7 +141,7 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
     using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
     constexpr int kFusedThreads = NTHR;
     constexpr int kOwnThreads = Gm::kOwnThreads;
-    if (batch != nullptr) {
+    if constexpr (BATCH) {
         // batched launch: blockIdx.y picks the recording; its tiles are blockIdx.x < ceil(w / OWN_K)
         const FusedRec rec = batch[blockIdx.y];
         x = static_cast<const XT *>(rec.x);
@@ -593,7 +595,7 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
     }
 }
 
-template <int L, int M, int T1, int T2, int PW, int NTHR, bool F16 = false, typename XT>
+template <int L, int M, int T1, int T2, int PW, int NTHR, bool F16 = false, bool BATCH = false, typename XT>
 void launch_fused(hipStream_t s, const XT *x, uint64_t n, const float *hb, const float *h2,
                   const float *h2p, float cosphi2, float sinphi, float inv_sinphi, float f16_unscale, float *f_out,
                   float *c_out, float *gm_out, uint64_t w,
@@ -602,7 +604,7 @@ void launch_fused(hipStream_t s, const XT *x, uint64_t n, const float *hb, const
     using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
     constexpr int kFusedThreads = NTHR;
     const size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
-    auto kern = k_fused<L, M, T1, T2, PW, NTHR, XT, F16>;
+    auto kern = k_fused<L, M, T1, T2, PW, NTHR, XT, F16, BATCH>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -753,44 +755,29 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
     return false;
 }
 
+bool fused_batch_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
+{
+    return l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3;  // the 48 kHz standard kernel
+}
+
 bool fused_front_end_batch(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
                            bool pcm16, const FusedRec *d_batch, int count, uint64_t max_w, const float *hb,
                            const float *h2, const float *h2p, float cosphi2, float sinphi, float inv_sinphi,
                            float f16_unscale)
 {
-    if (count <= 0 || d_batch == nullptr) return false;
+    if (count <= 0 || d_batch == nullptr || f16_unscale != 0.f) return false;
     const float *xf = nullptr;
     const int16_t *xi = nullptr;
     if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
-        if (f16_unscale != 0.f) {
-            if (pcm16)
-                launch_fused<13, 50, 959, 37, 3, 256, true>(s, xi, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi,
-                                                            f16_unscale, nullptr, nullptr, nullptr, max_w, 0, d_batch,
-                                                            count);
-            else
-                launch_fused<13, 50, 959, 37, 3, 256, true>(s, xf, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi,
-                                                            f16_unscale, nullptr, nullptr, nullptr, max_w, 0, d_batch,
-                                                            count);
-            return true;
-        }
         if (pcm16)
-            launch_fused<13, 50, 959, 37, 3, 256>(s, xi, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, nullptr,
-                                                  nullptr, nullptr, max_w, 0, d_batch, count);
+            launch_fused<13, 50, 959, 37, 3, 256, false, true>(s, xi, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi,
+                                                               0.f, nullptr, nullptr, nullptr, max_w, 0, d_batch, count);
         else
-            launch_fused<13, 50, 959, 37, 3, 256>(s, xf, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, nullptr,
-                                                  nullptr, nullptr, max_w, 0, d_batch, count);
+            launch_fused<13, 50, 959, 37, 3, 256, false, true>(s, xf, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi,
+                                                               0.f, nullptr, nullptr, nullptr, max_w, 0, d_batch, count);
         return true;
     }
-    if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3) {
-        if (pcm16)
-            launch_fused<13, 100, 1915, 37, 3, 128>(s, xi, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, nullptr,
-                                                    nullptr, nullptr, max_w, 0, d_batch, count);
-        else
-            launch_fused<13, 100, 1915, 37, 3, 128>(s, xf, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, nullptr,
-                                                    nullptr, nullptr, max_w, 0, d_batch, count);
-        return true;
-    }
-    return false;
+    return false;  // other geometries: recording by recording
 }
 
 }  // namespace apt::gpu

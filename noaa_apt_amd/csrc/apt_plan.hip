@@ -544,7 +544,10 @@ void aptgpu_plan::enqueue_image(int i, const float *d_rows, uint64_t rows_cap_fl
 bool aptgpu_plan::enqueue_batch(int count, const Input *ins, float *const *d_rows, const uint64_t *rows_cap_floats)
 {
     using namespace apt::gpu;
-    if (fused != 1 || !stream_front || count < 2 || count > max_batch) return false;
+    if (fused != 1 || fused_f16 || !stream_front || count < 2 || count > max_batch) return false;
+    if (!fused_batch_supported(l, m, static_cast<uint32_t>(taps_resample.size()),
+                               static_cast<uint32_t>(taps_lowpass.size()), pw))
+        return false;
     const bool pcm16 = ins[0].codec == static_cast<int>(apt::WavCodec::I16);
     for (int i = 0; i < count; ++i) {
         const Input &in = ins[i];
