@@ -16,7 +16,7 @@ import sys
 def short(name):
     m = re.search(r"(k_[a-z_0-9]+)", name)
     base = m.group(1) if m else name[:40]
-    if base.startswith("k_fused") and re.search(r",\s*short>", name):
+    if base.startswith("k_fused") and re.search(r",\s*short\s*[,>]", name):
         base += "_pcm16"  # the int16-input instantiation (WAV ingest inside the front end)
     return base
 
