@@ -139,7 +139,7 @@ def lib_path():
 
 def build():
     """Compile libaptgpu.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j4", "all"])
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j8", "all"])
 
 
 def _preload_hip_runtime():

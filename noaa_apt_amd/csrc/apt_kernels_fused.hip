@@ -20,8 +20,7 @@
 // low-pass and envelope look back 37 samples), 240 threads of owned outputs and 12
 // threads of post-halo (the correlation looks ahead 38*PW-1 samples).  LDS: the input
 // tile, later overwritten by R and then F (region P), plus D (region Q).
-#include "apt_kernels.hpp"
-#include "apt_envelope.hpp"
+#include "apt_kernels_fused_launch.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -32,592 +31,6 @@
 
 namespace apt::gpu {
 
-namespace {
-
-#ifndef APT_FUSED_MIN_WAVES
-#define APT_FUSED_MIN_WAVES 3
-#endif
-constexpr int kPreThreads = 4;    // pre-halo threads (low-pass + envelope history)
-constexpr int kPostThreads = 12;  // post-halo threads (correlation look-ahead)
-constexpr float kNegInfF = -__builtin_huge_valf();
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-template <int L, int M>
-__host__ __device__ constexpr int branch_first(int b)  // c_b = ceil(b*M / L)
-{
-    return (b * M + L - 1) / L;
-}
-template <int L, int M>
-__host__ __device__ constexpr int branch_phase(int b)  // p_b = c_b*L - b*M
-{
-    return branch_first<L, M>(b) * L - b * M;
-}
-
-// XB: bytes per input sample in the LDS tile (4: f32 Signal; 2: PCM16 kept as int16 — exact, and
-// half the tile, so the other regions set the footprint and 4 instead of 3 workgroups fit a CU)
-template <int L, int M, int T1, int T2, int PW, int NTHR, int XB = 4>
-struct FusedGeom {
-    static constexpr int kFusedThreads = NTHR;
-    static constexpr int kOwnThreads = NTHR - kPreThreads - kPostThreads;
-    static constexpr int TP = (T1 + L - 1) / L;                       // taps per branch (max)
-    static constexpr int CLAST = branch_first<L, M>(L - 1);           // last branch's first sample
-    static constexpr int WIN = CLAST + TP;                            // input window per thread
-    static constexpr int TILE_K = kFusedThreads * L;                  // work samples per tile
-    static constexpr int OWN_K = kOwnThreads * L;                     // owned work samples
-    static constexpr int PRE_K = kPreThreads * L;
-    static constexpr int XT = (kFusedThreads - 1) * M + WIN + 2;          // input floats per tile
-    static constexpr int XT_PAD = (XT + 3) & ~3;
-    static constexpr int G = 38 * PW;                                 // sync template length
-    static constexpr int FWIN = L + G - 1;                            // F window per thread
-    // one LDS region: the x tile, then R/F at [0, TILE_K+G), D and later C at D_OFF
-    static constexpr int D_OFF = (TILE_K + G + 3) & ~3;
-    static constexpr int C_OFF = D_OFF;  // C staging reuses D's region: D is dead once F is in P
-    static constexpr int XT_LDS = XB == 2 ? (XT_PAD / 2 + 4) : XT_PAD;  // floats of LDS under the x tile
-    static constexpr int LDS_FLOATS = XT_LDS > (C_OFF + TILE_K) ? XT_LDS : (C_OFF + TILE_K);
-    static constexpr int GS = 4 * L;                                  // correlation group size
-    static constexpr int NP = L / 2;                                  // accumulator pairs (+1 single if L odd)
-    static constexpr int PS = NP;                                     // f2 tap entries per window sample
-    static constexpr int HL_OFF = 2 * ((CLAST + (T1 + L - 1) / L) * NP);  // float offset of the odd branch's taps
-    static constexpr int DW = L + T2 - 1;                             // envelope window per thread
-    static_assert(PRE_K >= T2 + 1, "pre-halo too small for the low-pass");
-    static_assert((kFusedThreads - kPreThreads - kOwnThreads) * L >= G - 1, "post-halo too small");
-    static_assert(OWN_K % 4 == 0, "owned range must be float4-aligned");
-};
-
-// does polyphase branch b use window sample q?  (tap index i = q - c_b, p_b + i*L < T1)
-template <int L, int M, int T1>
-__host__ __device__ constexpr bool branch_uses(int b, int q)
-{
-    const int i = q - branch_first<L, M>(b);
-    return i >= 0 && branch_phase<L, M>(b) + i * L < T1;
-}
-
-// first branch that uses window sample 2c or 2c+1 (fp16 stage 1 works on sample pairs); L if none
-template <int L, int M, int T1>
-__host__ __device__ constexpr int first_branch_of_pair(int c)
-{
-    for (int b = 0; b < L; ++b)
-        if (branch_uses<L, M, T1>(b, 2 * c) || branch_uses<L, M, T1>(b, 2 * c + 1)) return b;
-    return L;
-}
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-// sign of the sync template at index j (decode.rs:188-198): + inside the seven high pulses
-template <int PW>
-__host__ __device__ constexpr bool sync_plus(int j)
-{
-    const int pulse = 2 * PW;
-    if (j < pulse || j >= pulse + 14 * pulse) return false;
-    return (((j - pulse) / pulse) & 1) == 1;
-}
-
-// XT = float: the f32 Signal; XT = int16_t: mono PCM16 straight from the WAV data chunk
-// (`*x as f32`, wav.rs:37), which halves the compulsory input bytes.
-// F16 (APTGPU_MODE_FP16_TAPS, BASELINE config 5): stage 1 only runs on fp16 taps (power-of-two
-// prescaled) and fp16-rounded samples through v_dot2_f32_f16 with f32 accumulation — one
-// instruction per two taps of one output instead of a packed mul + add per tap of two outputs,
-// about half the stage-1 instructions; `hs` then holds [ceil(WIN/2)][16] half2 tap pairs.
-// Tolerance-based, not bit-exact; every other stage stays strict.
-// BATCH: one launch over several recordings (blockIdx.y); a separate instantiation, because the extra
-// pointer and prologue cost the single-recording kernel 10 % through SGPR pressure in its hot loops.
-template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, bool F16, bool BATCH>
-__global__ void __launch_bounds__(NTHR, ((sizeof(XT) == 2 ? 4 : APT_FUSED_MIN_WAVES) * NTHR + 255) / 256)
-k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][PS] tap pairs*/,
-        const float *__restrict__ h2 /*[T2]*/, const f2 *__restrict__ h2p /*[T2+1] (h2[m-1], h2[m])*/,
-        float cosphi2, float sinphi, float inv_sinphi /* verified RN(1/sinphi), or 0 */,
-        float f16_unscale /* 2^-s of the fp16 tap prescale (F16 only) */,
-        float *__restrict__ f_out, float *__restrict__ c_out, float *__restrict__ gm_out,
-        uint64_t w, uint64_t n_corr, const FusedRec *__restrict__ batch /* nullptr: the arguments above */)
-{
-    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
-    constexpr int kFusedThreads = NTHR;
-    constexpr int kOwnThreads = Gm::kOwnThreads;
-    if constexpr (BATCH) {
-        // batched launch: blockIdx.y picks the recording; its tiles are blockIdx.x < ceil(w / OWN_K)
-        const FusedRec rec = batch[blockIdx.y];
-        x = static_cast<const XT *>(rec.x);
-        n = rec.n;
-        f_out = rec.f_out;
-        c_out = rec.c_out;
-        gm_out = rec.gm_out;
-        w = rec.w;
-        n_corr = rec.n_corr;
-        if (static_cast<uint64_t>(blockIdx.x) * Gm::OWN_K >= w) return;
-    }
-    extern __shared__ float lds[];
-    float *P = lds;                  // x tile -> R -> F
-    float *Q = lds + Gm::D_OFF;      // D (inside the dead part of the x tile)
-    float *CS = lds + Gm::C_OFF;     // correlation staging for coalesced stores
-
-    const int tid = threadIdx.x;
-    const int64_t tile = blockIdx.x;
-    const int64_t o0 = tile * Gm::OWN_K;            // first owned work sample
-    const int64_t k0 = o0 - Gm::PRE_K;              // first work sample of the tile (< 0 in tile 0)
-    const int64_t xs0 = (k0 / L) * M;               // first input sample of the tile
-    // everything below indexes relative to the tile with 32-bit integers; the global limits
-    // become wave-uniform scalars
-    auto rel = [](int64_t v) -> int { return v < -(1 << 30) ? -(1 << 30) : (v > (1 << 30) ? (1 << 30) : static_cast<int>(v)); };
-    const int x_lo = rel(-xs0);                                   // tile index of input sample 0
-    const int x_hi = rel(static_cast<int64_t>(n) - xs0);          // tile index of input sample n
-    const int k_lo = rel(-k0);                                    // tile index of work sample 0
-    const int k_hi = rel(static_cast<int64_t>(w) - k0);           // tile index of work sample w
-    const int c_hi = rel(static_cast<int64_t>(n_corr) - k0);      // tile index of position n_corr
-
-    // ---- stage 0: input tile -> LDS (coalesced 16-byte loads, zero outside [0, n))
-    if constexpr (sizeof(XT) == 4) {
-        const float *xt = x + xs0;  // only dereferenced inside [x_lo, x_hi)
-        for (int q = tid * 4; q < Gm::XT_PAD; q += kFusedThreads * 4) {
-            float4 v;
-            if (q >= x_lo && q + 3 < x_hi) {
-                v = *reinterpret_cast<const float4 *>(xt + q);
-            } else {
-                v.x = (q >= x_lo && q < x_hi) ? xt[q] : 0.f;
-                v.y = (q + 1 >= x_lo && q + 1 < x_hi) ? xt[q + 1] : 0.f;
-                v.z = (q + 2 >= x_lo && q + 2 < x_hi) ? xt[q + 2] : 0.f;
-                v.w = (q + 3 >= x_lo && q + 3 < x_hi) ? xt[q + 3] : 0.f;
-            }
-            *reinterpret_cast<float4 *>(P + q) = v;
-        }
-    } else {
-        // PCM16: the tile stays int16 in LDS (`*x as f32` happens when stage 1 reads it).  x is
-        // 4-byte aligned and xs0, q are even, so sample pairs move as dwords.
-        const int16_t *xt = x + xs0;
-        uint32_t *X32 = reinterpret_cast<uint32_t *>(lds);
-        for (int q = tid * 4; q < Gm::XT_PAD; q += kFusedThreads * 4) {
-            uint32_t a, b;
-            if (q >= x_lo && q + 3 < x_hi) {
-                const uint32_t *pp = reinterpret_cast<const uint32_t *>(xt + q);
-                a = pp[0];
-                b = pp[1];
-            } else {
-                auto at = [&](int i) -> uint32_t {
-                    return (i >= x_lo && i < x_hi) ? static_cast<uint32_t>(static_cast<uint16_t>(xt[i])) : 0u;
-                };
-                a = at(q) | (at(q + 1) << 16);
-                b = at(q + 2) | (at(q + 3) << 16);
-            }
-            X32[q / 2] = a;
-            X32[q / 2 + 1] = b;
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 1: polyphase resampler, L outputs per thread (dsp.rs:252-263)
-    // Sample-stationary form: window sample q is broadcast (op_sel) against a PAIR of taps
-    // (one scalar-loaded SGPR pair) feeding a pair of accumulators, so every tap costs half
-    // a v_pk_mul_f32 + half a v_pk_add_f32 and no register shuffling.  Each branch still
-    // accumulates its own taps in ascending order, products and sums rounded separately.
-    const int kq = tid * L;        // this thread's first work sample, tile-relative
-    const int kt = kq - k_lo;      // ... and as a global work-sample index clamped to int
-    float r[L];
-    if constexpr (F16) {
-        typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-        constexpr int NQP = (Gm::WIN + 1) / 2;  // window sample pairs
-        auto xsrc = [&](int q) -> float {
-            if constexpr (sizeof(XT) == 2) return static_cast<float>(reinterpret_cast<const int16_t *>(lds)[tid * M + q]);
-            else return P[tid * M + q];
-        };
-        const uint32_t *ht = reinterpret_cast<const uint32_t *>(hs);  // [NQP][16] half2 bit patterns
-        float acc[L];
-#pragma unroll
-        for (int b = 0; b < L; ++b) acc[b] = 0.f;
-        uint4 tb[2][4];  // tap pairs of the sample pair in use / in flight (16 SGPRs each)
-        float xa[2], xb[2];
-        static_assert(L <= 16, "one 16-dword table row per sample pair");
-        auto dot2 = [](float &a, uint32_t tap_pair /*SGPR*/, h2v x_pair) {
-            asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(a) : "s"(tap_pair), "v"(x_pair));
-        };
-        auto tapw = [&](int buf, int b) -> uint32_t {
-            const uint4 v = tb[buf][b >> 2];
-            return (b & 3) == 0 ? v.x : (b & 3) == 1 ? v.y : (b & 3) == 2 ? v.z : v.w;
-        };
-        auto issue = [&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int buf = c & 1;
-            xa[buf] = xsrc(2 * c);
-            xb[buf] = (2 * c + 1 < Gm::WIN) ? xsrc(2 * c + 1) : 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) tb[buf][k] = reinterpret_cast<const uint4 *>(ht)[c * 4 + k];
-        };
-        issue(std::integral_constant<int, 0>{});
-        static_for<0, NQP>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int buf = c & 1;
-            const h2v xh = {static_cast<_Float16>(xa[buf]), static_cast<_Float16>(xb[buf])};
-            // the first dot forces the wait for the loads issued one pair ago
-            // (asm volatile pins the dots between the scheduling barriers: as plain intrinsics the
-            // compiler sank all 793 of them behind the loads and spilled 750 SGPRs)
-            // only the branches whose taps reach one of the two samples (the others hold zeros)
-            constexpr int b0 = first_branch_of_pair<L, M, T1>(c);
-            if constexpr (b0 < L) dot2(acc[b0], tapw(buf, b0), xh);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (c + 1 < NQP) issue(std::integral_constant<int, c + 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, L>([&](auto bb) {
-                constexpr int b = decltype(bb)::value;
-                if constexpr (b > b0 && (branch_uses<L, M, T1>(b, 2 * c) || branch_uses<L, M, T1>(b, 2 * c + 1)))
-                    dot2(acc[b], tapw(buf, b), xh);
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-#pragma unroll
-        for (int b = 0; b < L; ++b) r[b] = (kq + b < k_lo || kq + b >= k_hi) ? 0.f : acc[b] * f16_unscale;
-    } else
-    {
-        // Software pipeline over chunks of CH window samples: SMEM returns out of order, so the
-        // only usable wait is lgkmcnt(0).  Each chunk therefore (1) consumes its first tap —
-        // which makes the compiler wait for exactly the loads issued one chunk ago — (2) issues
-        // the loads of the NEXT chunk, (3) computes the rest under their latency.
-        constexpr int CH = 2;
-        constexpr int NCH = (Gm::WIN + CH - 1) / CH;
-        auto xsrc = [&](int q) -> float {
-            if constexpr (sizeof(XT) == 2) return static_cast<float>(reinterpret_cast<const int16_t *>(lds)[tid * M + q]);
-            else return P[tid * M + q];
-        };
-        f2 acc[Gm::NP > 0 ? Gm::NP : 1];
-        float accl = 0.f;
-#pragma unroll
-        for (int pp = 0; pp < Gm::NP; ++pp) acc[pp] = (f2){0.f, 0.f};
-        f2 tb[2][CH * Gm::PS];   // tap pairs of the chunk in use / in flight (SGPRs)
-        float tl[2][CH];         // taps of the odd branch L-1 (contiguous per sample: aligned pairs)
-        float xb[2][CH];         // window samples of the chunk in use / in flight
-        const float *hl = reinterpret_cast<const float *>(hs) + Gm::HL_OFF;
-        auto issue = [&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int buf = c & 1;
-#pragma unroll
-            for (int e = 0; e < CH; ++e) {
-                const int q = c * CH + e;
-                xb[buf][e] = (q < Gm::WIN) ? xsrc(q) : 0.f;
-                if constexpr (L & 1) tl[buf][e] = (q < Gm::WIN) ? hl[q] : 0.f;
-#pragma unroll
-                for (int k = 0; k < Gm::PS; ++k)
-                    tb[buf][e * Gm::PS + k] = (q < Gm::WIN) ? hs[q * Gm::PS + k] : (f2){0.f, 0.f};
-            }
-        };
-        // product of window sample (c, e) with tap pair k — kept apart from the accumulation so
-        // that a sample's products are all issued before the first dependent add (a v_pk_add
-        // right behind the v_pk_mul it reads costs a wait state)
-        auto prod = [&](auto cc, auto ee, auto kk) -> f2 {
-            constexpr int c = decltype(cc)::value, e = decltype(ee)::value, k = decltype(kk)::value;
-            constexpr int buf = c & 1;
-            constexpr int q = c * CH + e;
-            f2 p = (f2){0.f, 0.f};
-            if constexpr (q < Gm::WIN) {
-                const float xq = xb[buf][e];
-                if constexpr (k < Gm::NP) {
-                    const f2 t = tb[buf][e * Gm::PS + k];
-                    constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
-                    constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
-                    if constexpr (va && vb) {
-                        p = t * (f2){xq, xq};
-                    } else if constexpr (va) {
-                        p.x = t.x * xq;
-                    } else if constexpr (vb) {
-                        p.y = t.y * xq;
-                    }
-                } else if constexpr (branch_uses<L, M, T1>(L - 1, q)) {
-                    p.x = tl[buf][e] * xq;
-                }
-            }
-            return p;
-        };
-        auto accum = [&](auto cc, auto ee, auto kk, f2 p) {
-            constexpr int c = decltype(cc)::value, e = decltype(ee)::value, k = decltype(kk)::value;
-            constexpr int q = c * CH + e;
-            if constexpr (q < Gm::WIN) {
-                if constexpr (k < Gm::NP) {
-                    constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
-                    constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
-                    if constexpr (va && vb) {
-                        acc[k] = acc[k] + p;
-                    } else if constexpr (va) {
-                        acc[k].x = acc[k].x + p.x;
-                    } else if constexpr (vb) {
-                        acc[k].y = acc[k].y + p.y;
-                    }
-                } else if constexpr (branch_uses<L, M, T1>(L - 1, q)) {
-                    accl = accl + p.x;
-                }
-            }
-        };
-        issue(std::integral_constant<int, 0>{});
-        static_for<0, NCH>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int NK = Gm::PS + (L & 1);
-            using I0 = std::integral_constant<int, 0>;
-            using I1 = std::integral_constant<int, 1>;
-            // the first two products force the wait for the loads issued one chunk ago
-            const f2 p00 = prod(cc, I0{}, I0{});
-            const f2 p01 = prod(cc, I0{}, I1{});
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (c + 1 < NCH) issue(std::integral_constant<int, c + 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, CH>([&](auto ee) {
-                constexpr int e = decltype(ee)::value;
-                f2 pr[NK];
-                static_for<0, NK>([&](auto kk) {
-                    constexpr int k = decltype(kk)::value;
-                    if constexpr (e == 0 && k == 0) pr[k] = p00;
-                    else if constexpr (e == 0 && k == 1) pr[k] = p01;
-                    else pr[k] = prod(cc, ee, kk);
-                });
-                static_for<0, NK>([&](auto kk) { accum(cc, ee, kk, pr[decltype(kk)::value]); });
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-#pragma unroll
-        for (int pp = 0; pp < Gm::NP; ++pp) {
-            r[2 * pp] = acc[pp].x;
-            r[2 * pp + 1] = acc[pp].y;
-        }
-        if constexpr (L & 1) r[L - 1] = accl;
-#pragma unroll
-        for (int b = 0; b < L; ++b)
-            if (kq + b < k_lo || kq + b >= k_hi) r[b] = 0.f;
-    }
-    __syncthreads();  // everyone is done reading the x tile
-#pragma unroll
-    for (int b = 0; b < L; ++b) P[tid * L + b] = r[b];
-    __syncthreads();
-
-    // ---- stage 2: AM envelope from consecutive samples (dsp.rs:369-377)
-    {
-        float prev = (tid > 0) ? P[tid * L - 1] : 0.f;
-        float xr[L];
-        bool in_range = inv_sinphi != 0.f;  // 0: the fast divide did not verify for this sin(phi)
-#pragma unroll
-        for (int b = 0; b < L; ++b) {
-            const float curr = r[b];
-            xr[b] = envelope_radicand(prev, curr, cosphi2);
-            // (outputs outside the recording are zeroed below whatever their radicand is)
-            in_range = in_range && (envelope_in_range(xr[b]) || kq + b <= k_lo || kq + b >= k_hi);
-            prev = curr;
-        }
-        // wave-uniform choice: the exactly rounded fast path (apt_envelope.hpp) when every value
-        // of the wave is in its range, the compiler's general sequences otherwise
-        if (__all(in_range)) {
-#pragma unroll
-            for (int b = 0; b < L; ++b) {
-                // (positions at or past the end of the recording hold garbage: never read)
-                Q[tid * L + b] = (kq + b > k_lo) ? envelope_fast(xr[b], sinphi, inv_sinphi) : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int b = 0; b < L; ++b) Q[tid * L + b] = (kq + b > k_lo) ? envelope_general(xr[b], sinphi) : 0.f;
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 3: causal low-pass with the `i > j` guard (dsp.rs:396-404)
-    // Same sample-stationary pairing: envelope sample d = D[kt-(T2-1)+qq] meets output b at
-    // tap j = (T2-1)+b-qq, so outputs (b, b+1) take the tap pair (h2[m], h2[m+1]); walking qq
-    // downwards gives every output its taps in ascending j.
-    float f[L];
-    {
-        const int base = tid * L - (T2 - 1);
-        if (kt >= T2) {
-            f2 fa[Gm::NP > 0 ? Gm::NP : 1];
-            float fl = 0.f;
-#pragma unroll
-            for (int pp = 0; pp < Gm::NP; ++pp) fa[pp] = (f2){0.f, 0.f};
-            constexpr int CH3 = 7;
-            static_for<0, (Gm::DW + CH3 - 1) / CH3>([&](auto cc) {
-                constexpr int hi = Gm::DW - 1 - decltype(cc)::value * CH3;  // walk qq downwards
-                float dv[CH3];
-#pragma unroll
-                for (int e = 0; e < CH3; ++e) dv[e] = (hi - e >= 0) ? Q[base + hi - e] : 0.f;
-                static_for<0, CH3>([&](auto ee) {
-                    constexpr int qq = hi - decltype(ee)::value;
-                    if constexpr (qq >= 0) {
-                        const float d = dv[decltype(ee)::value];
-                        // all products of this sample first, then the dependent adds (a
-                        // v_pk_add right behind the v_pk_mul it reads costs a wait state)
-                        f2 pr[Gm::NP > 0 ? Gm::NP : 1];
-                        float pl = 0.f;
-                        static_for<0, Gm::NP>([&](auto pc) {
-                            constexpr int pp = decltype(pc)::value;
-                            constexpr int m = (T2 - 1) + 2 * pp - qq;       // tap of lane x; lane y: m+1
-                            constexpr bool va = m >= 0 && m < T2;
-                            constexpr bool vb = m + 1 >= 0 && m + 1 < T2;
-                            pr[pp] = (f2){0.f, 0.f};
-                            if constexpr (va && vb) {
-                                pr[pp] = h2p[m + 1] * (f2){d, d};
-                            } else if constexpr (va) {
-                                pr[pp].x = h2[m] * d;
-                            } else if constexpr (vb) {
-                                pr[pp].y = h2[m + 1] * d;
-                            }
-                        });
-                        if constexpr (L & 1) {
-                            constexpr int ml = (T2 - 1) + (L - 1) - qq;
-                            if constexpr (ml >= 0 && ml < T2) pl = h2[ml] * d;
-                        }
-                        static_for<0, Gm::NP>([&](auto pc) {
-                            constexpr int pp = decltype(pc)::value;
-                            constexpr int m = (T2 - 1) + 2 * pp - qq;
-                            constexpr bool va = m >= 0 && m < T2;
-                            constexpr bool vb = m + 1 >= 0 && m + 1 < T2;
-                            if constexpr (va && vb) {
-                                fa[pp] = fa[pp] + pr[pp];
-                            } else if constexpr (va) {
-                                fa[pp].x = fa[pp].x + pr[pp].x;
-                            } else if constexpr (vb) {
-                                fa[pp].y = fa[pp].y + pr[pp].y;
-                            }
-                        });
-                        if constexpr (L & 1) {
-                            constexpr int ml = (T2 - 1) + (L - 1) - qq;
-                            if constexpr (ml >= 0 && ml < T2) fl = fl + pl;
-                        }
-                    }
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-#pragma unroll
-            for (int pp = 0; pp < Gm::NP; ++pp) {
-                f[2 * pp] = fa[pp].x;
-                f[2 * pp + 1] = fa[pp].y;
-            }
-            if constexpr (L & 1) f[L - 1] = fl;
-        } else {
-            // first samples of the recording (tile 0 only): the reference's `i > j` guard
-#pragma unroll
-            for (int b = 0; b < L; ++b) f[b] = 0.f;
-#pragma unroll 1
-            for (int j = 0; j < T2; ++j) {
-                const float hj = h2[j];
-#pragma unroll
-                for (int b = 0; b < L; ++b) {
-                    const int qi = base + (T2 - 1) + b - j;
-                    if (kt + b > j && qi >= 0) f[b] = f[b] + Q[qi] * hj;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < L; ++b) P[tid * L + b] = f[b];  // R is dead: P now holds F
-    __syncthreads();
-
-    // owned F -> HBM, coalesced 16-byte stores
-    {
-        float *ft = f_out + o0;
-        for (int q = tid * 4; q < Gm::OWN_K; q += kFusedThreads * 4) {
-            if (Gm::PRE_K + q + 3 < k_hi) {
-                *reinterpret_cast<float4 *>(ft + q) = *reinterpret_cast<const float4 *>(P + Gm::PRE_K + q);
-            } else {
-                for (int e = 0; e < 4; ++e)
-                    if (Gm::PRE_K + q + e < k_hi) ft[q + e] = P[Gm::PRE_K + q + e];
-            }
-        }
-    }
-
-    // ---- stage 4: sync cross-correlation (decode.rs:225-233), its group maxima, and C
-    if (gm_out != nullptr) {
-        // F sample q meets output b at template index j = q - b: outputs (b, b+1) add the
-        // same sample with the signs of T[j] and T[j-1] (neg_lo / neg_hi modifiers).
-        constexpr int CH4 = 6;
-        const float *src = P + tid * L;
-        f2 ca[Gm::NP > 0 ? Gm::NP : 1];
-        float cl = 0.f;
-#pragma unroll
-        for (int pp = 0; pp < Gm::NP; ++pp) ca[pp] = (f2){0.f, 0.f};
-        static_for<0, (Gm::FWIN + CH4 - 1) / CH4>([&](auto cc) {
-            constexpr int q0 = decltype(cc)::value * CH4;
-            float fv[CH4];
-#pragma unroll
-            for (int e = 0; e < CH4; ++e) fv[e] = (q0 + e < Gm::FWIN) ? src[q0 + e] : 0.f;
-            static_for<0, CH4>([&](auto ee) {
-                constexpr int q = q0 + decltype(ee)::value;
-                if constexpr (q < Gm::FWIN) {
-                    const float v = fv[decltype(ee)::value];
-                    static_for<0, Gm::NP>([&](auto pc) {
-                        constexpr int pp = decltype(pc)::value;
-                        constexpr int jx = q - 2 * pp, jy = q - 2 * pp - 1;
-                        constexpr bool va = jx >= 0 && jx < Gm::G;
-                        constexpr bool vb = jy >= 0 && jy < Gm::G;
-                        if constexpr (va && vb) {
-                            ca[pp] = ca[pp] + (f2){sync_plus<PW>(jx) ? v : -v, sync_plus<PW>(jy) ? v : -v};
-                        } else if constexpr (va) {
-                            ca[pp].x = sync_plus<PW>(jx) ? ca[pp].x + v : ca[pp].x - v;
-                        } else if constexpr (vb) {
-                            ca[pp].y = sync_plus<PW>(jy) ? ca[pp].y + v : ca[pp].y - v;
-                        }
-                    });
-                    if constexpr (L & 1) {
-                        constexpr int jl = q - (L - 1);
-                        if constexpr (jl >= 0 && jl < Gm::G) cl = sync_plus<PW>(jl) ? cl + v : cl - v;
-                    }
-                }
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        float c[L];
-#pragma unroll
-        for (int pp = 0; pp < Gm::NP; ++pp) {
-            c[2 * pp] = ca[pp].x;
-            c[2 * pp + 1] = ca[pp].y;
-        }
-        if constexpr (L & 1) c[L - 1] = cl;
-        float mx = kNegInfF;
-#pragma unroll
-        for (int b = 0; b < L; ++b) {
-            const int pq = kq + b;
-            float v = c[b];
-            if (pq == k_lo && !(v > 0.f)) v = 0.f;  // the picker starts from the peak (0, 0.)
-            if (pq >= k_lo && pq < c_hi) mx = fmaxf(mx, v);
-            CS[tid * L + b] = c[b];
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-        if ((tid & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads && kq < c_hi)
-            gm_out[o0 / Gm::GS + (tid - kPreThreads) / 4] = mx;
-        __syncthreads();
-        // owned C -> HBM, coalesced 16-byte stores (read by the fine stage of the picker)
-        float *ct = c_out + o0;
-        for (int q = tid * 4; q < Gm::OWN_K; q += kFusedThreads * 4) {
-            if (Gm::PRE_K + q + 3 < c_hi) {
-                *reinterpret_cast<float4 *>(ct + q) = *reinterpret_cast<const float4 *>(CS + Gm::PRE_K + q);
-            } else {
-                for (int e = 0; e < 4; ++e)
-                    if (Gm::PRE_K + q + e < c_hi) ct[q + e] = CS[Gm::PRE_K + q + e];
-            }
-        }
-    }
-}
-
-template <int L, int M, int T1, int T2, int PW, int NTHR, bool F16 = false, bool BATCH = false, typename XT>
-void launch_fused(hipStream_t s, const XT *x, uint64_t n, const float *hb, const float *h2,
-                  const float *h2p, float cosphi2, float sinphi, float inv_sinphi, float f16_unscale, float *f_out,
-                  float *c_out, float *gm_out, uint64_t w,
-                  uint64_t n_corr, const FusedRec *d_batch = nullptr, int count = 1)
-{
-    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
-    constexpr int kFusedThreads = NTHR;
-    const size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
-    auto kern = k_fused<L, M, T1, T2, PW, NTHR, XT, F16, BATCH>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        attr_set = true;
-    }
-    const unsigned tiles = static_cast<unsigned>((w + Gm::OWN_K - 1) / Gm::OWN_K);
-    hipLaunchKernelGGL(kern, dim3(tiles, static_cast<unsigned>(count)), dim3(kFusedThreads), lds, s, x, n,
-                       reinterpret_cast<const f2 *>(hb), h2, reinterpret_cast<const f2 *>(h2p), cosphi2, sinphi,
-                       inv_sinphi, f16_unscale, f_out, c_out, gm_out, w, n_corr, d_batch);
-}
-
-}  // namespace
 
 bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
 {
@@ -721,35 +134,19 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
                      float cosphi2, float sinphi, float inv_sinphi, float f16_unscale, float *f_out, float *c_out,
                      float *gm_out, uint64_t w, uint64_t n_corr)
 {
-    const float *xf = static_cast<const float *>(x);
-    const int16_t *xi = static_cast<const int16_t *>(x);
     if (pcm16 && (reinterpret_cast<uintptr_t>(x) & 3u)) return false;  // dword loads of sample pairs
+    const FusedLaunch a{s, x, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, f16_unscale, f_out, c_out, gm_out,
+                        w, n_corr, nullptr, 1};
     if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
-        if (f16_unscale != 0.f) {  // fp16-tap stage 1: hb is the half2 table of fused_f16_branch_taps
-            if (pcm16)
-                launch_fused<13, 50, 959, 37, 3, 256, true>(s, xi, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi,
-                                                            f16_unscale, f_out, c_out, gm_out, w, n_corr);
-            else
-                launch_fused<13, 50, 959, 37, 3, 256, true>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi,
-                                                            f16_unscale, f_out, c_out, gm_out, w, n_corr);
-            return true;
-        }
-        if (pcm16)
-            launch_fused<13, 50, 959, 37, 3, 256>(s, xi, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, f_out, c_out,
-                                                  gm_out, w, n_corr);
+        if (f16_unscale != 0.f)  // fp16-tap stage 1: hb is the half2 table of fused_f16_branch_taps
+            pcm16 ? fused_launch_48k_f16taps_i16(a) : fused_launch_48k_f16taps_f32(a);
         else
-            launch_fused<13, 50, 959, 37, 3, 256>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, f_out, c_out,
-                                                  gm_out, w, n_corr);
+            pcm16 ? fused_launch_48k_i16(a) : fused_launch_48k_f32(a);
         return true;
     }
-    if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3) {
+    if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3 && f16_unscale == 0.f) {
         // twice the input per work sample: 128-thread workgroups keep the x tile at 51.8 KB
-        if (pcm16)
-            launch_fused<13, 100, 1915, 37, 3, 128>(s, xi, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, f_out, c_out, gm_out,
-                                                    w, n_corr);
-        else
-            launch_fused<13, 100, 1915, 37, 3, 128>(s, xf, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, f_out, c_out, gm_out,
-                                                    w, n_corr);
+        pcm16 ? fused_launch_96k_i16(a) : fused_launch_96k_f32(a);
         return true;
     }
     return false;
@@ -766,18 +163,11 @@ bool fused_front_end_batch(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, u
                            float f16_unscale)
 {
     if (count <= 0 || d_batch == nullptr || f16_unscale != 0.f) return false;
-    const float *xf = nullptr;
-    const int16_t *xi = nullptr;
-    if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
-        if (pcm16)
-            launch_fused<13, 50, 959, 37, 3, 256, false, true>(s, xi, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi,
-                                                               0.f, nullptr, nullptr, nullptr, max_w, 0, d_batch, count);
-        else
-            launch_fused<13, 50, 959, 37, 3, 256, false, true>(s, xf, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi,
-                                                               0.f, nullptr, nullptr, nullptr, max_w, 0, d_batch, count);
-        return true;
-    }
-    return false;  // other geometries: recording by recording
+    if (!fused_batch_supported(l, m, t1, t2, pw)) return false;  // other geometries: recording by recording
+    const FusedLaunch a{s, nullptr, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, nullptr, nullptr, nullptr,
+                        max_w, 0, d_batch, count};
+    pcm16 ? fused_launch_48k_batch_i16(a) : fused_launch_48k_batch_f32(a);
+    return true;
 }
 
 }  // namespace apt::gpu

@@ -1,0 +1,12 @@
+// apt_kernels_fused_any_256x8.hip — the 256-thread, 8-outputs-per-thread launch shape of k_fused_any.
+#include "apt_kernels_fused_any_impl.hpp"
+
+namespace apt::gpu {
+
+void fused_any_launch_256x8(APT_ANY_SHAPE_ARGS)
+{
+    launch_any_shape<256, 8>(s, x, pcm16, n, table, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, c_out, gm_out, w,
+                              n_corr, g, lds, prof);
+}
+
+}  // namespace apt::gpu
