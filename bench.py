@@ -40,7 +40,9 @@ def main():
     ap.add_argument("--rate", type=int, default=48000)
     ap.add_argument("--seconds", type=float, default=600.0)
     ap.add_argument("--profile", default="standard")
-    ap.add_argument("--mode", default="strict", choices=["strict", "generic", "fp16taps"])
+    ap.add_argument("--mode", default="strict", choices=["strict", "generic", "fp16taps", "fast"],
+                    help="strict (default): bit-exact; fast: APTGPU_MODE_FAST, tolerance of SURVEY.md §8(d), "
+                         "checked against the oracle after the timed region")
     ap.add_argument("--inputs", type=int, default=4,
                     help="distinct recordings resident in HBM, decoded round-robin (4 x 115 MB exceeds "
                          "the 256 MB Infinity Cache, so every step reads its input from HBM)")
@@ -90,7 +92,8 @@ def main():
     with torch.cuda.stream(stream):
         d_xs = [torch.from_numpy(v).to(dev) for v in xs]
         d_x = d_xs[0]
-        mode = {"strict": apt.MODE_STRICT, "generic": apt.MODE_GENERIC, "fp16taps": apt.MODE_FP16_TAPS}[args.mode]
+        mode = {"strict": apt.MODE_STRICT, "generic": apt.MODE_GENERIC, "fp16taps": apt.MODE_FP16_TAPS,
+                "fast": apt.MODE_FAST}[args.mode]
         B = max(1, args.batch)
         plan = apt.Plan(settings, rate, not args.no_sync, max_samples=n, max_batch=B, device=local_rank,
                         mode=mode, stream=stream.cuda_stream if args.user_stream else 0)
@@ -127,10 +130,12 @@ def main():
             dist.barrier()
         t1 = time.perf_counter()
         dom_times = plan.collect_timing()
-        # untimed: the dominant kernel with nothing else on the GPU (one step at a time)
-        plan.enable_timing(1)
-        iso_n = 16  # mode 1 samples every 8th dominant launch
-        for _ in range(iso_n):
+        # untimed: the dominant kernel with nothing else on the GPU — one step at a time, a host
+        # synchronisation after each, HIP events around every launch.  This per-launch duration
+        # is what `roofline` uses (a launch in the timed region above shares the GPU with the
+        # launches of the other calls in flight, so its duration there is not GPU time per launch).
+        plan.enable_timing(2)
+        for _ in range(24):
             step()
             torch.cuda.synchronize()
         iso_times = plan.collect_timing()
@@ -142,6 +147,7 @@ def main():
         plan.enable_timing(0)
         step(0)  # the recording that is compared with the oracle below
         res = plan.results(1)[0]
+        ref_pos = plan.sync_positions(0) if not args.no_sync else np.zeros(0, np.uint64)
         torch.cuda.synchronize()
         ref_rows = d_rows[:res.n_out].clone()
 
@@ -219,21 +225,45 @@ def main():
         b_alg = (4.0 * n + 4.0 * 2080.0 * res.n_rows) * max(1, args.batch)  # per call (= per front-end launch)
         src = dom_times if dom_times else ktimes
         dom = max(src.items(), key=lambda kv: kv[1][0]) if src else ("none", (0.0, 0))
-        dom_ms = dom[1][0]
-        achieved = b_alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        dom_ms = dom[1][0]                                   # in the timed region: overlapped with other launches
+        alone_ms, alone_n = iso_times.get(dom[0], (0.0, 0))  # one launch at a time: GPU time per launch
+        achieved = b_alg / (alone_ms * 1e-3) / 1e9 if alone_ms > 0 else 0.0
         kernel_sum_ms = sum(v[0] for v in ktimes.values())
         pipe_achieved = b_alg / (ms_per_step * 1e-3) / 1e9
         # HBM bytes per launch of the dominant kernel as measured with rocprofv3 PMC counters
         # (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 2x read correction applied by
-        # tools/summarize_pmc.py) for THIS workload; null when no matching profile is committed
-        traffic = None
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-            if (args.rate, args.seconds, args.profile, args.mode) == (48000, 600.0, "standard", "strict") \
-                    and dom[0] == "fused_front_end":
-                traffic = prof["per_launch"]["k_fused"]["hbm_total_MB"] * 1e6
-        except Exception:
-            traffic = None
+        # tools/summarize_pmc.py) for THIS workload and mode; null when no matching profile is committed
+        traffic, traffic_src, sq = None, None, None
+        if (args.rate, args.seconds, args.profile, max(1, args.batch)) == (48000, 600.0, "standard", 1) \
+                and dom[0] == "fused_front_end" and args.mode in ("strict", "fast"):
+            try:
+                f = os.path.join(ROOT, "profiles", f"r02_hbm_traffic_{args.mode}.json")
+                traffic = json.load(open(f))["per_launch"]["k_fused"]["hbm_total_MB"] * 1e6
+                traffic_src = f"profiles/r02_hbm_traffic_{args.mode}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            except Exception:
+                traffic = None
+            try:
+                sq = json.load(open(os.path.join(ROOT, "profiles", f"r02_sq_counters_{args.mode}.json")))
+            except Exception:
+                sq = None
+        # arithmetic of the path per work-rate sample: two flops per FIR tap, ~8 for
+        # the envelope, one add per template sample of the strict correlation (22 in fast mode)
+        w_len = float(res.work_len)
+        taps1 = plan.info.n_resample_taps / plan.info.l
+        corr_ops = 22.0 if args.mode == "fast" else float(plan.info.n_sync_taps)
+        flops = w_len * (2.0 * taps1 + 8.0 + 2.0 * plan.info.n_lowpass_taps + corr_ops) * max(1, args.batch)
+        valu = {
+            "note": "the kernel is bound by VALU issue, not HBM (DESIGN.md §5.1): arithmetic of the path per launch "
+                    "over the isolated kernel time, against the 157.3 TFLOP/s fp32 vector peak",
+            "algorithmic_flops_per_launch": flops,
+            "achieved_tflops": round(flops / (alone_ms * 1e-3) / 1e12, 3) if alone_ms > 0 else None,
+            "pct_of_fp32_vector_peak": round(100.0 * flops / (alone_ms * 1e-3) / 157.3e12, 2) if alone_ms > 0 else None,
+        }
+        if sq:
+            valu.update({k: sq[k] for k in ("valu_instructions_per_wave", "waves_per_launch", "issue_floor_us",
+                                            "source") if k in sq})
+            if alone_ms > 0 and "issue_floor_us" in sq:
+                valu["achieved_frac_of_issue_floor"] = round(sq["issue_floor_us"] / (alone_ms * 1e3), 4)
         line = {
             "metric": "Msamples/sec WAV->APT-line decode",
             "value": round(value, 3),
@@ -267,23 +297,24 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": dom[0],
-                "kernel_avg_ms": round(dom_ms, 5),
+                # ONE launch at a time (host synchronisation between steps), HIP events on the launch's stream
+                "kernel_avg_ms": round(alone_ms, 5),
+                "launches_timed": int(alone_n),
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
-                "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-                                  if traffic else None,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": b_alg,
-                # the plan keeps several recordings in flight (6 streams), so a launch in the timed
-                # region shares the GPU with other launches of the same kernel: its duration is
-                # `avg_concurrent_launches` x the time the GPU spends per launch.  Alone it takes:
-                "recordings_in_flight": int(os.environ.get("APTGPU_STREAMS", "6")),
-                "avg_concurrent_launches": round(dom_ms / ms_per_step, 3) if ms_per_step > 0 else None,
-                "kernel_alone_avg_ms": round(iso_times.get(dom[0], (0.0, 0))[0], 5) if iso_times else None,
-                "frac_alone": round(b_alg / (iso_times[dom[0]][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                              if iso_times and iso_times.get(dom[0], (0, 0))[0] > 0 else None,
+                # in the timed region several calls are in flight and their front-end launches share the
+                # GPU: a launch then lasts `avg_concurrent_launches` x the time the GPU spends on it
+                "overlapped": {
+                    "kernel_avg_ms": round(dom_ms, 5),
+                    "calls_in_flight": int(os.environ.get("APTGPU_STREAMS", "0")) or "default",
+                    "avg_concurrent_launches": round(dom_ms / ms_per_step, 3) if ms_per_step > 0 else None,
+                },
+                "valu": valu,
             },
             "pipeline": {
                 "achieved": round(pipe_achieved, 2),
@@ -292,6 +323,7 @@ def main():
                 "sum_kernel_ms": round(kernel_sum_ms, 5),
                 "host_enqueue_ms_per_step": round(1e3 * (t_enq - t0) / args.steps, 5),
                 "kernels_ms": {k: round(v[0], 5) for k, v in sorted(ktimes.items())},
+                "kernels_alone_ms": {k: round(v[0], 5) for k, v in sorted(iso_times.items())},
             },
         }
         if extras:
@@ -318,16 +350,50 @@ def main():
                 "stage_seconds": {k: round(st[k], 4) for k in ("t_resample", "t_demod", "t_filter",
                                                                 "t_sync", "t_gather")},
             }
+            # one oracle instance per host core on the same recording (the reference decodes one file per
+            # process; a batch driver would run one process per core) — bounded: every instance decodes once
+            try:
+                from concurrent.futures import ThreadPoolExecutor
+                cores = max(1, min(os.cpu_count() or 1, 64))
+                a0 = time.perf_counter()
+                with ThreadPoolExecutor(cores) as ex:  # ctypes releases the GIL inside the oracle
+                    list(ex.map(lambda _: oracle.decode(x, args.rate, not args.no_sync, settings=os_), range(cores)))
+                a1 = time.perf_counter()
+                line["cpu_baseline"]["all_cores"] = {
+                    "value": round(cores * n / (a1 - a0) / 1e6, 3), "unit": "Msamples/s", "cores": cores,
+                    "sample": f"{cores} concurrent oracle instances, one decode of the same recording each ({a1 - a0:.2f} s)"}
+            except Exception as e:  # noqa: BLE001 - informational leg
+                line["cpu_baseline"]["all_cores"] = {"error": str(e)}
+            if (args.rate, args.profile) == (48000, "standard") and args.seconds >= 600:
+                # BASELINE config 3's rate on a bounded sample (5 of its 60 minutes)
+                x3 = synth_apt(96000, 300, seed=3)
+                b0 = time.perf_counter()
+                oracle.decode(x3, 96000, True, settings=os_)
+                b1 = time.perf_counter()
+                line["cpu_baseline"]["config3_sample"] = {
+                    "value": round(x3.size / (b1 - b0) / 1e6, 3), "unit": "Msamples/s", "cores": 1,
+                    "sample": f"96 kHz x 300 s ({x3.size} samples, {b1 - b0:.2f} s): 1/12 of config 3"}
             if extras:
                 from oracle import image_binding as oimg
                 i0 = time.perf_counter()
                 oimg.process_gray(ref, oimg.CONTRAST_PERCENT, 0.98)
                 line["cpu_baseline"]["image_stage_seconds"] = round(time.perf_counter() - i0, 4)
-            if args.mode == "fp16taps":
+            if args.mode in ("fp16taps", "fast"):
                 same_shape = got.size == ref.size
                 err = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref))) if same_shape and ref.size else float("nan")
-                line["parity"] = (f"fp16-tap mode: rows {'equal' if same_shape else 'DIFFER'} in count, "
-                                  f"max |err| / max |px| = {err:.2e} (tolerance 2e-3)")
+                if args.mode == "fp16taps":
+                    line["parity"] = (f"fp16-tap mode: rows {'equal' if same_shape else 'DIFFER'} in count, "
+                                      f"max |err| / max |px| = {err:.2e} (tolerance 2e-3)")
+                else:
+                    wp = st["sync_pos"].astype(np.int64)
+                    gp = ref_pos.astype(np.int64)
+                    pos_ok = gp.size == wp.size
+                    off = np.abs(gp - wp) if pos_ok else np.array([99])
+                    ok = bool(same_shape and pos_ok and off.max(initial=0) <= 1 and (off == 0).mean() >= 0.999
+                              and (err <= 1e-4 or (off != 0).any()))
+                    line["parity"] = (f"fast mode vs oracle: rows {'equal' if same_shape else 'DIFFER'} in count, "
+                                      f"sync positions identical {float((off == 0).mean()):.5f} (max off {int(off.max(initial=0))}), "
+                                      f"max |err| / max |px| = {err:.2e} (tolerance 1e-4): {'within' if ok else 'OUTSIDE'} tolerance")
             else:
                 line["parity"] = "bit-exact vs oracle" if parity else "MISMATCH vs oracle"
         print(json.dumps(line), flush=True)

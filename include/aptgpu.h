@@ -92,6 +92,15 @@ typedef struct aptgpu_context {
                                    v_dot2_f32_f16, f32 accumulate (BASELINE.json config 5).  NOT
                                    bit-exact: pixels within ~2e-3 of the row peak, sync positions
                                    unchanged on APT data; every other stage as in STRICT        */
+#define APTGPU_MODE_FAST 3 /* f32 throughout with the same taps in the same order, but fused
+                              multiply-adds in the two FIR stages, the native square root and a
+                              reciprocal multiplication in the envelope, and the +-1 sync correlation
+                              evaluated from pulse sums: about a third of the strict arithmetic.  NOT
+                              bit-exact, deterministic; tolerance (enforced by the tests):
+                              same row count, sync positions identical for >= 99.9 % of the rows and
+                              never off by more than one work-rate sample, |d px| <= 1e-4 * max|px| on
+                              rows with identical position.  Rates / profiles without a fast kernel
+                              are served by the strict kernels. */
 
 /* What find_sync()/decode() learned; the reference only logs it
  * (`info!("Found {} sync frames")` src/decode.rs:260). */

@@ -32,5 +32,5 @@ from .api import (  # noqa: F401
     get_min, get_max, percent, map_signal_u8, read_telemetry, process,
     Plan, PlanInfo, Result, KernelTime,
     lib, lib_path, build, device_count, version,
-    MODE_STRICT, MODE_GENERIC, MODE_FP16_TAPS,
+    MODE_STRICT, MODE_GENERIC, MODE_FP16_TAPS, MODE_FAST,
 )

@@ -14,6 +14,7 @@ CARRIER_FREQ = 2400  # decode.rs:38
 MODE_STRICT = 0
 MODE_GENERIC = 1
 MODE_FP16_TAPS = 2
+MODE_FAST = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libaptgpu.so")

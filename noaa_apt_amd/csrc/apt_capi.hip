@@ -73,14 +73,8 @@ void aptgpu_plan_destroy(aptgpu_plan *plan)
 {
     if (!plan) return;
     (void)hipSetDevice(plan->device);
-    if (plan->stream_front) (void)hipStreamSynchronize(plan->stream_front);
     for (hipStream_t st : plan->streams) (void)hipStreamSynchronize(st);
     if (plan->ev_user) (void)hipEventDestroy(plan->ev_user);
-    if (plan->ev_front) (void)hipEventDestroy(plan->ev_front);
-    for (auto &sl : plan->slots)
-        if (sl.ev_free) (void)hipEventDestroy(sl.ev_free);
-    if (plan->h_batch) (void)hipHostFree(plan->h_batch);
-    if (plan->stream_front) (void)hipStreamDestroy(plan->stream_front);
     for (hipStream_t st : plan->streams) (void)hipStreamDestroy(st);
     delete plan;
 }
@@ -117,19 +111,14 @@ int aptgpu_plan_decode_device(aptgpu_plan *plan, int count, const float *const *
         for (int i = 0; i < count; ++i)
             if (n[i] > plan->max_samples)
                 throw Error{ErrorKind::Invalid, "recording longer than the plan's max_samples"};
-        plan->begin_call(count);
-        if (count >= 2) {  // one front-end launch for the whole call where the geometry allows it
-            std::vector<aptgpu_plan::Input> ins(static_cast<size_t>(count));
-            std::vector<uint64_t> caps(static_cast<size_t>(count));
-            for (int i = 0; i < count; ++i) {
-                ins[static_cast<size_t>(i)].ptr = d_signals[i];
-                ins[static_cast<size_t>(i)].n = n[i];
-                caps[static_cast<size_t>(i)] = static_cast<uint64_t>(rows_cap[i]) * 2080u;
-            }
-            if (plan->enqueue_batch(count, ins.data(), d_rows, caps.data())) return APTGPU_OK;
+        std::vector<aptgpu_plan::Input> ins(static_cast<size_t>(count));
+        std::vector<uint64_t> caps(static_cast<size_t>(count));
+        for (int i = 0; i < count; ++i) {
+            ins[static_cast<size_t>(i)].ptr = d_signals[i];
+            ins[static_cast<size_t>(i)].n = n[i];
+            caps[static_cast<size_t>(i)] = static_cast<uint64_t>(rows_cap[i]) * 2080u;
         }
-        for (int i = 0; i < count; ++i)
-            plan->enqueue(i, d_signals[i], n[i], d_rows[i], rows_cap[i] * 2080u, false);
+        plan->run_call(count, ins.data(), d_rows, caps.data(), false);
         return APTGPU_OK;
     });
 }
@@ -151,7 +140,7 @@ int aptgpu_plan_join(aptgpu_plan *plan)
     if (!plan) return APTGPU_ERR_INVALID;
     if (!plan->user_stream) return aptgpu_plan_synchronize(plan);
     (void)hipSetDevice(plan->device);
-    // ctx.stream waits (on the device) for everything enqueued so far on both internal streams
+    // ctx.stream waits (on the device) for everything enqueued so far on the internal streams
     for (hipStream_t st : plan->streams) {
         if (hipEventRecord(plan->ev_user, st) != hipSuccess ||
             hipStreamWaitEvent(plan->user_stream, plan->ev_user, 0) != hipSuccess)
@@ -242,7 +231,7 @@ int aptgpu_plan_read_internal(aptgpu_plan *plan, int i, const char *name, void *
     }
     if (n == "filtered") { src = sl.filtered.ptr; size = sl.filtered.count * sizeof(float); }
     else if (n == "correlation") { src = sl.correlation.ptr; size = sl.correlation.count * sizeof(float); }
-    else if (n == "group_max") { src = sl.gm.ptr; size = sl.gm.count * sizeof(float); }
+    else if (n == "group_max") { src = sl.gm.ptr; size = sl.gm.count * sizeof(apt::gpu::GroupMax); }
     else if (n == "terminal_words") { src = sl.words.ptr; size = sl.words.count * sizeof(uint64_t); }
     else if (n == "peaks") { src = sl.peaks.ptr; size = sl.peaks.count * sizeof(uint32_t); }
     else if (n == "picker_flags") { src = sl.flags.ptr; size = sl.flags.count * sizeof(uint32_t); }
@@ -311,8 +300,9 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
             sync ? static_cast<uint64_t>(plan->max_rows) * 2080u : plan->out_len_nosync(w) + 16;
         d_rows.alloc(out_cap);
 
-        plan->begin_call(1);
-        plan->enqueue(0, in, d_rows.ptr, out_cap, steps);
+        float *rows_ptr = d_rows.ptr;
+        const uint64_t cap64 = out_cap;
+        plan->run_call(1, &in, &rows_ptr, &cap64, steps);
         aptgpu_plan::Slot &sl = plan->slot_of(0);
         if (steps) plan->sync_all();  // the step exports below read the slot's buffers
         if (wav && steps) {
@@ -388,8 +378,26 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
             if (steps) {
                 const uint64_t aligned = w / plan->spr * plan->spr;
                 step(&ctx, steps, "sync_result", 0, filtered_host.data(), aligned, work);
+                status(&ctx, 0.90f, "Resampling to 4160");
+                // final resample_with_filter(NoFilter) (decode.rs:158-159): the steps of dsp.rs:96-122
+                const float one = 1.f;
+                step(&ctx, steps, "resample_filter", 1, &one, 1, 0);
+                if (plan->l2 > 1) {
+                    // fast_resampling: the expanded signal is empty unless export_resample_filtered
+                    step(&ctx, steps, "resample_filtered", 0, nullptr, 0, work * plan->l2);
+                } else {
+                    // filter([1.]): 0.0 + x*1.0, and nothing at all for sample 0 (the `i > j` guard)
+                    apt::DeviceBuffer<float> d_fl;
+                    d_fl.alloc(aligned + 16);
+                    apt::gpu::fir_decimate(s, sl.filtered.ptr, aligned, plan->d_one.ptr, 1, 1, d_fl.ptr, aligned);
+                    apt::Signal fl = download(d_fl.ptr, aligned, s);
+                    step(&ctx, steps, "filter_filter", 1, &one, 1, 0);
+                    step(&ctx, steps, "filter_result", 0, fl.data(), fl.size(), 0);
+                    step(&ctx, steps, "resample_filtered", 0, fl.data(), fl.size(), work);
+                }
+            } else {
+                status(&ctx, 0.90f, "Resampling to 4160");
             }
-            status(&ctx, 0.90f, "Resampling to 4160");
         }
         if (res.status != APTGPU_OK)
             throw Error{ErrorKind::Internal, res.reason == 2 ? kFewSync
@@ -613,7 +621,7 @@ int aptgpu_find_sync(const aptgpu_context *ctx, const float *signal, size_t n,
         } else {
             const uint64_t ng = n_corr / apt::gpu::sync_group_size() + 2;
             const uint64_t chunks = ng / apt::gpu::sync_chunk_groups() + 2;
-            apt::DeviceBuffer<float> d_gm;
+            apt::DeviceBuffer<apt::gpu::GroupMax> d_gm;
             d_gm.alloc(ng + 64);
             apt::DeviceBuffer<uint64_t> d_words;
             d_words.alloc(ng + 64);
@@ -623,15 +631,36 @@ int aptgpu_find_sync(const aptgpu_context *ctx, const float *signal, size_t n,
             d_flags.alloc(32);
             apt::hip_check(hipMemsetAsync(d_flags.ptr, 0, 32 * sizeof(uint32_t), sc.stream), "hipMemsetAsync");
             const char *fw = std::getenv("APTGPU_FORCE_WALK");
-            const char *fg = std::getenv("APTGPU_PICKER_LDS");
-            apt::gpu::group_max(sc.stream, d_c.ptr, n_corr, d_gm.ptr);
-            apt::gpu::sync_nodes(sc.stream, d_gm.ptr, d_c.ptr, n_corr, spr, md, d_words.ptr, d_slot.ptr,
-                                 d_cnt.ptr, d_flags.ptr);
             apt::DeviceBuffer<uint32_t> d_ws;
-            d_ws.alloc(apt::gpu::sync_orbit_ws_words(n_corr, spr));
-            apt::gpu::sync_orbit(sc.stream, d_words.ptr, d_slot.ptr, d_cnt.ptr, d_flags.ptr, n_corr, n,
-                                 spr, md, d_ws.ptr, d_peaks.ptr, cap, d_res.ptr,
-                                 (fw && fw[0] == '1') ? 1 : ((fg && fg[0] == '1') ? 4 : 0));
+            d_ws.alloc(apt::gpu::sync_orbit_ws_words(n, spr));
+            // a one-recording "call" over a one-entry slot table
+            apt::gpu::SlotPtrs sp{};
+            sp.f = d_f.ptr;
+            sp.gm = d_gm.ptr;
+            sp.corr = d_c.ptr;
+            sp.words = d_words.ptr;
+            sp.slot_nt = d_slot.ptr;
+            sp.slot_cnt = d_cnt.ptr;
+            sp.flags = d_flags.ptr;
+            sp.orbit_ws = d_ws.ptr;
+            sp.peaks = d_peaks.ptr;
+            sp.res = d_res.ptr;
+            sp.peaks_cap = cap;
+            apt::DeviceBuffer<apt::gpu::SlotPtrs> d_sp;
+            d_sp.alloc(1);
+            apt::hip_check(hipMemcpyAsync(d_sp.ptr, &sp, sizeof sp, hipMemcpyHostToDevice, sc.stream), "hipMemcpyAsync");
+            apt::gpu::CallArgs call{};
+            call.count = 1;
+            call.rec[0].x = nullptr;
+            call.rec[0].n = 0;
+            call.rec[0].w = n;
+            call.rec[0].rows = nullptr;
+            call.rec[0].rows_cap = 0;
+            call.rec[0].slot = 0;
+            apt::gpu::group_max(sc.stream, d_c.ptr, n_corr, d_gm.ptr);
+            apt::gpu::sync_nodes(sc.stream, call, d_sp.ptr, n, pw, spr, md, false, true);
+            apt::gpu::sync_orbit(sc.stream, call, d_sp.ptr, spr, md, pw, (fw && fw[0] == '1') ? 1 : 0);
+            apt::hip_check(hipGetLastError(), "kernel launch (find_sync)");
             apt::hip_check(hipStreamSynchronize(sc.stream), "hipStreamSynchronize");
         }
         apt::gpu::Result r{};

@@ -295,7 +295,6 @@ int aptgpu_plan_decode_device_wav(aptgpu_plan *plan, int count, const void *cons
             if (!d_data[i] || !d_rows[i]) throw Error{ErrorKind::Invalid, "null device pointer"};
         }
         apt::hip_check(hipSetDevice(plan->device), "hipSetDevice");
-        plan->begin_call(count);
         std::vector<aptgpu_plan::Input> ins(static_cast<size_t>(count));
         std::vector<uint64_t> caps(static_cast<size_t>(count));
         for (int i = 0; i < count; ++i) {
@@ -307,10 +306,7 @@ int aptgpu_plan_decode_device_wav(aptgpu_plan *plan, int count, const void *cons
             in.codec = specs[i].codec;
             caps[static_cast<size_t>(i)] = static_cast<uint64_t>(rows_cap[i]) * 2080u;
         }
-        // all aligned mono PCM16: one front-end launch for the whole call
-        if (count >= 2 && plan->enqueue_batch(count, ins.data(), d_rows, caps.data())) return APTGPU_OK;
-        for (int i = 0; i < count; ++i)
-            plan->enqueue(i, ins[static_cast<size_t>(i)], d_rows[i], caps[static_cast<size_t>(i)], false);
+        plan->run_call(count, ins.data(), d_rows, caps.data(), false);
         return APTGPU_OK;
     });
 }

@@ -63,7 +63,7 @@ __device__ __forceinline__ float envelope_fast(float x, float sinphi, float inv_
 }
 
 // Host: true when fast_divide(x, c, rc) == x / c bit for bit for every x whose result stays in
-// the normal range (exhaustive over the significands; run once per plan).
-bool verify_fast_divide(hipStream_t s, float c, float rc);
+// the normal range (exhaustive over the significands; once per device and divisor).
+bool verify_fast_divide(int device, float c, float rc);
 
 }  // namespace apt::gpu

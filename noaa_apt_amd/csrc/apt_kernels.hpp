@@ -33,6 +33,47 @@ struct ImageResult {
     float values_a[16], values_b[16];
 };
 
+// Per-group record the front ends hand to the picker: maximum of the sync correlation over the
+// group's positions ignoring NaNs (position 0 clamped to >= 0: the picker starts from the peak
+// (0, 0.), decode.rs:208), and whether any position of the group is NaN.  A NaN position is never
+// exceeded (`corr > NaN` is false, decode.rs:250), so it is a terminal of the picker whatever the
+// finite values around it are: its group must reach the exact test even when the group's finite
+// maximum loses the coarse comparison.
+struct GroupMax {
+    float max;
+    float has_nan;  // 0.f or 1.f
+};
+
+// ---- one decode_device call = one launch per stage over all its recordings -----------
+// Per-recording arguments travel BY VALUE in the kernel-argument segment (no H2D copy, no pinned
+// staging, nothing for the host to wait on); blockIdx.y (front end, k_sync_nodes, k_gather_rows) or
+// blockIdx.x (k_sync_orbit) picks the recording.  The workspace of a recording is a slot of the
+// plan; the slots' pointers sit in a device table written once at plan creation.
+constexpr int kMaxCall = 32;  // recordings per launch; longer calls are split
+struct RecArgs {
+    const void *x;       // f32 Signal, or mono PCM16 payload (front end only)
+    uint64_t n;          // input samples
+    uint64_t w;          // work-rate samples (fast_resampling_len / decimation length)
+    float *rows;         // output pixel rows
+    uint32_t rows_cap;   // rows `rows` has room for
+    uint32_t slot;       // index into the slot table
+};
+struct CallArgs {
+    uint32_t count;
+    uint32_t reserved;
+    RecArgs rec[kMaxCall];
+};
+struct SlotPtrs {
+    float *f;               // filtered work-rate signal F
+    GroupMax *gm;           // per-group correlation maxima
+    const float *corr;      // full correlation (unfused path / step export only), else nullptr
+    uint64_t *words;        // 52-bit terminal words
+    uint32_t *slot_nt, *slot_cnt, *flags, *orbit_ws, *peaks;
+    Result *res;
+    uint32_t peaks_cap;
+    uint32_t reserved;
+};
+
 // ---- generic kernels (any l, m, tap count) --------------------------------------
 // fast_resampling, dsp.rs:186-289: out[k], k < w
 void resample_generic(hipStream_t s, const float *x, uint64_t n, const float *coeff,
@@ -59,8 +100,11 @@ void orbit_walk(hipStream_t s, const uint64_t *bits, uint64_t n_corr, uint64_t w
                 uint32_t spr, uint32_t md, uint32_t *peaks, uint32_t peaks_cap, Result *res);
 // row gather (decode.rs:120-134) taking every pw-th sample; raw = plain copy (the
 // "sync_result" step), !raw = through the final NoFilter stage (decode.rs:158-159)
-void gather_rows(hipStream_t s, const float *f, const uint32_t *peaks, const Result *res,
+void gather_rows(hipStream_t s, const float *f, const uint32_t *peaks, Result *res,
                  uint32_t spr, uint32_t pw, bool raw, float *rows, uint32_t rows_cap);
+// the same for the recordings of one call: rows / rows_cap from the call, F / peaks / res from the slots
+void gather_rows_call(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint32_t spr, uint32_t pw,
+                      uint32_t max_rows_cap);
 
 // ---- fused specialised front end (apt_kernels_fused.hip) --------------------------
 // true when a <L, M, T1, T2, PW> specialisation exists
@@ -71,33 +115,32 @@ uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1);
 void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, float *hs);
 // host: stage-3 tap pairs h2p[k] = (h2[k-1], h2[k]), k = 0 .. t2  (2*(t2+1) floats)
 void fused_lowpass_pairs(const float *h2, uint32_t t2, float *h2p);
-// One recording of a batched front-end launch (device-resident array, blockIdx.y selects).
-struct FusedRec {
-    const void *x;
-    uint64_t n;
-    float *f_out, *c_out, *gm_out;
-    uint64_t w, n_corr;
-};
 // fp16-tap stage 1 (APTGPU_MODE_FP16_TAPS): table size in dwords, host-side table builder (returns
 // the power-of-two unscale factor), availability
 uint32_t fused_f16_table_dwords(uint32_t l, uint32_t m, uint32_t t1);
 float fused_f16_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, uint32_t *table);
 bool fused_f16_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
-// x -> F (filtered work-rate signal) and, if gm_out != nullptr, the per-group maxima of
-// the sync cross-correlation.  Returns false if no specialisation matches.
-// x is the f32 Signal, or (pcm16) mono int16 samples at a 4-byte aligned address.
-bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
-                     const void *x, bool pcm16, uint64_t n, const float *hs, const float *h2, const float *h2p,
-                     float cosphi2, float sinphi, float inv_sinphi /* verified RN(1/sinphi) or 0, apt_envelope.hpp */,
-                     float f16_unscale /* 0: strict; else hs is the fp16 table and this its 2^-s */, float *f_out, float *c_out, float *gm_out, uint64_t w, uint64_t n_corr);
-
-// Batched form: ONE launch over `count` recordings described by d_batch (in HBM, written before the
-// launch on the same stream); grid.x covers the longest recording (max_w work samples).
-bool fused_batch_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
-bool fused_front_end_batch(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
-                           bool pcm16, const FusedRec *d_batch, int count, uint64_t max_w, const float *hs,
-                           const float *h2, const float *h2p, float cosphi2, float sinphi, float inv_sinphi,
-                           float f16_unscale);
+// fast mode (APTGPU_MODE_FAST): availability (same tables as strict)
+bool fused_fast_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
+// Per-plan parameters of the specialised front end, resident in HBM (the kernel fetches each when
+// the stage that needs it starts, instead of holding them in SGPRs from its first instruction on).
+struct FusedParams {
+    const float *hs;        // stage-1 table: tap pairs (fused_branch_taps), or the fp16 table
+    const float *h2;        // low-pass taps [T2]
+    const float *h2p;       // low-pass tap pairs (fused_lowpass_pairs)
+    const SlotPtrs *slots;  // the plan's slot table
+    float cosphi2, sinphi;
+    float inv_sinphi;       // strict: verified RN(1/sinphi) or 0 (apt_envelope.hpp); fast: RN(1/sinphi)
+    float f16_unscale;      // 2^-s of the fp16 tap prescale (fp16-tap mode)
+    int32_t want_gm;        // sync search wanted: emit the per-group correlation maxima
+    int32_t reserved;
+};
+// One launch over the recordings of `call`: x -> F (slot's filtered buffer) and, if prm->want_gm, the
+// per-group maxima of the sync cross-correlation.  Returns false if no specialisation matches.
+// Inputs are f32 Signals, or (pcm16) mono int16 samples at 4-byte aligned addresses.
+// mode: 0 strict, 1 fp16 taps, 2 fast.
+bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, int mode,
+                     bool pcm16, const CallArgs &call, const FusedParams *d_prm, uint64_t max_w);
 
 // ---- fused front end for any rate / profile (apt_kernels_fused_any.hip) -------------
 // run-time parameters, taps phase-major in LDS; same outputs as fused_front_end
@@ -107,23 +150,26 @@ void fused_any_table(uint32_t l, const float *coeff, uint32_t t1, float *table);
 bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
                          const void *x, bool pcm16, uint64_t n, const float *table, const float *h2,
                          const float *h2p /* fused_lowpass_pairs */, float cosphi2, float sinphi, float inv_sinphi, float *f_out,
-                         float *c_out, float *gm_out, uint64_t w, uint64_t n_corr);
+                         GroupMax *gm_out, uint64_t w, uint64_t n_corr);
 
 // ---- parallel peak picker (apt_kernels_sync.hip) ------------------------------------
+// Each launch covers the recordings of one call (CallArgs by value, slot table in HBM).
 uint32_t sync_group_size();    // correlation positions per group (52)
 uint32_t sync_chunk_groups();  // groups per k_sync_nodes workgroup
 uint32_t sync_slot_cap();      // node terminals kept per chunk
-// corr -> per-group maxima (unfused path; the fused front end writes them itself)
-void group_max(hipStream_t s, const float *corr, uint64_t n_corr, float *gm);
-// coarse/fine terminal detection -> terminal words + ordered node-terminal lists
-void sync_nodes(hipStream_t s, const float *gm, const float *corr, uint64_t n_corr, uint32_t spr,
-                uint32_t md, uint64_t *words, uint32_t *slot_nt, uint32_t *slot_cnt, uint32_t *flags);
-// orbit of the picker (LDS pointer doubling, or the sequential walk as fallback)
-size_t sync_orbit_ws_words(uint64_t n_corr, uint32_t spr);  // uint32 words of scratch it needs
-void sync_orbit(hipStream_t s, const uint64_t *words, const uint32_t *slot_nt,
-                const uint32_t *slot_cnt, uint32_t *flags, uint64_t n_corr, uint64_t work_len,
-                uint32_t spr, uint32_t md, uint32_t *ws, uint32_t *peaks, uint32_t peaks_cap,
-                Result *res, int force /* 0 global-memory kernel, 1 sequential walk, 4 LDS kernel first */);
+// corr -> per-group maxima (unfused path; the fused front ends write them themselves)
+void group_max(hipStream_t s, const float *corr, uint64_t n_corr, GroupMax *gm);
+// coarse/fine terminal detection -> terminal words + ordered node-terminal lists.  use_corr: read
+// the slots' full correlation (unfused kernels); else the correlation of the candidate groups is
+// re-evaluated from F — strictly (the reference's chain) or, `fast`, from pulse sums, exactly as the
+// front end of that mode did.
+void sync_nodes(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint64_t max_w, uint32_t pw,
+                uint32_t spr, uint32_t md, bool fast, bool use_corr);
+// orbit of the picker (direct / pointer doubling, or the sequential walk as fallback): peak
+// list + result record of every recording
+size_t sync_orbit_ws_words(uint64_t w, uint32_t spr);  // uint32 words of scratch it needs
+void sync_orbit(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint32_t spr, uint32_t md,
+                uint32_t pw, int force /* 0 parallel picker, 1 sequential walk */);
 
 // ---- consumers of the pixel rows (apt_kernels_image.hip) ------
 // All take the pixel count from `res` (device) when it is non-null, else `n`; `cap` bounds it
@@ -162,8 +208,9 @@ void wav_to_signal(hipStream_t s, const void *d_data, uint64_t n_frames, uint32_
 void quantize_i16(hipStream_t s, const float *d_x, uint64_t n, const float *d_limits, int16_t *d_out);
 
 // exhaustive device-side check that division by c through rc = RN(1/c) + one FMA correction is
-// correctly rounded (apt_envelope.hpp); run once per plan
-bool verify_fast_divide(hipStream_t s, float c, float rc);
+// correctly rounded (apt_envelope.hpp); run once per (device, divisor) and process, on a stream of
+// its own (the current device must be `device`)
+bool verify_fast_divide(int device, float c, float rc);
 
 // writes a result record from the host's knowledge (too-short recording, no-sync path)
 void set_result(hipStream_t s, Result *res, Result value);

@@ -129,45 +129,37 @@ bool fused_f16_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint3
     return l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3;
 }
 
-bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
-                     const void *x, bool pcm16, uint64_t n, const float *hb, const float *h2, const float *h2p,
-                     float cosphi2, float sinphi, float inv_sinphi, float f16_unscale, float *f_out, float *c_out,
-                     float *gm_out, uint64_t w, uint64_t n_corr)
+bool fused_fast_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
 {
-    if (pcm16 && (reinterpret_cast<uintptr_t>(x) & 3u)) return false;  // dword loads of sample pairs
-    const FusedLaunch a{s, x, n, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, f16_unscale, f_out, c_out, gm_out,
-                        w, n_corr, nullptr, 1};
+    return fused_supported(l, m, t1, t2, pw);
+}
+
+bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, int mode,
+                     bool pcm16, const CallArgs &call, const FusedParams *d_prm, uint64_t max_w)
+{
+    if (call.count == 0 || call.count > static_cast<uint32_t>(kMaxCall)) return false;
+    if (pcm16)  // dword loads of sample pairs
+        for (uint32_t i = 0; i < call.count; ++i)
+            if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 3u) return false;
+    const FusedLaunch a{s, &call, d_prm, max_w};
     if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
-        if (f16_unscale != 0.f)  // fp16-tap stage 1: hb is the half2 table of fused_f16_branch_taps
+        if (mode == kModeF16Taps)  // fp16-tap stage 1: hb is the half2 table of fused_f16_branch_taps
             pcm16 ? fused_launch_48k_f16taps_i16(a) : fused_launch_48k_f16taps_f32(a);
+        else if (mode == kModeFast)
+            pcm16 ? fused_launch_48k_fast_i16(a) : fused_launch_48k_fast_f32(a);
         else
             pcm16 ? fused_launch_48k_i16(a) : fused_launch_48k_f32(a);
         return true;
     }
-    if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3 && f16_unscale == 0.f) {
+    if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3 && mode != kModeF16Taps) {
         // twice the input per work sample: 128-thread workgroups keep the x tile at 51.8 KB
-        pcm16 ? fused_launch_96k_i16(a) : fused_launch_96k_f32(a);
+        if (mode == kModeFast)
+            pcm16 ? fused_launch_96k_fast_i16(a) : fused_launch_96k_fast_f32(a);
+        else
+            pcm16 ? fused_launch_96k_i16(a) : fused_launch_96k_f32(a);
         return true;
     }
     return false;
-}
-
-bool fused_batch_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
-{
-    return l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3;  // the 48 kHz standard kernel
-}
-
-bool fused_front_end_batch(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
-                           bool pcm16, const FusedRec *d_batch, int count, uint64_t max_w, const float *hb,
-                           const float *h2, const float *h2p, float cosphi2, float sinphi, float inv_sinphi,
-                           float f16_unscale)
-{
-    if (count <= 0 || d_batch == nullptr || f16_unscale != 0.f) return false;
-    if (!fused_batch_supported(l, m, t1, t2, pw)) return false;  // other geometries: recording by recording
-    const FusedLaunch a{s, nullptr, 0, hb, h2, h2p, cosphi2, sinphi, inv_sinphi, 0.f, nullptr, nullptr, nullptr,
-                        max_w, 0, d_batch, count};
-    pcm16 ? fused_launch_48k_batch_i16(a) : fused_launch_48k_batch_f32(a);
-    return true;
 }
 
 }  // namespace apt::gpu

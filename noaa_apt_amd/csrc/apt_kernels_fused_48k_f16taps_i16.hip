@@ -3,6 +3,6 @@
 
 namespace apt::gpu {
 
-void fused_launch_48k_f16taps_i16(const FusedLaunch &a) { launch_fused_args<13, 50, 959, 37, 3, 256, true, false, int16_t>(a); }
+void fused_launch_48k_f16taps_i16(const FusedLaunch &a) { launch_fused_args<13, 50, 959, 37, 3, 256, kModeF16Taps, int16_t>(a); }
 
 }  // namespace apt::gpu

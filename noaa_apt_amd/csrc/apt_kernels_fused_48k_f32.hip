@@ -3,6 +3,6 @@
 
 namespace apt::gpu {
 
-void fused_launch_48k_f32(const FusedLaunch &a) { launch_fused_args<13, 50, 959, 37, 3, 256, false, false, float>(a); }
+void fused_launch_48k_f32(const FusedLaunch &a) { launch_fused_args<13, 50, 959, 37, 3, 256, kModeStrict, float>(a); }
 
 }  // namespace apt::gpu

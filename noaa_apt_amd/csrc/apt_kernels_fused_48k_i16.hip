@@ -3,6 +3,6 @@
 
 namespace apt::gpu {
 
-void fused_launch_48k_i16(const FusedLaunch &a) { launch_fused_args<13, 50, 959, 37, 3, 256, false, false, int16_t>(a); }
+void fused_launch_48k_i16(const FusedLaunch &a) { launch_fused_args<13, 50, 959, 37, 3, 256, kModeStrict, int16_t>(a); }
 
 }  // namespace apt::gpu

@@ -6,6 +6,7 @@
 #include "apt_kernels_fused_any_launch.hpp"
 #include "apt_envelope.hpp"
 
+#include <atomic>
 #include <type_traits>
 
 #pragma clang fp contract(off)
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(NTHR)
 k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ table /*[l][tpp]*/,
             const float *__restrict__ h2, const f2 *__restrict__ h2p /*[t2+1] (h2[k-1], h2[k])*/,
             float cosphi2, float sinphi, float inv_sinphi, float *__restrict__ f_out,
-            float *__restrict__ c_out, float *__restrict__ gm_out, uint64_t w, uint64_t n_corr, AnyGeom G)
+            GroupMax *__restrict__ gm_out, uint64_t w, uint64_t n_corr, AnyGeom G)
 {
     extern __shared__ float lds[];
     float *T = lds;
@@ -369,17 +370,8 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
     }
     __syncthreads();
 
-    // ---- stage 5b: owned C -> HBM, group maxima
-    for (uint32_t q = tid * 4; q < G.own; q += NTHR * 4) {
-        const uint64_t k = static_cast<uint64_t>(o0) + q;
-        const float *src = B + P(static_cast<int>(G.pre + q));
-        if (k + 3 < n_corr) {
-            *reinterpret_cast<float4 *>(c_out + k) = make_float4(src[0], src[1], src[2], src[3]);
-        } else {
-            for (int e = 0; e < 4; ++e)
-                if (k + e < n_corr) c_out[k + e] = src[e];
-        }
-    }
+    // ---- stage 5b: group maxima (the correlation itself stays on the CU: k_sync_nodes re-evaluates
+    // it for the candidate groups).  NaNs are left out of the maximum and reported separately.
     for (uint32_t g = tid; g < G.own / kGS; g += NTHR) {
         const uint64_t k = static_cast<uint64_t>(o0) + static_cast<uint64_t>(g) * kGS;
         if (k >= n_corr) break;
@@ -388,31 +380,40 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
 #pragma unroll
         for (int o = 0; o < kGS; ++o) cv[o] = B[P(base + o)];  // all 52 reads in flight
         float mx = kNegInfAny;
+        bool has_nan = false;
 #pragma unroll
         for (int o = 0; o < kGS; ++o) {
             float v = cv[o];
             if (k + o == 0 && !(v > 0.f)) v = 0.f;  // the picker starts from the peak (0, 0.)
-            mx = (k + o < n_corr) ? fmaxf(mx, v) : mx;
+            if (k + o < n_corr) {
+                mx = fmaxf(mx, v);
+                has_nan = has_nan || (v != v);
+            }
         }
-        gm_out[static_cast<uint64_t>(o0) / kGS + g] = mx;
+        gm_out[static_cast<uint64_t>(o0) / kGS + g] = GroupMax{mx, has_nan ? 1.f : 0.f};
     }
 }
 
 template <int NTHR, int KPT, int T2C, int PWC, typename XT>
 void launch_any(hipStream_t s, const XT *x, uint64_t n, const float *table, const float *h2, const float *h2p,
-                float cosphi2, float sinphi, float inv_sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w, uint64_t n_corr,
+                float cosphi2, float sinphi, float inv_sinphi, float *f_out, GroupMax *gm_out, uint64_t w, uint64_t n_corr,
                 const AnyGeom &g, size_t lds)
 {
     auto kern = k_fused_any<NTHR, KPT, XT, T2C, PWC>;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds && lds > 48 * 1024) {
+    // (a per-device property of the function: plans on several devices / threads pass through here)
+    constexpr int kMaxDevices = 64;
+    static std::atomic<size_t> attr_lds[kMaxDevices];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (lds > attr_lds[dev].load(std::memory_order_acquire) && lds > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   static_cast<int>(lds));
-        attr_lds = lds;
+        attr_lds[dev].store(lds, std::memory_order_release);
     }
     const unsigned tiles = static_cast<unsigned>((w + g.own - 1) / g.own);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHR), lds, s, x, n, table, h2, reinterpret_cast<const f2 *>(h2p), cosphi2,
-                       sinphi, inv_sinphi, f_out, c_out,
+                       sinphi, inv_sinphi, f_out,
                        gm_out, w, n_corr, g);
 }
 
@@ -420,18 +421,18 @@ void launch_any(hipStream_t s, const XT *x, uint64_t n, const float *table, cons
 // all profiles x input types of one launch shape
 template <int NT, int KP>
 void launch_any_shape(hipStream_t s, const void *x, bool pcm16, uint64_t n, const float *table, const float *h2,
-                      const float *h2p, float cosphi2, float sinphi, float inv_sinphi, float *f_out, float *c_out,
-                      float *gm_out, uint64_t w, uint64_t n_corr, const AnyGeom &g, size_t lds, int prof)
+                      const float *h2p, float cosphi2, float sinphi, float inv_sinphi, float *f_out,
+                      GroupMax *gm_out, uint64_t w, uint64_t n_corr, const AnyGeom &g, size_t lds, int prof)
 {
     const float *xf = static_cast<const float *>(x);
     const int16_t *xi = static_cast<const int16_t *>(x);
 #define APT_ANY_LAUNCH(T2C, PWC)                                                                                \
     do {                                                                                                        \
         if (pcm16)                                                                                              \
-            launch_any<NT, KP, T2C, PWC>(s, xi, n, table, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, c_out,   \
+            launch_any<NT, KP, T2C, PWC>(s, xi, n, table, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out,          \
                                          gm_out, w, n_corr, g, lds);                                            \
         else                                                                                                    \
-            launch_any<NT, KP, T2C, PWC>(s, xf, n, table, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, c_out,   \
+            launch_any<NT, KP, T2C, PWC>(s, xf, n, table, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out,          \
                                          gm_out, w, n_corr, g, lds);                                            \
         return;                                                                                                 \
     } while (0)

@@ -21,7 +21,7 @@ struct AnyGeom {
 
 #define APT_ANY_SHAPE_ARGS                                                                                       \
     hipStream_t s, const void *x, bool pcm16, uint64_t n, const float *table, const float *h2, const float *h2p, \
-        float cosphi2, float sinphi, float inv_sinphi, float *f_out, float *c_out, float *gm_out, uint64_t w,    \
+        float cosphi2, float sinphi, float inv_sinphi, float *f_out, GroupMax *gm_out, uint64_t w,    \
         uint64_t n_corr, const AnyGeom &g, size_t lds, int prof
 void fused_any_launch_256x8(APT_ANY_SHAPE_ARGS);
 void fused_any_launch_1024x8(APT_ANY_SHAPE_ARGS);

@@ -6,9 +6,11 @@
 
 #include "apt_kernels_fused_launch.hpp"
 #include "apt_envelope.hpp"
+#include "apt_sync_corr.hpp"
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <type_traits>
 
@@ -64,9 +66,9 @@ struct FusedGeom {
     static constexpr int FWIN = L + G - 1;                            // F window per thread
     // one LDS region: the x tile, then R/F at [0, TILE_K+G), D and later C at D_OFF
     static constexpr int D_OFF = (TILE_K + G + 3) & ~3;
-    static constexpr int C_OFF = D_OFF;  // C staging reuses D's region: D is dead once F is in P
     static constexpr int XT_LDS = XB == 2 ? (XT_PAD / 2 + 4) : XT_PAD;  // floats of LDS under the x tile
-    static constexpr int LDS_FLOATS = XT_LDS > (C_OFF + TILE_K) ? XT_LDS : (C_OFF + TILE_K);
+    // (+36*PW: the fast correlation's pulse-sum window of the last thread reaches past the tile)
+    static constexpr int LDS_FLOATS = XT_LDS > (D_OFF + TILE_K + 36 * PW) ? XT_LDS : (D_OFF + TILE_K + 36 * PW);
     static constexpr int GS = 4 * L;                                  // correlation group size
     static constexpr int NP = L / 2;                                  // accumulator pairs (+1 single if L odd)
     static constexpr int PS = NP;                                     // f2 tap entries per window sample
@@ -95,6 +97,13 @@ __host__ __device__ constexpr int first_branch_of_pair(int c)
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+// The tap tables and the slot table are never written while a decode runs: pointers fetched from the
+// parameter block are cast to the constant address space, which is what makes the (wave-uniform)
+// reads of them scalar loads — a generic pointer loaded from memory would turn every tap read
+// into a per-lane flat load.
+#define APT_CONST_AS __attribute__((address_space(4)))
+typedef const f2 APT_CONST_AS *cf2_ptr;
+typedef const float APT_CONST_AS *cfloat_ptr;
 
 // sign of the sync template at index j (decode.rs:188-198): + inside the seven high pulses
 template <int PW>
@@ -107,41 +116,48 @@ __host__ __device__ constexpr bool sync_plus(int j)
 
 // XT = float: the f32 Signal; XT = int16_t: mono PCM16 straight from the WAV data chunk
 // (`*x as f32`, wav.rs:37), which halves the compulsory input bytes.
-// F16 (APTGPU_MODE_FP16_TAPS, BASELINE config 5): stage 1 only runs on fp16 taps (power-of-two
-// prescaled) and fp16-rounded samples through v_dot2_f32_f16 with f32 accumulation — one
-// instruction per two taps of one output instead of a packed mul + add per tap of two outputs,
-// about half the stage-1 instructions; `hs` then holds [ceil(WIN/2)][16] half2 tap pairs.
-// Tolerance-based, not bit-exact; every other stage stays strict.
-// BATCH: one launch over several recordings (blockIdx.y); a separate instantiation, because the extra
-// pointer and prologue cost the single-recording kernel 10 % through SGPR pressure in its hot loops.
-template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, bool F16, bool BATCH>
+// MODE:
+//   kModeStrict  every product and sum rounded separately in the reference's order: bit-identical
+//                to the scalar Rust loops.
+//   kModeF16Taps (APTGPU_MODE_FP16_TAPS, BASELINE config 5) stage 1 only runs on fp16 taps
+//                (power-of-two prescaled) and fp16-rounded samples through v_dot2_f32_f16 with f32
+//                accumulation; `hs` then holds [ceil(WIN/2)][16] half2 tap pairs.  Tolerance-based.
+//   kModeFast    (APTGPU_MODE_FAST) f32 throughout, same taps, same tap order, but every
+//                multiply-add is one fused v_pk_fma_f32 (stages 1 and 3), the envelope uses the
+//                native v_sqrt_f32 and a multiplication by 1/sin(phi), and the +-1 correlation is
+//                evaluated from pulse sums (apt_sync_corr.hpp): ~1/3 of the strict VALU
+//                instructions.  Tolerance-based; deterministic.
+// One launch covers the `count` recordings of a call: blockIdx.y picks the recording, whose
+// tiles are blockIdx.x < ceil(w / OWN_K); the per-recording arguments travel by value in the
+// kernel-argument segment, the workspace pointers come from the plan's slot table.
+template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
+// (104 VGPRs: three workgroups per CU then leave 200 registers per SIMD lane free, which is what lets
+// the picker's kernels of the previous call — one 1024-thread workgroup among them — run beside this one)
 __global__ void __launch_bounds__(NTHR, ((sizeof(XT) == 2 ? 4 : APT_FUSED_MIN_WAVES) * NTHR + 255) / 256)
-k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][PS] tap pairs*/,
-        const float *__restrict__ h2 /*[T2]*/, const f2 *__restrict__ h2p /*[T2+1] (h2[m-1], h2[m])*/,
-        float cosphi2, float sinphi, float inv_sinphi /* verified RN(1/sinphi), or 0 */,
-        float f16_unscale /* 2^-s of the fp16 tap prescale (F16 only) */,
-        float *__restrict__ f_out, float *__restrict__ c_out, float *__restrict__ gm_out,
-        uint64_t w, uint64_t n_corr, const FusedRec *__restrict__ batch /* nullptr: the arguments above */)
+__attribute__((amdgpu_num_vgpr(104)))
+k_fused(const CallArgs call, const FusedParams *__restrict__ prm)
 {
+    // Only the stage-1 tap table is fetched from `prm` here; everything the later stages need is
+    // loaded after stage 1 (see `late`): an SGPR held across stage 1 is one its tap pipeline cannot
+    // use, and the register allocator answered the extra pressure by spilling the table pointer
+    // itself inside the hot loop.
+    const cf2_ptr hs = (cf2_ptr)(prm->hs);  // [WIN][PS] tap pairs
     using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
     constexpr int kFusedThreads = NTHR;
     constexpr int kOwnThreads = Gm::kOwnThreads;
-    if constexpr (BATCH) {
-        // batched launch: blockIdx.y picks the recording; its tiles are blockIdx.x < ceil(w / OWN_K)
-        const FusedRec rec = batch[blockIdx.y];
-        x = static_cast<const XT *>(rec.x);
-        n = rec.n;
-        f_out = rec.f_out;
-        c_out = rec.c_out;
-        gm_out = rec.gm_out;
-        w = rec.w;
-        n_corr = rec.n_corr;
-        if (static_cast<uint64_t>(blockIdx.x) * Gm::OWN_K >= w) return;
-    }
+    constexpr bool F16 = MODE == kModeF16Taps;
+    constexpr bool FAST = MODE == kModeFast;
+    // (field by field: only what the stages below need is loaded, and the output pointers are
+    // fetched from the slot table after stage 3 — every SGPR held across stage 1 is one the tap
+    // pipeline cannot use)
+    const uint64_t w = call.rec[blockIdx.y].w;
+    if (static_cast<uint64_t>(blockIdx.x) * Gm::OWN_K >= w) return;
+    const XT *__restrict__ x = static_cast<const XT *>(call.rec[blockIdx.y].x);
+    const uint64_t n = call.rec[blockIdx.y].n;
+    const uint64_t n_corr = w - Gm::G;  // w >= 10 rows of samples > G (checked on the host)
     extern __shared__ float lds[];
     float *P = lds;                  // x tile -> R -> F
-    float *Q = lds + Gm::D_OFF;      // D (inside the dead part of the x tile)
-    float *CS = lds + Gm::C_OFF;     // correlation staging for coalesced stores
+    float *Q = lds + Gm::D_OFF;      // D (inside the dead part of the x tile), later the pulse sums (fast mode)
 
     const int tid = threadIdx.x;
     const int64_t tile = blockIdx.x;
@@ -211,18 +227,20 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
             if constexpr (sizeof(XT) == 2) return static_cast<float>(reinterpret_cast<const int16_t *>(lds)[tid * M + q]);
             else return P[tid * M + q];
         };
-        const uint32_t *ht = reinterpret_cast<const uint32_t *>(hs);  // [NQP][16] half2 bit patterns
+        typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+        typedef const u4v APT_CONST_AS *cu4v_ptr;
+        const cu4v_ptr ht = (cu4v_ptr)(hs);  // [NQP][16] half2 bit patterns (4 x 4 dwords per row)
         float acc[L];
 #pragma unroll
         for (int b = 0; b < L; ++b) acc[b] = 0.f;
-        uint4 tb[2][4];  // tap pairs of the sample pair in use / in flight (16 SGPRs each)
+        u4v tb[2][4];  // tap pairs of the sample pair in use / in flight (16 SGPRs each)
         float xa[2], xb[2];
         static_assert(L <= 16, "one 16-dword table row per sample pair");
         auto dot2 = [](float &a, uint32_t tap_pair /*SGPR*/, h2v x_pair) {
             asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(a) : "s"(tap_pair), "v"(x_pair));
         };
         auto tapw = [&](int buf, int b) -> uint32_t {
-            const uint4 v = tb[buf][b >> 2];
+            const u4v v = tb[buf][b >> 2];
             return (b & 3) == 0 ? v.x : (b & 3) == 1 ? v.y : (b & 3) == 2 ? v.z : v.w;
         };
         auto issue = [&](auto cc) {
@@ -231,7 +249,7 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
             xa[buf] = xsrc(2 * c);
             xb[buf] = (2 * c + 1 < Gm::WIN) ? xsrc(2 * c + 1) : 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) tb[buf][k] = reinterpret_cast<const uint4 *>(ht)[c * 4 + k];
+            for (int k = 0; k < 4; ++k) tb[buf][k] = ht[c * 4 + k];
         };
         issue(std::integral_constant<int, 0>{});
         static_for<0, NQP>([&](auto cc) {
@@ -254,6 +272,7 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
             });
             __builtin_amdgcn_sched_barrier(0);
         });
+        const float f16_unscale = prm->f16_unscale;  // 2^-s of the fp16 tap prescale
 #pragma unroll
         for (int b = 0; b < L; ++b) r[b] = (kq + b < k_lo || kq + b >= k_hi) ? 0.f : acc[b] * f16_unscale;
     } else
@@ -262,6 +281,8 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
         // only usable wait is lgkmcnt(0).  Each chunk therefore (1) consumes its first tap —
         // which makes the compiler wait for exactly the loads issued one chunk ago — (2) issues
         // the loads of the NEXT chunk, (3) computes the rest under their latency.
+        // kModeFast runs the same pipeline with one v_pk_fma_f32 per tap pair instead of a
+        // v_pk_mul_f32 + v_pk_add_f32 (half the VALU instructions under the same tap loads).
         constexpr int CH = 2;
         constexpr int NCH = (Gm::WIN + CH - 1) / CH;
         auto xsrc = [&](int q) -> float {
@@ -275,7 +296,7 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
         f2 tb[2][CH * Gm::PS];   // tap pairs of the chunk in use / in flight (SGPRs)
         float tl[2][CH];         // taps of the odd branch L-1 (contiguous per sample: aligned pairs)
         float xb[2][CH];         // window samples of the chunk in use / in flight
-        const float *hl = reinterpret_cast<const float *>(hs) + Gm::HL_OFF;
+        const cfloat_ptr hl = (cfloat_ptr)(hs) + Gm::HL_OFF;
         auto issue = [&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int buf = c & 1;
@@ -316,6 +337,29 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
             }
             return p;
         };
+        // kModeFast: acc += tap * x in one fused operation
+        auto mac = [&](auto cc, auto ee, auto kk) {
+            constexpr int c = decltype(cc)::value, e = decltype(ee)::value, k = decltype(kk)::value;
+            constexpr int buf = c & 1;
+            constexpr int q = c * CH + e;
+            if constexpr (q < Gm::WIN) {
+                const float xq = xb[buf][e];
+                if constexpr (k < Gm::NP) {
+                    const f2 t = tb[buf][e * Gm::PS + k];
+                    constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
+                    constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
+                    if constexpr (va && vb) {
+                        acc[k] = __builtin_elementwise_fma(t, (f2){xq, xq}, acc[k]);
+                    } else if constexpr (va) {
+                        acc[k].x = __builtin_fmaf(t.x, xq, acc[k].x);
+                    } else if constexpr (vb) {
+                        acc[k].y = __builtin_fmaf(t.y, xq, acc[k].y);
+                    }
+                } else if constexpr (branch_uses<L, M, T1>(L - 1, q)) {
+                    accl = __builtin_fmaf(tl[buf][e], xq, accl);
+                }
+            }
+        };
         auto accum = [&](auto cc, auto ee, auto kk, f2 p) {
             constexpr int c = decltype(cc)::value, e = decltype(ee)::value, k = decltype(kk)::value;
             constexpr int q = c * CH + e;
@@ -341,6 +385,22 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
             constexpr int NK = Gm::PS + (L & 1);
             using I0 = std::integral_constant<int, 0>;
             using I1 = std::integral_constant<int, 1>;
+            if constexpr (FAST) {
+                // the first two multiply-adds force the wait for the loads issued one chunk ago
+                mac(cc, I0{}, I0{});
+                mac(cc, I0{}, I1{});
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (c + 1 < NCH) issue(std::integral_constant<int, c + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, CH>([&](auto ee) {
+                    constexpr int e = decltype(ee)::value;
+                    static_for<0, NK>([&](auto kk) {
+                        constexpr int k = decltype(kk)::value;
+                        if constexpr (!(e == 0 && k < 2)) mac(cc, ee, kk);
+                    });
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
             // the first two products force the wait for the loads issued one chunk ago
             const f2 p00 = prod(cc, I0{}, I0{});
             const f2 p01 = prod(cc, I0{}, I1{});
@@ -359,6 +419,7 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
                 static_for<0, NK>([&](auto kk) { accum(cc, ee, kk, pr[decltype(kk)::value]); });
             });
             __builtin_amdgcn_sched_barrier(0);
+            }
         });
 #pragma unroll
         for (int pp = 0; pp < Gm::NP; ++pp) {
@@ -375,8 +436,34 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
     for (int b = 0; b < L; ++b) P[tid * L + b] = r[b];
     __syncthreads();
 
+    // the parameters of the later stages, fetched now (the empty asm keeps the loads from being hoisted)
+    typedef const FusedParams APT_CONST_AS *cprm_ptr;
+    cprm_ptr late = (cprm_ptr)(prm);
+    asm volatile("" : "+s"(late));
+    const float cosphi2 = late->cosphi2, sinphi = late->sinphi;
+    const float inv_sinphi = late->inv_sinphi;  // strict: verified RN(1/sinphi) or 0; fast: RN(1/sinphi)
+    const cfloat_ptr h2 = (cfloat_ptr)(late->h2);   // [T2]
+    const cf2_ptr h2p = (cf2_ptr)(late->h2p);       // [T2+1] (h2[m-1], h2[m])
+    typedef const SlotPtrs APT_CONST_AS *cslot_ptr;
+    const cslot_ptr slots = (cslot_ptr)(late->slots);
+    const int want_gm = late->want_gm;
+
     // ---- stage 2: AM envelope from consecutive samples (dsp.rs:369-377)
-    {
+    if constexpr (FAST) {
+        // native v_sqrt_f32 (1 ulp) and a multiplication by RN(1/sin(phi)): ~2 ulp from the
+        // correctly rounded value, no range checks (the radicand is >= (1-|cos phi|)(p^2+c^2) >= 0)
+        float prev = (tid > 0) ? P[tid * L - 1] : 0.f;
+        float prev_sq = prev * prev;
+#pragma unroll
+        for (int b = 0; b < L; ++b) {
+            const float curr = r[b];
+            const float curr_sq = curr * curr;
+            const float rad = __builtin_fmaf(-(prev * curr), cosphi2, prev_sq + curr_sq);
+            Q[tid * L + b] = (kq + b > k_lo) ? __builtin_amdgcn_sqrtf(rad) * inv_sinphi : 0.f;
+            prev = curr;
+            prev_sq = curr_sq;
+        }
+    } else {
         float prev = (tid > 0) ? P[tid * L - 1] : 0.f;
         float xr[L];
         bool in_range = inv_sinphi != 0.f;  // 0: the fast divide did not verify for this sin(phi)
@@ -435,7 +522,15 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
                             constexpr bool va = m >= 0 && m < T2;
                             constexpr bool vb = m + 1 >= 0 && m + 1 < T2;
                             pr[pp] = (f2){0.f, 0.f};
-                            if constexpr (va && vb) {
+                            if constexpr (FAST) {
+                                if constexpr (va && vb) {
+                                    fa[pp] = __builtin_elementwise_fma(h2p[m + 1], (f2){d, d}, fa[pp]);
+                                } else if constexpr (va) {
+                                    fa[pp].x = __builtin_fmaf(h2[m], d, fa[pp].x);
+                                } else if constexpr (vb) {
+                                    fa[pp].y = __builtin_fmaf(h2[m + 1], d, fa[pp].y);
+                                }
+                            } else if constexpr (va && vb) {
                                 pr[pp] = h2p[m + 1] * (f2){d, d};
                             } else if constexpr (va) {
                                 pr[pp].x = h2[m] * d;
@@ -445,8 +540,12 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
                         });
                         if constexpr (L & 1) {
                             constexpr int ml = (T2 - 1) + (L - 1) - qq;
-                            if constexpr (ml >= 0 && ml < T2) pl = h2[ml] * d;
+                            if constexpr (ml >= 0 && ml < T2) {
+                                if constexpr (FAST) fl = __builtin_fmaf(h2[ml], d, fl);
+                                else pl = h2[ml] * d;
+                            }
                         }
+                        if constexpr (!FAST) {
                         static_for<0, Gm::NP>([&](auto pc) {
                             constexpr int pp = decltype(pc)::value;
                             constexpr int m = (T2 - 1) + 2 * pp - qq;
@@ -463,6 +562,7 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
                         if constexpr (L & 1) {
                             constexpr int ml = (T2 - 1) + (L - 1) - qq;
                             if constexpr (ml >= 0 && ml < T2) fl = fl + pl;
+                        }
                         }
                     }
                 });
@@ -494,6 +594,9 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
     __syncthreads();
 
     // owned F -> HBM, coalesced 16-byte stores
+    uint32_t slot_late = call.rec[blockIdx.y].slot;
+    asm volatile("" : "+s"(slot_late));  // keeps the loads below from being hoisted above stage 1
+    float *__restrict__ f_out = slots[slot_late].f;
     {
         float *ft = f_out + o0;
         for (int q = tid * 4; q < Gm::OWN_K; q += kFusedThreads * 4) {
@@ -506,8 +609,57 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
         }
     }
 
-    // ---- stage 4: sync cross-correlation (decode.rs:225-233), its group maxima, and C
-    if (gm_out != nullptr) {
+    // ---- stage 4: sync cross-correlation (decode.rs:225-233) -> per-group maxima.  The correlation
+    // itself never leaves the CU: k_sync_nodes re-evaluates it (same arithmetic, apt_sync_corr.hpp)
+    // for the few candidate groups the picker has to look at.
+    if (want_gm) {
+        GroupMax *__restrict__ gm_out = slots[slot_late].gm;
+        float c[L];
+        if constexpr (FAST) {
+            // pulse sums of the thread's own L positions -> Q (D is dead), then 19 terms per output
+            constexpr int PUL = 2 * PW;
+            {
+                const float *src = P + tid * L;
+                float fw[L + PUL - 1];
+#pragma unroll
+                for (int e = 0; e < L + PUL - 1; ++e) fw[e] = src[e];  // (past the tile: unused garbage)
+                float b2[L + PUL - 2];
+#pragma unroll
+                for (int e = 0; e < L + PUL - 2; ++e) b2[e] = fw[e] + fw[e + 1];
+#pragma unroll
+                for (int b = 0; b < L; ++b) {
+                    float bs = b2[b] + b2[b + 2];
+#pragma unroll
+                    for (int t = 2; t < PW; ++t) bs = bs + b2[b + 2 * t];
+                    Q[tid * L + b] = bs;
+                }
+            }
+            __syncthreads();
+            constexpr int BW = L + 18 * PUL;  // pulse-sum window per thread
+            constexpr int CH4 = 11;
+            const float *src = Q + tid * L;
+            static_for<0, (BW + CH4 - 1) / CH4>([&](auto cc) {
+                constexpr int q0 = decltype(cc)::value * CH4;
+                float bv[CH4];
+#pragma unroll
+                for (int e = 0; e < CH4; ++e) bv[e] = (q0 + e < BW) ? src[q0 + e] : 0.f;
+                static_for<0, CH4>([&](auto ee) {
+                    constexpr int q = q0 + decltype(ee)::value;
+                    if constexpr (q < BW) {
+                        const float v = bv[decltype(ee)::value];
+                        static_for<0, L>([&](auto bb) {
+                            constexpr int b = decltype(bb)::value;
+                            if constexpr (q >= b && (q - b) % PUL == 0 && (q - b) / PUL < 19) {
+                                constexpr int k = (q - b) / PUL;
+                                if constexpr (k == 0) c[b] = -v;
+                                else c[b] = sync_pulse_plus(k) ? c[b] + v : c[b] - v;
+                            }
+                        });
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
         // F sample q meets output b at template index j = q - b: outputs (b, b+1) add the
         // same sample with the signs of T[j] and T[j-1] (neg_lo / neg_hi modifiers).
         constexpr int CH4 = 6;
@@ -546,69 +698,64 @@ k_fused(const XT *__restrict__ x, uint64_t n, const f2 *__restrict__ hs /*[WIN][
             });
             __builtin_amdgcn_sched_barrier(0);
         });
-        float c[L];
 #pragma unroll
         for (int pp = 0; pp < Gm::NP; ++pp) {
             c[2 * pp] = ca[pp].x;
             c[2 * pp + 1] = ca[pp].y;
         }
         if constexpr (L & 1) c[L - 1] = cl;
+        }
+        // maximum over the group's positions, NaNs left out and reported separately (a NaN position
+        // is a terminal of the picker, decode.rs:250, whatever the finite maximum of its group is)
         float mx = kNegInfF;
+        bool has_nan = false;
 #pragma unroll
         for (int b = 0; b < L; ++b) {
             const int pq = kq + b;
             float v = c[b];
             if (pq == k_lo && !(v > 0.f)) v = 0.f;  // the picker starts from the peak (0, 0.)
-            if (pq >= k_lo && pq < c_hi) mx = fmaxf(mx, v);
-            CS[tid * L + b] = c[b];
+            if (pq >= k_lo && pq < c_hi) {
+                mx = fmaxf(mx, v);
+                has_nan = has_nan || (v != v);
+            }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        int hn = has_nan ? 1 : 0;
+        hn |= __shfl_xor(hn, 1, 64);
+        hn |= __shfl_xor(hn, 2, 64);
         if ((tid & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads && kq < c_hi)
-            gm_out[o0 / Gm::GS + (tid - kPreThreads) / 4] = mx;
-        __syncthreads();
-        // owned C -> HBM, coalesced 16-byte stores (read by the fine stage of the picker)
-        float *ct = c_out + o0;
-        for (int q = tid * 4; q < Gm::OWN_K; q += kFusedThreads * 4) {
-            if (Gm::PRE_K + q + 3 < c_hi) {
-                *reinterpret_cast<float4 *>(ct + q) = *reinterpret_cast<const float4 *>(CS + Gm::PRE_K + q);
-            } else {
-                for (int e = 0; e < 4; ++e)
-                    if (Gm::PRE_K + q + e < c_hi) ct[q + e] = CS[Gm::PRE_K + q + e];
-            }
-        }
+            gm_out[o0 / Gm::GS + (tid - kPreThreads) / 4] = GroupMax{mx, hn ? 1.f : 0.f};
     }
 }
 
-template <int L, int M, int T1, int T2, int PW, int NTHR, bool F16 = false, bool BATCH = false, typename XT>
-void launch_fused(hipStream_t s, const XT *x, uint64_t n, const float *hb, const float *h2,
-                  const float *h2p, float cosphi2, float sinphi, float inv_sinphi, float f16_unscale, float *f_out,
-                  float *c_out, float *gm_out, uint64_t w,
-                  uint64_t n_corr, const FusedRec *d_batch = nullptr, int count = 1)
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the function: set it once
+// per (kernel instantiation, device) — plans on different devices, and host threads creating them
+// concurrently, all pass through here
+template <auto Kern>
+inline void ensure_dynamic_lds(size_t lds)
 {
-    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
-    constexpr int kFusedThreads = NTHR;
-    const size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
-    auto kern = k_fused<L, M, T1, T2, PW, NTHR, XT, F16, BATCH>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        attr_set = true;
+    constexpr int kMaxDevices = 64;
+    static std::atomic<size_t> have[kMaxDevices];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (lds > 48 * 1024 && lds > have[dev].load(std::memory_order_acquire)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  static_cast<int>(lds));
+        have[dev].store(lds, std::memory_order_release);
     }
-    const unsigned tiles = static_cast<unsigned>((w + Gm::OWN_K - 1) / Gm::OWN_K);
-    hipLaunchKernelGGL(kern, dim3(tiles, static_cast<unsigned>(count)), dim3(kFusedThreads), lds, s, x, n,
-                       reinterpret_cast<const f2 *>(hb), h2, reinterpret_cast<const f2 *>(h2p), cosphi2, sinphi,
-                       inv_sinphi, f16_unscale, f_out, c_out, gm_out, w, n_corr, d_batch);
 }
 
-
-template <int L, int M, int T1, int T2, int PW, int NTHR, bool F16, bool BATCH, typename XT>
+template <int L, int M, int T1, int T2, int PW, int NTHR, int MODE, typename XT>
 void launch_fused_args(const FusedLaunch &a)
 {
-    launch_fused<L, M, T1, T2, PW, NTHR, F16, BATCH>(a.s, static_cast<const XT *>(a.x), a.n, a.hb, a.h2, a.h2p,
-                                                      a.cosphi2, a.sinphi, a.inv_sinphi, a.f16_unscale, a.f_out,
-                                                      a.c_out, a.gm_out, a.w, a.n_corr, a.d_batch, a.count);
+    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
+    const size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
+    constexpr auto kern = k_fused<L, M, T1, T2, PW, NTHR, XT, MODE>;
+    ensure_dynamic_lds<kern>(lds);
+    const unsigned tiles = static_cast<unsigned>((a.max_w + Gm::OWN_K - 1) / Gm::OWN_K);
+    hipLaunchKernelGGL(kern, dim3(tiles, a.call->count), dim3(NTHR), lds, a.s, *a.call, a.prm);
 }
 
 }  // namespace

@@ -6,17 +6,17 @@
 
 namespace apt::gpu {
 
-// arguments of one launch (single recording, or a batch described by d_batch)
+// k_fused's MODE template argument
+constexpr int kModeStrict = 0;
+constexpr int kModeF16Taps = 1;
+constexpr int kModeFast = 2;
+
+// arguments of one launch: the recordings of one call (see CallArgs / SlotPtrs in apt_kernels.hpp)
 struct FusedLaunch {
     hipStream_t s;
-    const void *x;
-    uint64_t n;
-    const float *hb, *h2, *h2p;
-    float cosphi2, sinphi, inv_sinphi, f16_unscale;
-    float *f_out, *c_out, *gm_out;
-    uint64_t w, n_corr;
-    const FusedRec *d_batch;
-    int count;
+    const CallArgs *call;      // host copy; passed to the kernel by value
+    const FusedParams *prm;    // device-resident parameters of the plan
+    uint64_t max_w;            // longest recording of the call, work samples (sizes grid.x)
 };
 
 // one function per instantiation, each in its own translation unit
@@ -26,7 +26,9 @@ void fused_launch_96k_f32(const FusedLaunch &a);
 void fused_launch_96k_i16(const FusedLaunch &a);
 void fused_launch_48k_f16taps_f32(const FusedLaunch &a);
 void fused_launch_48k_f16taps_i16(const FusedLaunch &a);
-void fused_launch_48k_batch_f32(const FusedLaunch &a);
-void fused_launch_48k_batch_i16(const FusedLaunch &a);
+void fused_launch_48k_fast_f32(const FusedLaunch &a);
+void fused_launch_48k_fast_i16(const FusedLaunch &a);
+void fused_launch_96k_fast_f32(const FusedLaunch &a);
+void fused_launch_96k_fast_i16(const FusedLaunch &a);
 
 }  // namespace apt::gpu

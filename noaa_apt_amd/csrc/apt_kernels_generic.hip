@@ -11,6 +11,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 // never fuse a*b+c: the reference rounds the product and the sum separately
 #pragma clang fp contract(off)
@@ -335,14 +339,23 @@ k_orbit_walk(const uint64_t *__restrict__ bits, uint64_t n_corr, uint64_t work_l
 // to 4160 Hz (decode.rs:158-159 -> filter([1.]) + decimate(pw), dsp.rs:106-116):
 //   px[r*2080 + c] = 0.0 + F[peaks[r] + pw*c] * 1.0,  and px[0] = 0 (the `i > j` guard).
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
-k_gather_rows(const float *__restrict__ f, const uint32_t *__restrict__ peaks,
-              const Result *__restrict__ res, uint32_t spr, uint32_t pw, int raw,
-              float *__restrict__ rows, uint32_t rows_cap)
+__device__ __forceinline__ void gather_rows_body(const float *__restrict__ f, const uint32_t *__restrict__ peaks,
+                                                 Result *__restrict__ res, uint32_t spr, uint32_t pw, int raw,
+                                                 float *__restrict__ rows, uint32_t rows_cap)
 {
     uint32_t n_rows = res->n_rows;
-    if (n_rows > rows_cap) n_rows = rows_cap;
     const uint32_t px_per_row = spr / pw;  // 2080 when pw = work_rate / 4160
+    if (n_rows > rows_cap) {
+        // the caller's buffer holds fewer rows than the recording has: the record reports what
+        // was written (reason 4), so a caller that trusts n_out never reads past its buffer.
+        // Every thread takes the same minimum, so the racing update below is benign.
+        n_rows = rows_cap;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+            res->n_rows = rows_cap;
+            res->n_out = static_cast<uint64_t>(rows_cap) * px_per_row;
+            res->reason = 4;
+        }
+    }
     for (uint32_t r = blockIdx.y; r < n_rows; r += gridDim.y) {
         const float *src = f + peaks[r];
         for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < px_per_row;
@@ -355,6 +368,23 @@ k_gather_rows(const float *__restrict__ f, const uint32_t *__restrict__ peaks,
             rows[static_cast<uint64_t>(r) * px_per_row + c] = v;
         }
     }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_gather_rows(const float *__restrict__ f, const uint32_t *__restrict__ peaks,
+              Result *__restrict__ res, uint32_t spr, uint32_t pw, int raw,
+              float *__restrict__ rows, uint32_t rows_cap)
+{
+    gather_rows_body(f, peaks, res, spr, pw, raw, rows, rows_cap);
+}
+
+// the recordings of one call: blockIdx.z picks the recording
+__global__ void __launch_bounds__(kBlock)
+k_gather_rows_call(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t spr, uint32_t pw)
+{
+    const RecArgs rec = call.rec[blockIdx.z];
+    const SlotPtrs sp = slots[rec.slot];
+    gather_rows_body(sp.f, sp.peaks, sp.res, spr, pw, 0, rec.rows, rec.rows_cap);
 }
 
 __global__ void k_set_result(Result *res, Result value) { *res = value; }
@@ -450,11 +480,21 @@ void orbit_walk(hipStream_t s, const uint64_t *bits, uint64_t n_corr, uint64_t w
                        peaks, peaks_cap, res);
 }
 
-void gather_rows(hipStream_t s, const float *f, const uint32_t *peaks, const Result *res,
+void gather_rows_call(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint32_t spr, uint32_t pw,
+                      uint32_t max_rows_cap)
+{
+    if (call.count == 0) return;
+    const unsigned gy = max_rows_cap == 0 ? 1u : (max_rows_cap < 4096u ? max_rows_cap : 4096u);
+    const unsigned gx = (spr / pw + 4 * kBlock - 1) / (4 * kBlock);
+    hipLaunchKernelGGL(k_gather_rows_call, dim3(gx ? gx : 1, gy, call.count), dim3(kBlock), 0, s, call, d_slots,
+                       spr, pw);
+}
+
+void gather_rows(hipStream_t s, const float *f, const uint32_t *peaks, Result *res,
                  uint32_t spr, uint32_t pw, bool raw, float *rows, uint32_t rows_cap)
 {
-    if (rows_cap == 0) return;
-    const unsigned gy = rows_cap < 4096u ? rows_cap : 4096u;
+    // (rows_cap == 0 still launches: the kernel then only clamps the result record)
+    const unsigned gy = rows_cap == 0 ? 1u : (rows_cap < 4096u ? rows_cap : 4096u);
     const unsigned gx = (spr / pw + 4 * kBlock - 1) / (4 * kBlock);
     hipLaunchKernelGGL(k_gather_rows, dim3(gx ? gx : 1, gy), dim3(kBlock), 0, s, f, peaks, res, spr,
                        pw, raw ? 1 : 0, rows, rows_cap);
@@ -475,22 +515,41 @@ __global__ void __launch_bounds__(256) k_verify_fast_divide(float c, float rc, u
     if (__float_as_uint(want) != __float_as_uint(got)) atomicAdd(bad, 1u);
 }
 
-bool verify_fast_divide(hipStream_t s, float c, float rc)
+bool verify_fast_divide(int device, float c, float rc)
 {
     if (!(c == c) || !(rc == rc) || c == 0.f || rc == 0.f) return false;
     // keep every intermediate of the check itself in the normal range
     const float ac = c < 0.f ? -c : c;
     if (!(ac > 1e-6f && ac < 1e6f)) return false;
+    // The answer depends on (c, rc) only — sin(phi) is a function of work_rate — so it is computed
+    // once per (device, divisor) and process; later plans (every one-shot aptgpu_decode builds one)
+    // take it from the cache and never touch the device here.
+    static std::mutex mu;
+    static std::map<std::tuple<int, uint32_t, uint32_t>, bool> cache;
+    uint32_t cb, rb;
+    std::memcpy(&cb, &c, 4);
+    std::memcpy(&rb, &rc, 4);
+    const auto key = std::make_tuple(device, cb, rb);
+    std::lock_guard<std::mutex> lock(mu);
+    if (auto it = cache.find(key); it != cache.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
     uint32_t *d_bad = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&d_bad), sizeof(uint32_t)) != hipSuccess) return false;
+    if (hipMalloc(reinterpret_cast<void **>(&d_bad), sizeof(uint32_t)) != hipSuccess) {
+        (void)hipStreamDestroy(s);
+        return false;
+    }
     uint32_t bad = 1;
     bool ok = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), s) == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(k_verify_fast_divide, dim3((1u << 24) / 256u), dim3(256), 0, s, c, rc, d_bad);
-        ok = hipMemcpyAsync(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess &&
+        ok = hipGetLastError() == hipSuccess &&
+             hipMemcpyAsync(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess &&
              hipStreamSynchronize(s) == hipSuccess;
     }
     (void)hipFree(d_bad);
+    (void)hipStreamDestroy(s);
+    if (ok) cache[key] = bad == 0;  // a failed check (HIP error) is not cached
     return ok && bad == 0;
 }
 

@@ -23,14 +23,20 @@
 // Kernels (GS = 52 correlation positions per group; md = 32*pw groups, spr = 40*pw groups):
 //   k_group_max   corr -> GM (unfused path only; the fused front end emits GM itself)
 //   k_sync_nodes  coarse: a group can hold a terminal only if GM[g] is not exceeded by the
-//                 next md/GS-1 group maxima; fine: exact test on the few candidates;
-//                 emits terminal words (fallback input) and ordered node-terminal lists
-//   k_sync_orbit  one workgroup: gathers the node terminals into LDS, builds the
-//                 functional graph over start nodes, extracts the orbit of the root by
-//                 pointer doubling, writes the peak list and the result record; falls
-//                 back to a sequential walk over the terminal words when a capacity is
-//                 exceeded (pathological inputs, very long recordings).
+//                 next md/GS-1 group maxima (or it holds a NaN); fine: exact test on the few
+//                 candidates, whose correlation values are RE-EVALUATED from F with the front
+//                 end's own arithmetic (apt_sync_corr.hpp) — the fused front ends never write
+//                 the correlation to HBM; emits terminal words (fallback input) and ordered
+//                 node-terminal lists
+//   k_sync_orbit  one workgroup per recording: builds the functional graph over start nodes,
+//                 extracts the orbit of the root (directly when the recording is confluent,
+//                 else by pointer doubling), writes the peak list and the result record;
+//                 falls back to a sequential walk over the terminal words when a per-chunk
+//                 list overflowed (pathological inputs).
+// All three take the recordings of one decode_device call in one launch (CallArgs by value,
+// slot table in HBM; apt_kernels.hpp).
 #include "apt_kernels.hpp"
+#include "apt_sync_corr.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -44,45 +50,73 @@ constexpr float kNegInf = -__builtin_huge_valf();
 
 // ------------------------------------------------------------------ k_group_max
 __global__ void __launch_bounds__(256)
-k_group_max(const float *__restrict__ corr, uint64_t n_corr, float *__restrict__ gm, uint32_t ng)
+k_group_max(const float *__restrict__ corr, uint64_t n_corr, GroupMax *__restrict__ gm, uint32_t ng)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= ng) return;
     const uint64_t base = static_cast<uint64_t>(g) * GS;
     float mx = kNegInf;
+    bool has_nan = false;
     for (int o = 0; o < GS; ++o) {
         const uint64_t i = base + o;
         if (i < n_corr) {
             float v = corr[i];
             if (i == 0 && !(v > 0.f)) v = 0.f;
             mx = fmaxf(mx, v);
+            has_nan = has_nan || (v != v);
         }
     }
-    gm[g] = mx;
+    gm[g] = GroupMax{mx, has_nan ? 1.f : 0.f};
 }
 
 // ------------------------------------------------------------------ k_sync_nodes
 constexpr int kNodesThreads = 128;
+constexpr int kNodesWaves = kNodesThreads / 64;
 constexpr int kChunkGroups = 128;  // own groups per workgroup
 constexpr int kSlotCap = 64;       // node terminals kept per chunk before "overflow"
 
-__global__ void __launch_bounds__(kNodesThreads)
-k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict__ corr,
-             uint64_t n_corr, uint32_t r_groups /* md/GS */, uint32_t grid_groups /* spr/GS */,
-             uint64_t *__restrict__ words_out, uint32_t *__restrict__ slot_nt,
-             uint32_t *__restrict__ slot_cnt, uint32_t *__restrict__ flags)
+// floats of LDS one wave needs to re-evaluate the correlation of one candidate: two F windows
+// (the candidate group and the group md ahead) of GS + 38*pw - 1 samples each
+__host__ __device__ constexpr uint32_t nodes_window(uint32_t pw) { return (GS + 38u * pw - 1u + 3u) & ~3u; }
+
+// NL: 64-lane loads per F window kept in registers while a wave has four candidates in flight
+// (window <= 64*NL samples); 0: any window, one candidate at a time straight into LDS.
+template <int NL>
+__global__ void __launch_bounds__(kNodesThreads, 4)  // <= 128 VGPRs: must fit beside the front end's waves
+k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t pw,
+             uint32_t r_groups /* md/GS */, uint32_t grid_groups /* spr/GS */, int fast, int use_corr)
 {
+    const RecArgs rec = call.rec[blockIdx.y];
+    const uint64_t w = rec.w;
+    const uint64_t n_corr = w - 38ull * pw;
+    const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
+    if (blockIdx.x * static_cast<uint32_t>(kChunkGroups) >= ng) return;
+    const SlotPtrs sp = slots[rec.slot];
+    const GroupMax *__restrict__ gm = sp.gm;
+    const float *__restrict__ corr = use_corr ? sp.corr : nullptr;  // nullptr: re-evaluate from F
+    const float *__restrict__ fsig = sp.f;
+    uint64_t *__restrict__ words_out = sp.words;
+    uint32_t *__restrict__ slot_nt = sp.slot_nt;
+    uint32_t *__restrict__ slot_cnt = sp.slot_cnt;
+    uint32_t *__restrict__ flags = sp.flags;
+
     // window of groups [gw0, gw0 + nwin): gw0 = g0 - R - 1, nwin = CG + R + 1.  LDS is sized
-    // at launch for the actual R (4.4 KB at R = 96) so these workgroups fit beside the front
-    // end of the next recording, which leaves only ~5 KB of LDS free per CU.
+    // at launch for the actual R and pw (7 KB at R = 96, pw = 3) so these workgroups fit beside
+    // the front end of the next recording, which leaves only ~9 KB of LDS free per CU.
     extern __shared__ uint64_t lds_nodes[];
     const int R = static_cast<int>(r_groups);
     uint64_t *s_words = lds_nodes;                                           // [CG + R + 1]
     float *s_gm = reinterpret_cast<float *>(s_words + (kChunkGroups + R + 1));  // [CG + 2R + 2]
     float *s_wm = s_gm + (kChunkGroups + 2 * R + 2);                         // [CG + R + 1]
     uint16_t *s_cand = reinterpret_cast<uint16_t *>(s_wm + (kChunkGroups + R + 1));  // [CG + R + 1]
+    uint8_t *s_nan = reinterpret_cast<uint8_t *>(s_cand + (kChunkGroups + R + 1));   // [CG + R + 1]
+    const uint32_t wlen = nodes_window(pw);
+    // per wave: two F windows (16-byte aligned; plain pointer arithmetic keeps these LDS accesses)
+    const uint32_t win_ofs = (static_cast<uint32_t>(kChunkGroups + R + 1) * 15u +
+                              static_cast<uint32_t>(kChunkGroups + 2 * R + 2) * 4u + 15u) & ~15u;
+    float *s_win = reinterpret_cast<float *>(reinterpret_cast<char *>(lds_nodes) + win_ofs);
     __shared__ uint32_t s_ncand;
-    __shared__ uint32_t s_scan[kNodesThreads / 64];
+    __shared__ uint32_t s_scan[kNodesWaves];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -93,9 +127,17 @@ k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict_
     const uint64_t md = static_cast<uint64_t>(R) * GS;
 
     if (tid == 0) s_ncand = 0;
+    if (blockIdx.x == 0 && tid == 0) {
+        // an unfinished chain is detectable: the orbit kernel overwrites this when it completes
+        sp.res->status = -1;
+        sp.res->reason = -1;
+    }
     for (int q = tid; q < nwin + R; q += kNodesThreads) {
         const int64_t g = gw0 + q;
-        s_gm[q] = (g >= 0 && g < static_cast<int64_t>(ng)) ? gm[g] : kNegInf;
+        const bool in = g >= 0 && g < static_cast<int64_t>(ng);
+        const GroupMax v = in ? gm[g] : GroupMax{kNegInf, 0.f};
+        s_gm[q] = v.max;
+        if (q < nwin) s_nan[q] = v.has_nan != 0.f ? 1 : 0;
     }
     __syncthreads();
 
@@ -116,18 +158,27 @@ k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict_
         s_wm[q] = wm;
         s_words[q] = 0ull;
         const bool valid = g >= 0 && g < static_cast<int64_t>(ng);
-        if (valid && !(wm > s_gm[q])) s_cand[atomicAdd(&s_ncand, 1u)] = static_cast<uint16_t>(q);
+        // a group whose finite maximum is exceeded can still hold a terminal: a NaN position
+        if (valid && (!(wm > s_gm[q]) || s_nan[q])) s_cand[atomicAdd(&s_ncand, 1u)] = static_cast<uint16_t>(q);
     }
     __syncthreads();
 
     // fine: exact terminal test for the candidate groups; each wave takes four candidates at
-    // a time so their eight corr loads are in flight together
+    // a time so their loads are in flight together
     const uint32_t ncand = s_ncand;
-    constexpr int kBatch = 4;
-    for (uint32_t c0 = wave * kBatch; c0 < ncand; c0 += kBatch * (kNodesThreads / 64)) {
+    constexpr int kBatch = NL > 0 ? 4 : 1;
+    constexpr int NLR = NL > 0 ? NL : 1;
+    // One wave owns a window pair: its LDS operations complete in program order, and the compiler
+    // keeps stores and loads of the same array in order (they may alias), so no barrier is needed
+    // between filling a window and reading it; wave_barrier() only pins the phases for the scheduler.
+    float *wa = s_win + static_cast<size_t>(wave) * 2 * wlen;  // window of the candidate group
+    float *wb = wa + wlen;                                     // ... of the group md ahead
+    const uint32_t wneed = GS + 38u * pw - 1u;  // samples of a window
+    for (uint32_t c0 = wave * kBatch; c0 < ncand; c0 += kBatch * kNodesWaves) {
         int qv[kBatch];
         float cv[kBatch], c2v[kBatch];
         bool inv[kBatch];
+        float fa[kBatch][NLR], fb[kBatch][NLR];
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
             const uint32_t ci = c0 + e;
@@ -137,16 +188,98 @@ k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict_
             inv[e] = qv[e] >= 0 && lane < GS && i < n_corr;
             cv[e] = kNegInf;
             c2v[e] = kNegInf;
-            if (inv[e]) {
-                cv[e] = corr[i];
-                if (i == 0 && !(cv[e] > 0.f)) cv[e] = 0.f;
-                if (i + md < n_corr) c2v[e] = corr[i + md];
+            if (corr != nullptr) {
+                if (inv[e]) {
+                    cv[e] = corr[i];
+                    if (i + md < n_corr) c2v[e] = corr[i + md];
+                }
+            } else if constexpr (NL > 0) {
+#pragma unroll
+                for (int t = 0; t < NL; ++t) {
+                    const uint64_t j = static_cast<uint64_t>(g) * GS + lane + 64u * t;
+                    const bool take = qv[e] >= 0 && lane + 64u * t < wneed;
+                    fa[e][t] = (take && j < w) ? fsig[j] : 0.f;
+                    fb[e][t] = (take && j + md < w) ? fsig[j + md] : 0.f;
+                }
             }
         }
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
             if (qv[e] < 0) continue;  // wave-uniform
-            // suffix max over lanes > lane (rest of this group)
+            if (corr == nullptr) {
+                // F windows -> LDS (one wave: its LDS operations complete in order)
+                const uint64_t base = static_cast<uint64_t>(gw0 + qv[e]) * GS;
+                if constexpr (NL > 0) {
+#pragma unroll
+                    for (int t = 0; t < NL; ++t)
+                        if (lane + 64u * t < wlen) {
+                            wa[lane + 64 * t] = fa[e][t];
+                            wb[lane + 64 * t] = fb[e][t];
+                        }
+                } else {
+                    for (uint32_t t = lane; t < wlen; t += 64) {
+                        const uint64_t j = base + t;
+                        wa[t] = (t < wneed && j < w) ? fsig[j] : 0.f;
+                        wb[t] = (t < wneed && j + md < w) ? fsig[j + md] : 0.f;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const bool in2 = inv[e] && base + lane + md < n_corr;
+                if (fast) {
+                    // pulse sums in place: every value a lane needs is read before anything is written
+                    const uint32_t blen = GS + 36u * pw;  // positions whose pulse sum is used
+                    if constexpr (NL > 0) {
+                        float ba[NLR], bb[NLR];
+#pragma unroll
+                        for (int t = 0; t < NL; ++t) {
+                            const uint32_t pq = lane + 64u * t;
+                            ba[t] = bb[t] = 0.f;
+                            if (pq < blen) {
+                                ba[t] = sync_pulse_sum(pw, [&](uint32_t j) { return wa[pq + j]; });
+                                bb[t] = sync_pulse_sum(pw, [&](uint32_t j) { return wb[pq + j]; });
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int t = 0; t < NL; ++t) {
+                            const uint32_t pq = lane + 64u * t;
+                            if (pq < blen) {
+                                wa[pq] = ba[t];
+                                wb[pq] = bb[t];
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    } else {
+                        // any pulse width: ascending sweeps of 64 positions; position p only reads
+                        // F[p .. p+2pw-1], which earlier sweeps (positions < p) never overwrite...
+                        // except through other lanes of the SAME sweep, all of which read first
+                        for (uint32_t p0 = 0; p0 < blen; p0 += 64) {
+                            const uint32_t pq = p0 + lane;
+                            float ba = 0.f, bb = 0.f;
+                            if (pq < blen) {
+                                ba = sync_pulse_sum(pw, [&](uint32_t j) { return wa[pq + j]; });
+                                bb = sync_pulse_sum(pw, [&](uint32_t j) { return wb[pq + j]; });
+                            }
+                            // positions pq+1 .. pq+2pw-1 of the next sweep's first lanes were read above
+                            // only by this sweep; the next sweep reads [p0+64, ...) which this sweep's
+                            // writes (< p0+64) do not touch
+                            __builtin_amdgcn_wave_barrier();
+                            if (pq < blen) {
+                                wa[pq] = ba;
+                                wb[pq] = bb;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    }
+                    if (inv[e]) cv[e] = sync_corr_from_pulses([&](int k) { return wa[lane + k * 2 * pw]; });
+                    if (in2) c2v[e] = sync_corr_from_pulses([&](int k) { return wb[lane + k * 2 * pw]; });
+                } else {
+                    if (inv[e]) cv[e] = sync_corr_strict(pw, [&](uint32_t j) { return wa[lane + j]; });
+                    if (in2) c2v[e] = sync_corr_strict(pw, [&](uint32_t j) { return wb[lane + j]; });
+                }
+            }
+            if (inv[e] && gw0 + qv[e] == 0 && lane == 0 && !(cv[e] > 0.f)) cv[e] = 0.f;  // the peak (0, 0.)
+            // suffix max over lanes > lane (rest of this group); fmaxf drops NaNs: a NaN never exceeds
             float sfx = cv[e];
             for (int d = 1; d < 64; d <<= 1) {
                 const float o = __shfl_down(sfx, d, 64);
@@ -161,9 +294,11 @@ k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict_
                 if (lane >= d) pfx = fmaxf(pfx, o);
             }
             const float wmax = fmaxf(fmaxf(sfx_ex, s_wm[qv[e]]), pfx);
+            // (a NaN position is a terminal: `wmax > NaN` is false, as `corr > last` is in decode.rs:250)
             const bool term = inv[e] && !(wmax > cv[e]);
             const unsigned long long word = __ballot(term) & kGroupMask;
             if (lane == 0) s_words[qv[e]] = word;
+            __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
@@ -174,13 +309,13 @@ k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict_
     const int64_t g = g0 + tid;
     uint64_t nw = 0;
     if (g < static_cast<int64_t>(ng)) {
-        const uint64_t w = s_words[q];
+        const uint64_t wd = s_words[q];
         const uint64_t prev_bit = s_words[q - 1] >> (GS - 1);
-        const uint64_t heads = w & ~(((w << 1) | prev_bit) & kGroupMask);
+        const uint64_t heads = wd & ~(((wd << 1) | prev_bit) & kGroupMask);
         const uint64_t shifted = ((s_words[q - R] << 1) | (s_words[q - R - 1] >> (GS - 1))) & kGroupMask;
         const uint64_t on_grid = (g % grid_groups == 0) ? 1ull : 0ull;
-        nw = w & (heads | shifted | on_grid);
-        words_out[g] = w;
+        nw = wd & (heads | shifted | on_grid);
+        words_out[g] = wd;
     }
     // ordered compaction of the node-terminal positions of this chunk
     const uint32_t cnt = static_cast<uint32_t>(__popcll(nw));
@@ -194,15 +329,15 @@ k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict_
     uint32_t base = 0;
     for (int wv = 0; wv < wave; ++wv) base += s_scan[wv];
     uint32_t total = 0;
-    for (int wv = 0; wv < kNodesThreads / 64; ++wv) total += s_scan[wv];
+    for (int wv = 0; wv < kNodesWaves; ++wv) total += s_scan[wv];
     uint32_t ofs = base + inc - cnt;
     uint64_t bitsleft = nw;
     while (bitsleft) {
-        const int b = __ffsll(static_cast<long long>(bitsleft)) - 1;
+        const int bpos = __ffsll(static_cast<long long>(bitsleft)) - 1;
         bitsleft &= bitsleft - 1;
         if (ofs < kSlotCap)
             slot_nt[static_cast<uint64_t>(blockIdx.x) * kSlotCap + ofs] =
-                static_cast<uint32_t>(static_cast<uint64_t>(g) * GS + b);
+                static_cast<uint32_t>(static_cast<uint64_t>(g) * GS + bpos);
         ++ofs;
     }
     if (tid == 0) {
@@ -213,12 +348,7 @@ k_sync_nodes(const float *__restrict__ gm, uint32_t ng, const float *__restrict_
 
 // ------------------------------------------------------------------ k_sync_orbit
 constexpr int kOrbitThreads = 1024;
-constexpr int kMaxLevels = 64;    // breadth-first levels before giving up on the fast path
-// capacities of the LDS-resident kernel (the global-memory kernel has none)
-constexpr int kNtCap = 16384;     // node terminals held in LDS
-constexpr int kCellCap = 8192;    // image rows (grid cells)
-constexpr int kNodeCap = kNtCap + kCellCap + 2;
-constexpr int kListCap = 8192;    // nodes the marked (reachable) set may hold
+constexpr int kMaxLevels = 64;    // breadth-first levels before giving up on the parallel path
 
 struct OrbitGeom {
     uint64_t n_corr, work_len;
@@ -289,271 +419,6 @@ __device__ void orbit_walk52(const uint64_t *__restrict__ words, const OrbitGeom
     }
 }
 
-__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint64_t key)
-{
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (a[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-// ---- LDS-resident picker: fastest, bounded capacity (147 KB of LDS, one workgroup)
-__global__ void __launch_bounds__(kOrbitThreads)
-k_sync_orbit_lds(const uint64_t *__restrict__ words, const uint32_t *__restrict__ slot_nt,
-             const uint32_t *__restrict__ slot_cnt, uint32_t n_chunks,
-             uint32_t *__restrict__ flags, OrbitGeom gq, uint32_t *__restrict__ peaks,
-             uint32_t peaks_cap, Result *__restrict__ res, int force_walk)
-{
-    extern __shared__ uint32_t lds_u32[];
-    uint32_t *s_nt = lds_u32;                                         // [kNtCap] node terminals
-    uint32_t *s_mark = s_nt + kNtCap;                                 // [kNodeCap/32 + 1] visited bits
-    uint16_t *s_ja = reinterpret_cast<uint16_t *>(s_mark + (kNodeCap / 32 + 1));  // [kNodeCap] next / jump
-    uint16_t *s_list = s_ja + kNodeCap;                               // [kListCap] visited node ids
-    uint16_t *s_path = s_list + kListCap;                             // [kCellCap + 2]
-    __shared__ uint32_t s_wave[kOrbitThreads / 64];
-    __shared__ uint32_t s_total, s_count, s_plen, s_bad;
-    __shared__ unsigned long long s_fit;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const uint64_t n_corr = gq.n_corr;
-    const uint32_t spr = gq.spr, md = gq.md;
-    // s / spr for s < 2^32 by multiply-high with floor(2^32/spr) and two corrections
-    const uint32_t spr_magic = static_cast<uint32_t>((1ull << 32) / spr);
-    auto div_spr = [&](uint32_t s) -> uint32_t {
-        uint32_t q = __umulhi(s, spr_magic);
-        uint32_t r = s - q * spr;
-        if (r >= spr) { ++q; r -= spr; }
-        if (r >= spr) ++q;
-        return q;
-    };
-    const uint64_t t_begin = __builtin_readcyclecounter();
-    auto stamp = [&](int k) {
-        if (tid == 0) flags[8 + k] = static_cast<uint32_t>(__builtin_readcyclecounter() - t_begin);
-    };
-
-    // number of grid cells that can hold a start: c in [2, kc]
-    const uint64_t kc = n_corr ? (n_corr - 1) / spr : 0;
-    bool walk = force_walk == 1 || flags[0] != 0 || n_corr == 0 || gq.work_len >= (1ull << 31);
-    // beyond the LDS capacities the global-memory kernel (launched next) takes over
-    bool defer = !walk && (force_walk == 2 || kc + 2 > kCellCap || n_chunks > kOrbitThreads * 16);
-
-    // ---- gather the per-chunk node-terminal lists into one sorted LDS array
-    uint32_t total = 0;
-    if (!walk && !defer) {
-        const uint32_t per = (n_chunks + kOrbitThreads - 1) / kOrbitThreads;
-        const uint32_t c_lo = tid * per;
-        uint32_t mine = 0;
-        for (uint32_t e = 0; e < per; ++e)
-            if (c_lo + e < n_chunks) mine += slot_cnt[c_lo + e];
-        uint32_t inc = mine;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += o;
-        }
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        uint32_t base = 0;
-        for (int wv = 0; wv < wave; ++wv) base += s_wave[wv];
-        if (tid == kOrbitThreads - 1) s_total = base + inc;
-        __syncthreads();
-        total = s_total;
-        if (total > kNtCap) {
-            defer = true;  // uniform: s_total is shared
-        } else if (total == 0) {
-            walk = true;
-        } else {
-            uint32_t ofs = base + inc - mine;
-            for (uint32_t e = 0; e < per; ++e) {
-                const uint32_t ch = c_lo + e;
-                if (ch >= n_chunks) break;
-                const uint32_t cnt = (per == 1) ? mine : slot_cnt[ch];
-                const uint4 *src = reinterpret_cast<const uint4 *>(slot_nt + static_cast<uint64_t>(ch) * kSlotCap);
-                uint4 v[kSlotCap / 4];
-#pragma unroll
-                for (int j = 0; j < kSlotCap / 4; ++j)
-                    if (static_cast<uint32_t>(4 * j) < cnt) v[j] = src[j];
-#pragma unroll
-                for (int j = 0; j < kSlotCap / 4; ++j) {
-                    if (static_cast<uint32_t>(4 * j) < cnt) s_nt[ofs + 4 * j] = v[j].x;
-                    if (static_cast<uint32_t>(4 * j + 1) < cnt) s_nt[ofs + 4 * j + 1] = v[j].y;
-                    if (static_cast<uint32_t>(4 * j + 2) < cnt) s_nt[ofs + 4 * j + 2] = v[j].z;
-                    if (static_cast<uint32_t>(4 * j + 3) < cnt) s_nt[ofs + 4 * j + 3] = v[j].w;
-                }
-                ofs += cnt;
-            }
-        }
-        __syncthreads();
-    }
-    stamp(0);  // node terminals gathered
-    if (defer) {
-        if (tid == 0) flags[5] = 1u;  // k_sync_orbit_global runs the picker for this recording
-        return;
-    }
-
-    // ---- nodes: 0 = root, 1 .. n_grid = grid cells 2 .. kc, then one per node terminal, END
-    const uint32_t n_grid = kc >= 2 ? static_cast<uint32_t>(kc - 1) : 0;
-    const uint32_t base_d = 1 + n_grid;
-    const uint32_t n_nodes = base_d + total + 1;
-    const uint32_t END = n_nodes - 1;
-    const uint32_t nc32 = static_cast<uint32_t>(n_corr);
-    const uint32_t wl32 = static_cast<uint32_t>(gq.work_len);
-
-    auto node_start = [&](uint32_t v, uint32_t *cell) -> uint32_t {
-        // start position and the cell used for the "(cell+1)*spr" term
-        if (v == 0) { *cell = 1; return 0; }
-        if (v < base_d) { *cell = v + 1; return (v + 1) * spr; }
-        const uint32_t s = s_nt[v - base_d] + md + 1;
-        *cell = div_spr(s);
-        return s;
-    };
-    auto first_node_terminal = [&](uint32_t s) -> uint32_t {
-        uint32_t ui = lower_bound_u32(s_nt, total, s);
-        if (ui >= total) ui = total - 1;  // cannot happen (fact 3); keeps reads in bounds
-        return ui;
-    };
-    auto next_of = [&](uint32_t v) -> uint32_t {
-        uint32_t cell;
-        const uint32_t s = node_start(v, &cell);
-        if (s >= nc32) return END;
-        const uint32_t ui = first_node_terminal(v == 0 ? 0u : s);
-        const uint32_t a = s_nt[ui] + md + 1;
-        const uint32_t b = (cell + 1) * spr;
-        const uint32_t s2 = a > b ? a : b;
-        if (s2 >= nc32) return END;
-        return (a >= b) ? base_d + ui : cell;  // grid(cell+1) has id `cell`
-    };
-
-    // ---- reachable set by breadth-first marking from the root and every grid node: on real
-    // recordings all chains merge within a step or two, so a handful of levels closes it.
-    uint32_t count = 0;
-    if (!walk) {
-        for (uint32_t wq = tid; wq < kNodeCap / 32 + 1; wq += kOrbitThreads) s_mark[wq] = 0u;
-        if (tid == 0) { s_bad = 0; }
-        __syncthreads();
-        for (uint32_t v = tid; v < base_d; v += kOrbitThreads) {
-            if (v < kListCap) s_list[v] = static_cast<uint16_t>(v);
-            atomicOr(&s_mark[v >> 5], 1u << (v & 31));
-        }
-        if (tid == 0) {
-            s_count = base_d;
-            if (base_d > kListCap) s_bad = 1;
-        }
-        __syncthreads();
-        uint32_t lo = 0, hi = base_d;
-        for (int level = 0; level < kMaxLevels && lo < hi && !s_bad; ++level) {
-            for (uint32_t idx = lo + tid; idx < hi; idx += kOrbitThreads) {
-                const uint32_t v = s_list[idx];
-                const uint32_t nx = next_of(v);
-                s_ja[v] = static_cast<uint16_t>(nx);
-                if (nx != END) {
-                    const uint32_t bit = 1u << (nx & 31);
-                    if (!(atomicOr(&s_mark[nx >> 5], bit) & bit)) {
-                        const uint32_t pos = atomicAdd(&s_count, 1u);
-                        if (pos < kListCap) s_list[pos] = static_cast<uint16_t>(nx); else s_bad = 1;
-                    }
-                }
-            }
-            __syncthreads();
-            lo = hi;
-            hi = s_count < kListCap ? s_count : kListCap;
-            __syncthreads();
-        }
-        if (lo < hi || s_bad) {  // not closed within the LDS budget: the global kernel takes over
-            if (tid == 0) flags[5] = 1u;
-            return;
-        }
-        count = hi;
-    }
-    stamp(1);  // reachable set closed
-
-    if (walk) {
-        if (wave == 0) orbit_walk52(words, gq, peaks, peaks_cap, res);
-        if (tid == 0) {
-            flags[1] = 1u;  // report which path ran
-            flags[0] = 0u;  // re-arm the overflow flag for the next decode
-        }
-        return;
-    }
-    if (tid == 0) { s_ja[END] = static_cast<uint16_t>(END); s_path[0] = 0; }
-    __syncthreads();
-
-    // ---- orbit of the root by pointer doubling over the visited nodes only:
-    // path[m + 2^r] = J_r[path[m]],  J_{r+1} = J_r o J_r  (staged in registers, in place)
-    const uint32_t path_cap = static_cast<uint32_t>(kc) + 2;  // root + at most one start per cell
-    constexpr int kPerThread = (kListCap + kOrbitThreads - 1) / kOrbitThreads;
-    for (uint32_t span = 1; span < path_cap; span <<= 1) {
-        for (uint32_t mI = tid; mI < span && mI + span < path_cap; mI += kOrbitThreads)
-            s_path[mI + span] = s_ja[s_path[mI]];
-        uint16_t nv[kPerThread];
-#pragma unroll
-        for (int j = 0; j < kPerThread; ++j) {
-            const uint32_t idx = tid + j * kOrbitThreads;
-            nv[j] = (idx < count) ? s_ja[s_ja[s_list[idx]]] : 0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < kPerThread; ++j) {
-            const uint32_t idx = tid + j * kOrbitThreads;
-            if (idx < count) s_ja[s_list[idx]] = nv[j];
-        }
-        __syncthreads();
-    }
-    stamp(2);  // orbit extracted
-
-    // ---- peak list: path[k] (k >= 1) starts at s in cell c; pushes fill
-    // peaks[cell(prev) .. c-2] with s and peaks[c-1] with u = firstT(s)
-    if (tid == 0) { s_plen = 1; s_fit = 0ull; }
-    __syncthreads();
-    unsigned long long fit_local = 0;
-    for (uint32_t k = tid; k < path_cap; k += kOrbitThreads) {
-        const uint32_t v = s_path[k];
-        if (v == END) continue;
-        uint32_t cell;
-        const uint32_t s = node_start(v, &cell);
-        const uint32_t u = s_nt[first_node_terminal(v == 0 ? 0u : s)];
-        const bool is_last = (k + 1 >= path_cap) || s_path[k + 1] == END;
-        if (k == 0) {
-            if (peaks_cap > 0) peaks[0] = u;
-            if (!is_last && u + spr < wl32) ++fit_local;
-            if (is_last) s_plen = 1;
-            continue;
-        }
-        uint32_t pcell;
-        (void)node_start(s_path[k - 1], &pcell);
-        const uint32_t c_prev = (k - 1 == 0) ? 1u : pcell;  // the root leaves one entry
-        const uint32_t c = cell;                             // = s / spr for k >= 1
-        for (uint32_t qv = c_prev; qv + 1 < c; ++qv)
-            if (qv < peaks_cap) peaks[qv] = s;
-        if (c - 1 < peaks_cap) peaks[c - 1] = u;
-        if (s + spr < wl32) fit_local += c - c_prev - 1;
-        if (!is_last && u + spr < wl32) ++fit_local;  // the last peak is dropped
-        if (is_last) s_plen = c;
-    }
-    atomicAdd(&s_fit, fit_local);
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t len = s_plen;
-        const bool few = len < 5;  // decode.rs:112-118
-        const uint64_t rows = s_fit;
-        res->status = few ? 1 : 0;
-        res->reason = few ? 2 : 0;
-        res->n_sync = len;
-        res->n_rows = few ? 0 : static_cast<uint32_t>(rows);
-        res->work_len = gq.work_len;
-        res->n_out = few ? 0 : rows * 2080u;
-        flags[1] = 0u;
-        flags[0] = 0u;
-        flags[2] = total;
-        flags[3] = n_nodes;
-        flags[4] = count;
-    }
-    stamp(3);  // peaks written
-}
-
 
 // Relaxed agent-scope accesses: the tables below live in global memory (L2) and are written
 // and re-read inside one launch; these bypass the CU's L1 so a __syncthreads() is enough to
@@ -566,23 +431,33 @@ __device__ __forceinline__ void gst(uint32_t *p, uint32_t v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// One workgroup; every table in the global scratch `ws` (sized by sync_orbit_ws_words()), so
-// the kernel needs almost no LDS and can run beside the next recording's front end.  Node
-// terminals are looked up straight in the per-chunk slots k_sync_nodes wrote (no gather pass):
-// chunk = position / (128*52), then the first entry >= s of that slot or of the next
-// non-empty one.  Node ids: 0 root, 1..n_grid grid cells 2..kc, base_d + slot entry, END.
+// One workgroup per recording (blockIdx.x); every table in the global scratch `ws` (sized by
+// sync_orbit_ws_words()), so the kernel needs almost no LDS and can run beside the next call's
+// front end.  Node terminals are looked up straight in the per-chunk slots k_sync_nodes wrote
+// (no gather pass): chunk = position / (128*52), then the first entry >= s of that slot or of the
+// next non-empty one.  Node ids: 0 root, 1..n_grid grid cells 2..kc, base_d + slot entry, END.
 __global__ void __launch_bounds__(kOrbitThreads, 8)
-k_sync_orbit_global(const uint64_t *__restrict__ words, const uint32_t *__restrict__ slot_nt,
-             const uint32_t *__restrict__ slot_cnt, uint32_t n_chunks, uint32_t *__restrict__ flags,
-             OrbitGeom gq, uint32_t *__restrict__ ws, uint32_t nt_cap, uint32_t *__restrict__ peaks,
-             uint32_t peaks_cap, Result *__restrict__ res, int force_walk)
+k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t spr_in, uint32_t md_in,
+                    uint32_t pw, int force_walk)
 {
-    // after the LDS-resident kernel (force_walk == 3) it runs only if that kernel handed the
-    // recording over (flags[5]); on its own it is the default picker
-    if (force_walk == 3) {
-        if (flags[5] == 0) return;
-        force_walk = 0;
-    }
+    const RecArgs rec = call.rec[blockIdx.x];
+    const SlotPtrs sp = slots[rec.slot];
+    const uint64_t *__restrict__ words = sp.words;
+    const uint32_t *__restrict__ slot_nt = sp.slot_nt;
+    const uint32_t *__restrict__ slot_cnt = sp.slot_cnt;
+    uint32_t *__restrict__ flags = sp.flags;
+    uint32_t *__restrict__ ws = sp.orbit_ws;
+    uint32_t *__restrict__ peaks = sp.peaks;
+    const uint32_t peaks_cap = sp.peaks_cap;
+    Result *__restrict__ res = sp.res;
+    OrbitGeom gq;
+    gq.work_len = rec.w;
+    gq.n_corr = rec.w - 38ull * pw;
+    gq.spr = spr_in;
+    gq.md = md_in;
+    const uint32_t n_chunks =
+        static_cast<uint32_t>(((gq.n_corr + GS - 1) / GS + kChunkGroups - 1) / kChunkGroups);
+    const uint32_t nt_cap = n_chunks * kSlotCap;  // node ids of slot entries: base_d + chunk*kSlotCap + k
     __shared__ uint32_t s_count, s_plen, s_conflict, s_endcell;
     __shared__ unsigned long long s_fit;
     // this latency-bound workgroup shares its CU with VALU-saturated front-end waves of the next
@@ -829,67 +704,60 @@ uint32_t sync_group_size() { return GS; }
 uint32_t sync_chunk_groups() { return kChunkGroups; }
 uint32_t sync_slot_cap() { return kSlotCap; }
 
-void group_max(hipStream_t s, const float *corr, uint64_t n_corr, float *gm)
+void group_max(hipStream_t s, const float *corr, uint64_t n_corr, GroupMax *gm)
 {
     const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
     if (ng == 0) return;
     hipLaunchKernelGGL(k_group_max, dim3((ng + 255) / 256), dim3(256), 0, s, corr, n_corr, gm, ng);
 }
 
-void sync_nodes(hipStream_t s, const float *gm, const float *corr, uint64_t n_corr, uint32_t spr,
-                uint32_t md, uint64_t *words, uint32_t *slot_nt, uint32_t *slot_cnt, uint32_t *flags)
+void sync_nodes(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint64_t max_w, uint32_t pw,
+                uint32_t spr, uint32_t md, bool fast, bool use_corr)
 {
+    if (call.count == 0 || max_w <= 38ull * pw) return;
+    const uint64_t n_corr = max_w - 38ull * pw;
     const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
-    if (ng == 0) return;
     const uint32_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
     const uint32_t r = md / GS;
-    const size_t lds = static_cast<size_t>(kChunkGroups + r + 1) * 8 + static_cast<size_t>(kChunkGroups + 2 * r + 2) * 4 +
-                       static_cast<size_t>(kChunkGroups + r + 1) * 4 + static_cast<size_t>(kChunkGroups + r + 1) * 2 + 16;
-    hipLaunchKernelGGL(k_sync_nodes, dim3(chunks), dim3(kNodesThreads), lds, s, gm, ng, corr, n_corr,
-                       r, spr / GS, words, slot_nt, slot_cnt, flags);
+    const size_t lds = static_cast<size_t>(kChunkGroups + r + 1) * (8 + 4 + 2 + 1) +
+                       static_cast<size_t>(kChunkGroups + 2 * r + 2) * 4 + 32 +
+                       static_cast<size_t>(kNodesWaves) * 2 * nodes_window(pw) * sizeof(float);
+    const dim3 grid(chunks, call.count);
+    const uint32_t wneed = GS + 38u * pw - 1u;
+    if (wneed <= 192)
+        hipLaunchKernelGGL(k_sync_nodes<3>, grid, dim3(kNodesThreads), lds, s, call, d_slots, pw, r, spr / GS,
+                           fast ? 1 : 0, use_corr ? 1 : 0);
+    else if (wneed <= 256)
+        hipLaunchKernelGGL(k_sync_nodes<4>, grid, dim3(kNodesThreads), lds, s, call, d_slots, pw, r, spr / GS,
+                           fast ? 1 : 0, use_corr ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_sync_nodes<0>, grid, dim3(kNodesThreads), lds, s, call, d_slots, pw, r, spr / GS,
+                           fast ? 1 : 0, use_corr ? 1 : 0);
 }
 
-// uint32 words of scratch k_sync_orbit needs for a correlation of n_corr positions
-size_t sync_orbit_ws_words(uint64_t n_corr, uint32_t spr)
+// node-terminal capacity and uint32 words of scratch k_sync_orbit needs for a work signal of w samples
+uint32_t sync_nt_cap(uint64_t w)
 {
-    const uint64_t ng = (n_corr + GS - 1) / GS;
+    const uint64_t ng = (w + GS - 1) / GS;
     const uint64_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
-    const uint64_t nt_cap = chunks * kSlotCap;
-    const uint64_t kc = (spr ? n_corr / spr : 0) + 2;
+    return static_cast<uint32_t>(chunks * kSlotCap);
+}
+
+size_t sync_orbit_ws_words(uint64_t w, uint32_t spr)
+{
+    const uint64_t nt_cap = sync_nt_cap(w);
+    const uint64_t kc = (spr ? w / spr : 0) + 2;
     const uint64_t node_cap = 1 + kc + nt_cap + 1;
     return 4 * node_cap + (node_cap / 32 + 1) + (kc + 2) + (kc + 3) + 64;
 }
 
-void sync_orbit(hipStream_t s, const uint64_t *words, const uint32_t *slot_nt,
-                const uint32_t *slot_cnt, uint32_t *flags, uint64_t n_corr, uint64_t work_len,
-                uint32_t spr, uint32_t md, uint32_t *ws, uint32_t *peaks, uint32_t peaks_cap,
-                Result *res, int force)
+void sync_orbit(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint32_t spr, uint32_t md,
+                uint32_t pw, int force)
 {
-    const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
-    const uint32_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
-    OrbitGeom gq{n_corr, work_len, spr, md};
-    const size_t lds = static_cast<size_t>(kNtCap) * 4 + static_cast<size_t>(kNodeCap / 32 + 1) * 4 +
-                       static_cast<size_t>(kNodeCap) * 2 + static_cast<size_t>(kListCap) * 2 +
-                       static_cast<size_t>(kCellCap + 2) * 2 + 64;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_orbit_lds),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        attr_set = true;
-    }
-    // force: 0 = global-memory kernel (default: tiny LDS, co-runs with the next front end, no
-    // capacity limits), 1 = sequential walk, 2 = same as 0, 4 = LDS-resident kernel first (lowest
-    // stand-alone latency) with the global-memory kernel as its overflow path
-    if (force == 4) {
-        hipLaunchKernelGGL(k_sync_orbit_lds, dim3(1), dim3(kOrbitThreads), lds, s, words, slot_nt, slot_cnt,
-                           chunks, flags, gq, peaks, peaks_cap, res, 0);
-        hipLaunchKernelGGL(k_sync_orbit_global, dim3(1), dim3(kOrbitThreads), 0, s, words, slot_nt,
-                           slot_cnt, chunks, flags, gq, ws, chunks * kSlotCap, peaks, peaks_cap, res, 3);
-    } else {
-        hipLaunchKernelGGL(k_sync_orbit_global, dim3(1), dim3(kOrbitThreads), 0, s, words, slot_nt,
-                           slot_cnt, chunks, flags, gq, ws, chunks * kSlotCap, peaks, peaks_cap, res,
-                           force == 1 ? 1 : 0);
-    }
+    if (call.count == 0) return;
+    // force: 0 = parallel picker, 1 = sequential walk over the terminal words
+    hipLaunchKernelGGL(k_sync_orbit_global, dim3(call.count), dim3(kOrbitThreads), 0, s, call, d_slots, spr, md, pw,
+                       force == 1 ? 1 : 0);
 }
 
 }  // namespace apt::gpu

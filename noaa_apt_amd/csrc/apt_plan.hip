@@ -110,6 +110,8 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     const uint64_t spr64 = static_cast<uint64_t>(PX_PER_ROW) * settings.work_rate;
     if (spr64 > 0xFFFFFFFFull) throw Error{ErrorKind::Invalid, "work_rate too large"};
     plan->spr = static_cast<uint32_t>(spr64 / FINAL_RATE);
+    // (the reference would divide by zero at decode.rs:142 / find nothing to sync on)
+    if (plan->spr == 0) throw Error{ErrorKind::Invalid, "work_rate too small"};
 
     const Rate in_rate = Rate::hz(input_rate);
     const Rate work_rate = Rate::hz(settings.work_rate);
@@ -179,6 +181,16 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         plan->user_stream = static_cast<hipStream_t>(ctx->stream);
         hip_check(hipEventCreateWithFlags(&plan->ev_user, hipEventDisableTiming), "hipEventCreate");
     }
+    // Calls in flight = streams (call j runs on stream j % depth and owns that stream's slots).
+    if (depth <= 0) {
+        const char *e = std::getenv("APTGPU_STREAMS");
+        depth = e ? std::atoi(e) : (max_batch >= 4 ? 3 : 6);
+    }
+    depth = std::max(1, std::min(depth, 16));
+    plan->streams.resize(static_cast<size_t>(depth));
+    for (auto &st : plan->streams)
+        hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+    plan->stream = plan->streams[0];
 
     plan->max_work_len = plan->work_len_for(max_samples);
     const uint64_t rows = plan->spr ? plan->max_work_len / plan->spr + 2 : 2;
@@ -186,9 +198,12 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
 
     auto upload = [&](DeviceBuffer<float> &dst, const Signal &src) {
         dst.alloc(src.size());
-        hip_check(hipMemcpy(dst.ptr, src.data(), src.size() * sizeof(float),
-                            hipMemcpyHostToDevice),
+        // on the plan's own stream (the null stream would serialise against other plans' work);
+        // the source is a temporary of the caller, so wait for the copy before returning
+        hip_check(hipMemcpyAsync(dst.ptr, src.data(), src.size() * sizeof(float),
+                                 hipMemcpyHostToDevice, plan->stream),
                   "hipMemcpy taps");
+        hip_check(hipStreamSynchronize(plan->stream), "hipStreamSynchronize");
     };
     upload(plan->d_taps_resample, plan->taps_resample);
     upload(plan->d_taps_lowpass, plan->taps_lowpass);
@@ -196,13 +211,18 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     {
         const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
         const uint32_t t2 = static_cast<uint32_t>(plan->taps_lowpass.size());
-        const bool eligible = plan->mode == APTGPU_MODE_STRICT && plan->l > 1 && plan->work_is_multiple;
+        // APTGPU_MODE_FAST permits deviations within the stated tolerance; where no fast kernel exists
+        // (other rates / profiles) the strict kernels serve it
+        const bool eligible = (plan->mode == APTGPU_MODE_STRICT || plan->mode == APTGPU_MODE_FAST) && plan->l > 1 &&
+                              plan->work_is_multiple;
         const char *force_any = std::getenv("APTGPU_FUSED_ANY");  // tests: run-time kernel even if specialised
         plan->fused = 0;
         if (eligible && gpu::fused_supported(plan->l, plan->m, t1, t2, plan->pw) && !(force_any && force_any[0] == '1'))
             plan->fused = 1;
         else if (eligible && gpu::fused_any_supported(plan->l, plan->m, t1, t2, plan->pw))
             plan->fused = 2;
+        plan->fused_fast = plan->mode == APTGPU_MODE_FAST && plan->fused == 1 &&
+                           gpu::fused_fast_supported(plan->l, plan->m, t1, t2, plan->pw);
         // fp16-tap mode inside the specialised fused kernel where one exists (else the generic kernel)
         if (plan->mode == APTGPU_MODE_FP16_TAPS && plan->l > 1 && plan->work_is_multiple &&
             gpu::fused_f16_supported(plan->l, plan->m, t1, t2, plan->pw)) {
@@ -215,13 +235,16 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         std::vector<uint16_t> tab(static_cast<size_t>(plan->l) * gpu::f16taps_pairs_per_phase(plan->l, t1) * 2 + 8, 0);
         plan->f16_unscale = gpu::f16taps_pack(plan->l, plan->taps_resample.data(), t1, tab.data());
         plan->d_taps_f16.alloc(tab.size());
-        hip_check(hipMemcpy(plan->d_taps_f16.ptr, tab.data(), tab.size() * 2, hipMemcpyHostToDevice), "hipMemcpy f16 taps");
+        hip_check(hipMemcpyAsync(plan->d_taps_f16.ptr, tab.data(), tab.size() * 2, hipMemcpyHostToDevice, plan->stream),
+                  "hipMemcpy f16 taps");
+        hip_check(hipStreamSynchronize(plan->stream), "hipStreamSynchronize");  // `tab` dies here
     }
     if (plan->fused != 0) {
         // division by sin(phi) through its reciprocal: only if it is exactly rounded for every x
         const float rc = 1.0f / plan->sinphi;
         const char *off = std::getenv("APTGPU_GENERAL_ENVELOPE");  // tests: force the general code
-        if (!(off && off[0] == '1') && gpu::verify_fast_divide(nullptr, plan->sinphi, rc)) plan->inv_sinphi = rc;
+        if (plan->fused_fast) plan->inv_sinphi = rc;  // a plain multiplication by the rounded reciprocal
+        else if (!(off && off[0] == '1') && gpu::verify_fast_divide(plan->device, plan->sinphi, rc)) plan->inv_sinphi = rc;
     }
     if (plan->fused == 2) {
         const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
@@ -252,48 +275,13 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         upload(plan->d_taps_lowpass_pairs, h2p);
     }
 
-    // one extra slot so that consecutive calls (and consecutive recordings of a call) overlap
-    // Recordings in flight = streams (slot k always runs on stream k % depth).  Measured on
-    // MI355X at config 2 (ms per recording, HBM-cold inputs): 1: 0.143, 2: 0.117, 4: 0.119,
-    // 5: 0.105, 6: 0.103, 7: 0.117, 8: 0.113, 10: 0.103 — six keeps enough front-end launches
-    // queued that the tail of one is always filled by the head of the next, whatever the
-    // latency of the picker chain behind it.
-    if (depth <= 0) {
-        // batch-capable plans run ONE front-end launch per call on a stream of its own and fan the
-        // per-recording chains out over 3 streams (front + 3 = the 4 hardware queues; measured at
-        // config 4's per-GPU share, 32 x 15 min: 1 chain stream 0.178, 2-4: 0.143, 6: 0.171 ms per
-        // recording; the recording-by-recording pipeline with 6 streams: 0.154 ms)
-        const char *e = std::getenv("APTGPU_STREAMS");
-        depth = e ? std::atoi(e) : (max_batch >= 2 ? 3 : 6);
-    }
-    depth = std::max(1, std::min(depth, 16));
-    plan->slots.resize(std::max<size_t>(max_batch >= 2 ? 2 * static_cast<size_t>(max_batch)
-                                                       : static_cast<size_t>(max_batch) + (depth > 1 ? 1 : 0),
-                                        static_cast<size_t>(depth)));
-    plan->streams.resize(static_cast<size_t>(depth));
-    for (auto &st : plan->streams)
-        hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
-    plan->stream = plan->streams[0];
-    if (max_batch >= 2) {
-        // lowest priority: HIP keeps a separate hardware queue per priority level, so the batched
-        // launch never sits in an in-order queue in front of (or behind) a chain stream's kernels,
-        // and the small chain kernels are dispatched ahead of its thousands of workgroups
-        int prio_least = 0, prio_greatest = 0;
-        hip_check(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest), "hipDeviceGetStreamPriorityRange");
-        hip_check(hipStreamCreateWithPriority(&plan->stream_front, hipStreamNonBlocking, prio_least),
-                  "hipStreamCreateWithPriority");
-        hip_check(hipEventCreateWithFlags(&plan->ev_front, hipEventDisableTiming), "hipEventCreate");
-        plan->d_batch.alloc(static_cast<size_t>(max_batch));
-        for (auto &sl : plan->slots)
-            hip_check(hipEventCreateWithFlags(&sl.ev_free, hipEventDisableTiming), "hipEventCreate");
-    }
+    // workspace: one set of max_batch slots per stream
+    plan->slots.resize(static_cast<size_t>(depth) * static_cast<size_t>(max_batch));
     const uint64_t w = plan->max_work_len;
     for (auto &sl : plan->slots) {
-        // (resampled / demodulated are only needed by the unfused kernels: allocated on first use)
+        // (resampled / demodulated / correlation are only needed by the unfused kernels: allocated on first use)
         sl.filtered.alloc(w + 64);
         if (sync) {
-            sl.correlation.alloc(w + 64);
-            sl.bits.alloc(w / 64 + plan->md / 64 + 4);
             sl.peaks.alloc(plan->max_rows + 2);
             const uint64_t ng = w / gpu::sync_group_size() + 2;
             const uint64_t chunks = ng / gpu::sync_chunk_groups() + 2;
@@ -303,18 +291,63 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
             sl.slot_cnt.alloc(chunks);
             sl.orbit_ws.alloc(gpu::sync_orbit_ws_words(w, plan->spr));
             sl.flags.alloc(32);
-            hip_check(hipMemset(sl.flags.ptr, 0, 32 * sizeof(uint32_t)), "hipMemset flags");
+            hip_check(hipMemsetAsync(sl.flags.ptr, 0, 32 * sizeof(uint32_t), plan->stream), "hipMemset flags");
+            if (plan->fused == 0) sl.correlation.alloc(w + 64);
+            if (plan->mode == APTGPU_MODE_GENERIC) sl.bits.alloc(w / 64 + plan->md / 64 + 4);
         }
     }
     plan->d_results.alloc(plan->slots.size());
-    hip_check(hipMemset(plan->d_results.ptr, 0, sizeof(gpu::Result) * plan->slots.size()), "hipMemset");
-    // the uploads and memsets above went through the null stream, which the plan's non-blocking
-    // streams do not wait for: make them land before the first decode can be enqueued
-    hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    hip_check(hipMemsetAsync(plan->d_results.ptr, 0, sizeof(gpu::Result) * plan->slots.size(), plan->stream),
+              "hipMemset");
+    plan->d_slots.alloc(plan->slots.size());
+    // the uploads and memsets above ran on the plan's first stream: make them land before a decode can
+    // be enqueued on any of the others (a stream sync, not a device sync — other plans of this process,
+    // e.g. concurrent aptgpu_decode calls on other host threads, keep running)
+    plan->upload_slot_table();
     return plan.release();
 }
 
 }  // namespace apt
+
+void aptgpu_plan::upload_slot_table()
+{
+    std::vector<apt::gpu::SlotPtrs> tab(slots.size());
+    for (size_t k = 0; k < slots.size(); ++k) {
+        Slot &sl = slots[k];
+        apt::gpu::SlotPtrs &t = tab[k];
+        t.f = sl.filtered.ptr;
+        t.gm = sl.gm.ptr;
+        t.corr = sl.correlation.ptr;
+        t.words = sl.words.ptr;
+        t.slot_nt = sl.slot_nt.ptr;
+        t.slot_cnt = sl.slot_cnt.ptr;
+        t.flags = sl.flags.ptr;
+        t.orbit_ws = sl.orbit_ws.ptr;
+        t.peaks = sl.peaks.ptr;
+        t.res = d_results.ptr + k;
+        t.peaks_cap = static_cast<uint32_t>(sl.peaks.count);
+        t.reserved = 0;
+    }
+    apt::hip_check(hipMemcpyAsync(d_slots.ptr, tab.data(), tab.size() * sizeof(apt::gpu::SlotPtrs),
+                                  hipMemcpyHostToDevice, stream),
+                   "hipMemcpy slot table");
+    apt::gpu::FusedParams prm{};
+    if (fused == 1) {
+        prm.hs = d_taps_branch.ptr;
+        prm.h2 = d_taps_lowpass.ptr;
+        prm.h2p = d_taps_lowpass_pairs.ptr;
+        prm.slots = d_slots.ptr;
+        prm.cosphi2 = cosphi2;
+        prm.sinphi = sinphi;
+        prm.inv_sinphi = inv_sinphi;
+        prm.f16_unscale = fused_f16 ? f16_unscale : 0.f;
+        prm.want_gm = (sync && work_is_multiple) ? 1 : 0;
+        if (!d_fused_params.ptr) d_fused_params.alloc(1);
+        apt::hip_check(hipMemcpyAsync(d_fused_params.ptr, &prm, sizeof prm, hipMemcpyHostToDevice, stream),
+                       "hipMemcpy fused params");
+    }
+    apt::hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+}
 
 // ------------------------------------------------------------------ geometry
 uint64_t aptgpu_plan::work_len_for(uint64_t n) const
@@ -330,45 +363,28 @@ uint64_t aptgpu_plan::out_len_nosync(uint64_t work_len) const
     return aligned / m2;
 }
 
-// ------------------------------------------------------------------ pipeline
-// The kernel sequence of decode() for one recording already in HBM.
-void aptgpu_plan::begin_call(int count)
-{
-    last_slots.assign(static_cast<size_t>(count), 0);
-    // the streams this call uses wait for ctx.stream in enqueue()
-    if (user_stream) apt::hip_check(hipEventRecord(ev_user, user_stream), "hipEventRecord");
-}
-
 void aptgpu_plan::sync_all()
 {
-    if (stream_front) apt::hip_check(hipStreamSynchronize(stream_front), "hipStreamSynchronize");
     for (hipStream_t st : streams) apt::hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
 }
 
-int aptgpu_plan::enqueue(int i, const Input &in, float *d_rows, uint64_t rows_cap_floats, bool keep_steps,
-                         int forced_slot, bool front_done)
+// ------------------------------------------------------------------ pipeline
+// The kernel sequence of decode() for the recordings of one call, all already in HBM.
+void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, const uint64_t *rows_cap_floats,
+                           bool keep_steps)
 {
     using namespace apt::gpu;
-    const uint64_t n = in.n;
-    const int slot = forced_slot >= 0 ? forced_slot : static_cast<int>(seq++ % slots.size());
-    if (static_cast<size_t>(i) < last_slots.size()) last_slots[static_cast<size_t>(i)] = slot;
-    Slot &sl = slots[static_cast<size_t>(slot)];
-    Result *res = d_results.ptr + slot;
-    const uint64_t w = work_len_for(n);
-    // everything of this recording runs in order on the slot's own stream; the recording that
-    // reuses the slot is enqueued on the same stream, so no hand-over events are needed
-    hipStream_t cur = streams[static_cast<size_t>(slot) % streams.size()];
-    if (user_stream && !front_done) apt::hip_check(hipStreamWaitEvent(cur, ev_user, 0), "hipStreamWaitEvent");
-    // batch-capable plans: tell the batched front end when this slot's chain is over
-    struct FreeMark {
-        aptgpu_plan *p;
-        Slot &sl;
-        hipStream_t st;
-        ~FreeMark()
-        {
-            if (p->stream_front && sl.ev_free && hipEventRecord(sl.ev_free, st) == hipSuccess) sl.ev_free_recorded = true;
-        }
-    } free_mark{this, sl, cur};
+    if (count < 0 || count > max_batch) throw apt::Error{apt::ErrorKind::Invalid, "more recordings than max_batch"};
+    last_stream = static_cast<int>(calls++ % streams.size());
+    hipStream_t cur = streams[static_cast<size_t>(last_stream)];
+    const int slot0 = last_stream * max_batch;
+    last_slots.assign(static_cast<size_t>(count), 0);
+    for (int i = 0; i < count; ++i) last_slots[static_cast<size_t>(i)] = slot0 + i;
+    // the call's stream waits for what is already enqueued on ctx.stream (inputs may be produced there)
+    if (user_stream) {
+        apt::hip_check(hipEventRecord(ev_user, user_stream), "hipEventRecord");
+        apt::hip_check(hipStreamWaitEvent(cur, ev_user, 0), "hipStreamWaitEvent");
+    }
     auto timed = [&](const char *name, auto &&launch) {
         const bool dominant = !std::strcmp(name, "fused_front_end") || !std::strcmp(name, "resample_generic") ||
                               !std::strcmp(name, "resample_f16taps");
@@ -377,130 +393,209 @@ int aptgpu_plan::enqueue(int i, const Input &in, float *d_rows, uint64_t rows_ca
         timer.end(cur);
     };
 
-    // decode.rs:79-83 — fewer than 10 rows of samples
-    if (w < 10ull * spr) {
-        set_result(cur, res, Result{APTGPU_ERR_INTERNAL, 1, 0, 0, w, 0});
-        return slot;
+    const bool use_fused = fused != 0 && !keep_steps;
+    const bool want_sync = sync && work_is_multiple;
+    if (!use_fused && sync) {
+        // the unfused kernels keep the full correlation; a fused plan that exports steps gets the
+        // buffers (and their entry in the slot table) on first use
+        bool grew = false;
+        for (int i = 0; i < count; ++i) {
+            Slot &sl = slots[static_cast<size_t>(slot0 + i)];
+            if (!sl.correlation.ptr) {
+                sl.correlation.alloc(max_work_len + 64);
+                grew = true;
+            }
+        }
+        if (grew) {
+            sync_all();  // (no launch in flight may be reading the table while it is rewritten)
+            upload_slot_table();
+        }
     }
 
-    const bool use_fused = fused != 0 && !keep_steps;
-    // WAV ingest (wav.rs:30-51): mono PCM16 goes straight into the fused front end, anything
-    // else is converted into the slot's f32 staging buffer first
-    const float *d_signal = static_cast<const float *>(in.ptr);
-    const bool pcm16 = in.codec == static_cast<int>(apt::WavCodec::I16) && in.channels == 1 && use_fused &&
-                       (reinterpret_cast<uintptr_t>(in.ptr) & (fused == 1 ? 3u : 1u)) == 0;
-    if (in.codec >= 0 && !pcm16) {
-        if (!sl.ingest.ptr) sl.ingest.alloc(max_samples + 16);
-        timed("wav_to_signal", [&] {
-            wav_to_signal(cur, in.ptr, n, in.channels, in.bytes_per_sample, in.codec, sl.ingest.ptr);
-        });
-        d_signal = sl.ingest.ptr;
+    // recordings that go through the kernels; the error paths of decode() are settled per recording
+    std::vector<int> live;
+    std::vector<uint64_t> wlen(static_cast<size_t>(count));
+    std::vector<const void *> xin(static_cast<size_t>(count));
+    std::vector<char> is_pcm(static_cast<size_t>(count), 0);
+    for (int i = 0; i < count; ++i) {
+        const Input &in = ins[i];
+        Slot &sl = slots[static_cast<size_t>(slot0 + i)];
+        Result *res = d_results.ptr + slot0 + i;
+        const uint64_t w = work_len_for(in.n);
+        wlen[static_cast<size_t>(i)] = w;
+        // decode.rs:79-83 — fewer than 10 rows of samples
+        if (w < 10ull * spr) {
+            set_result(cur, res, Result{APTGPU_ERR_INTERNAL, 1, 0, 0, w, 0});
+            continue;
+        }
+        // WAV ingest (wav.rs:30-51): mono PCM16 goes straight into the fused front end, anything
+        // else is converted into the slot's f32 staging buffer first
+        const bool pcm16 = in.codec == static_cast<int>(apt::WavCodec::I16) && in.channels == 1 && use_fused &&
+                           (reinterpret_cast<uintptr_t>(in.ptr) & (fused == 1 ? 3u : 1u)) == 0;
+        xin[static_cast<size_t>(i)] = in.ptr;
+        is_pcm[static_cast<size_t>(i)] = pcm16 ? 1 : 0;
+        if (in.codec >= 0 && !pcm16) {
+            if (!sl.ingest.ptr) sl.ingest.alloc(max_samples + 16);
+            timed("wav_to_signal", [&] {
+                wav_to_signal(cur, in.ptr, in.n, in.channels, in.bytes_per_sample, in.codec, sl.ingest.ptr);
+            });
+            xin[static_cast<size_t>(i)] = sl.ingest.ptr;
+        }
+        live.push_back(i);
     }
-    if (use_fused && front_done) {
-        // the batched launch of enqueue_batch() has produced F, C and GM for this slot already
+
+    // per-stage launches cover up to kMaxCall recordings each
+    auto make_call = [&](const std::vector<int> &idx, size_t from, size_t to, uint64_t *max_w, uint32_t *max_cap) {
+        CallArgs c{};
+        c.count = static_cast<uint32_t>(to - from);
+        *max_w = 0;
+        *max_cap = 0;
+        for (size_t k = from; k < to; ++k) {
+            const int i = idx[k];
+            RecArgs &r = c.rec[k - from];
+            r.x = xin[static_cast<size_t>(i)];
+            r.n = ins[i].n;
+            r.w = wlen[static_cast<size_t>(i)];
+            r.rows = d_rows[i];
+            uint64_t rc = rows_cap_floats[i] / 2080u;
+            if (rc > max_rows) rc = max_rows;
+            r.rows_cap = static_cast<uint32_t>(rc);
+            r.slot = static_cast<uint32_t>(slot0 + i);
+            *max_w = std::max(*max_w, r.w);
+            *max_cap = std::max(*max_cap, r.rows_cap);
+        }
+        return c;
+    };
+    auto for_chunks = [&](const std::vector<int> &idx, auto &&fn) {
+        for (size_t from = 0; from < idx.size(); from += static_cast<size_t>(kMaxCall)) {
+            const size_t to = std::min(idx.size(), from + static_cast<size_t>(kMaxCall));
+            uint64_t max_w = 0;
+            uint32_t max_cap = 0;
+            const CallArgs c = make_call(idx, from, to, &max_w, &max_cap);
+            fn(c, max_w, max_cap);
+        }
+    };
+
+    const uint32_t t1 = static_cast<uint32_t>(taps_resample.size());
+    const uint32_t t2 = static_cast<uint32_t>(taps_lowpass.size());
+    if (use_fused && fused == 1) {
+        // 1-3 fused: resample -> envelope -> low-pass (-> correlation maxima) in one launch per input
+        // kind (apt_kernels_fused.hip)
+        for (int kind = 0; kind < 2; ++kind) {
+            std::vector<int> idx;
+            for (int i : live)
+                if (is_pcm[static_cast<size_t>(i)] == kind) idx.push_back(i);
+            for_chunks(idx, [&](const CallArgs &c, uint64_t max_w, uint32_t) {
+                timed("fused_front_end", [&] {
+                    const int kmode = fused_f16 ? 1 : (fused_fast ? 2 : 0);
+                    if (!fused_front_end(cur, l, m, t1, t2, pw, kmode, kind == 1, c, d_fused_params.ptr, max_w))
+                        throw apt::Error{apt::ErrorKind::Internal, "fused front end: no kernel for this geometry"};
+                });
+            });
+        }
     } else if (use_fused) {
-        // 1-3 fused: resample -> envelope -> low-pass in one launch (apt_kernels_fused.hip)
-        timed("fused_front_end", [&] {
-            const uint32_t t1 = static_cast<uint32_t>(taps_resample.size());
-            const uint32_t t2 = static_cast<uint32_t>(taps_lowpass.size());
-            const void *xin = pcm16 ? in.ptr : static_cast<const void *>(d_signal);
-            float *c_out = (sync && work_is_multiple) ? sl.correlation.ptr : nullptr;
-            float *gm_out = (sync && work_is_multiple) ? sl.gm.ptr : nullptr;
-            if (fused == 1)
-                fused_front_end(cur, l, m, t1, t2, pw, xin, pcm16, n, d_taps_branch.ptr, d_taps_lowpass.ptr,
-                                d_taps_lowpass_pairs.ptr, cosphi2, sinphi, inv_sinphi,
-                                fused_f16 ? f16_unscale : 0.f, sl.filtered.ptr, c_out, gm_out, w,
-                                w - n_sync_taps);
-            else
-                fused_any_front_end(cur, l, m, t1, t2, pw, xin, pcm16, n, d_taps_any.ptr, d_taps_lowpass.ptr,
-                                    d_taps_lowpass_pairs.ptr, cosphi2, sinphi, inv_sinphi, sl.filtered.ptr, c_out,
-                                    gm_out, w, w - n_sync_taps);
-        });
+        for (int i : live) {
+            Slot &sl = slots[static_cast<size_t>(slot0 + i)];
+            const uint64_t w = wlen[static_cast<size_t>(i)];
+            timed("fused_front_end", [&] {
+                fused_any_front_end(cur, l, m, t1, t2, pw, xin[static_cast<size_t>(i)], is_pcm[static_cast<size_t>(i)] != 0,
+                                    ins[i].n, d_taps_any.ptr, d_taps_lowpass.ptr, d_taps_lowpass_pairs.ptr, cosphi2,
+                                    sinphi, inv_sinphi, sl.filtered.ptr, want_sync ? sl.gm.ptr : nullptr, w,
+                                    w - n_sync_taps);
+            });
+        }
     } else {
-    if (!sl.resampled.ptr) {
-        sl.resampled.alloc(max_work_len + 64);
-        sl.demodulated.alloc(max_work_len + 64);
-    }
-    // 1. resample to work_rate (dsp.rs:62-126)
-    if (l > 1 && mode == APTGPU_MODE_FP16_TAPS) {
-        timed("resample_f16taps", [&] {
-            resample_f16taps(cur, d_signal, n, d_taps_f16.ptr, static_cast<uint32_t>(taps_resample.size()),
-                             l, m, f16_unscale, sl.resampled.ptr, w);
-        });
-    } else if (l > 1) {
-        timed("resample_generic", [&] {
-            resample_generic(cur, d_signal, n, d_taps_resample.ptr,
-                             static_cast<uint32_t>(taps_resample.size()), l, m, sl.resampled.ptr, w);
-        });
-    } else {
-        timed("fir_decimate", [&] {
-            fir_decimate(cur, d_signal, n, d_taps_resample.ptr,
-                         static_cast<uint32_t>(taps_resample.size()), m, sl.resampled.ptr, w);
-        });
-    }
-    // 2. AM envelope (dsp.rs:350-383)
-    timed("demodulate",
-          [&] { demodulate(cur, sl.resampled.ptr, w, cosphi2, sinphi, sl.demodulated.ptr); });
-    // 3. low-pass (dsp.rs:386-410)
-    timed("lowpass", [&] {
-        fir_decimate(cur, sl.demodulated.ptr, w, d_taps_lowpass.ptr,
-                     static_cast<uint32_t>(taps_lowpass.size()), 1, sl.filtered.ptr, w);
-    });
+        for (int i : live) {
+            Slot &sl = slots[static_cast<size_t>(slot0 + i)];
+            const uint64_t w = wlen[static_cast<size_t>(i)];
+            const uint64_t n = ins[i].n;
+            const float *d_signal = static_cast<const float *>(xin[static_cast<size_t>(i)]);
+            if (!sl.resampled.ptr) {
+                sl.resampled.alloc(max_work_len + 64);
+                sl.demodulated.alloc(max_work_len + 64);
+            }
+            // 1. resample to work_rate (dsp.rs:62-126)
+            if (l > 1 && mode == APTGPU_MODE_FP16_TAPS) {
+                timed("resample_f16taps", [&] {
+                    resample_f16taps(cur, d_signal, n, d_taps_f16.ptr, t1, l, m, f16_unscale, sl.resampled.ptr, w);
+                });
+            } else if (l > 1) {
+                timed("resample_generic", [&] {
+                    resample_generic(cur, d_signal, n, d_taps_resample.ptr, t1, l, m, sl.resampled.ptr, w);
+                });
+            } else {
+                timed("fir_decimate", [&] {
+                    fir_decimate(cur, d_signal, n, d_taps_resample.ptr, t1, m, sl.resampled.ptr, w);
+                });
+            }
+            // 2. AM envelope (dsp.rs:350-383)
+            timed("demodulate", [&] { demodulate(cur, sl.resampled.ptr, w, cosphi2, sinphi, sl.demodulated.ptr); });
+            // 3. low-pass (dsp.rs:386-410)
+            timed("lowpass", [&] {
+                fir_decimate(cur, sl.demodulated.ptr, w, d_taps_lowpass.ptr, t2, 1, sl.filtered.ptr, w);
+            });
+            // 4a. the full correlation of find_sync (decode.rs:225-233) and its group maxima
+            if (want_sync) {
+                const uint64_t n_corr = w - n_sync_taps;  // w >= 10*spr > 38*pw
+                timed("correlate", [&] { correlate(cur, sl.filtered.ptr, n_corr, pw, sl.correlation.ptr); });
+                if (mode != APTGPU_MODE_GENERIC)
+                    timed("group_max", [&] { group_max(cur, sl.correlation.ptr, n_corr, sl.gm.ptr); });
+            }
+        }
     }
 
     if (sync && !work_is_multiple) {
         // generate_sync_frame, decode.rs:172-176
-        set_result(cur, res, Result{APTGPU_ERR_INTERNAL, 3, 0, 0, w, 0});
+        for (int i : live)
+            set_result(cur, d_results.ptr + slot0 + i, Result{APTGPU_ERR_INTERNAL, 3, 0, 0, wlen[static_cast<size_t>(i)], 0});
     } else if (sync) {
-        // 4. find_sync (decode.rs:204-263): correlation, terminal flags, orbit
-        const uint64_t n_corr = w - n_sync_taps;  // w >= 10*spr > 38*pw
-        if (!use_fused)
-            timed("correlate", [&] { correlate(cur, sl.filtered.ptr, n_corr, pw, sl.correlation.ptr); });
+        // 4. find_sync (decode.rs:204-263): terminal flags, orbit
         if (mode == APTGPU_MODE_GENERIC) {
             // reference-shaped picker: full sliding-window terminals + sequential orbit
-            timed("terminals", [&] { terminals(cur, sl.correlation.ptr, n_corr, md, sl.bits.ptr); });
-            timed("orbit_walk", [&] {
-                orbit_walk(cur, sl.bits.ptr, n_corr, w, spr, md, sl.peaks.ptr,
-                           static_cast<uint32_t>(sl.peaks.count), res);
-            });
+            for (int i : live) {
+                Slot &sl = slots[static_cast<size_t>(slot0 + i)];
+                const uint64_t w = wlen[static_cast<size_t>(i)];
+                const uint64_t n_corr = w - n_sync_taps;
+                timed("terminals", [&] { terminals(cur, sl.correlation.ptr, n_corr, md, sl.bits.ptr); });
+                timed("orbit_walk", [&] {
+                    orbit_walk(cur, sl.bits.ptr, n_corr, w, spr, md, sl.peaks.ptr, static_cast<uint32_t>(sl.peaks.count),
+                               d_results.ptr + slot0 + i);
+                });
+            }
         } else {
-            if (!use_fused)
-                timed("group_max", [&] { group_max(cur, sl.correlation.ptr, n_corr, sl.gm.ptr); });
-            timed("sync_nodes", [&] {
-                sync_nodes(cur, sl.gm.ptr, sl.correlation.ptr, n_corr, spr, md, sl.words.ptr,
-                           sl.slot_nt.ptr, sl.slot_cnt.ptr, sl.flags.ptr);
-            });
-            timed("sync_orbit", [&] {
-                sync_orbit(cur, sl.words.ptr, sl.slot_nt.ptr, sl.slot_cnt.ptr, sl.flags.ptr, n_corr,
-                           w, spr, md, sl.orbit_ws.ptr, sl.peaks.ptr,
-                           static_cast<uint32_t>(sl.peaks.count), res, picker_force);
+            for_chunks(live, [&](const CallArgs &c, uint64_t max_w, uint32_t) {
+                timed("sync_nodes", [&] { sync_nodes(cur, c, d_slots.ptr, max_w, pw, spr, md, use_fused && fused_fast, !use_fused); });
+                timed("sync_orbit", [&] { sync_orbit(cur, c, d_slots.ptr, spr, md, pw, picker_force); });
             });
         }
         // 5. aligned rows + final /pw (decode.rs:120-134,158-159)
-        uint64_t rows_cap = rows_cap_floats / 2080u;
-        if (rows_cap > max_rows) rows_cap = max_rows;
-        timed("gather_rows", [&] {
-            gather_rows(cur, sl.filtered.ptr, sl.peaks.ptr, res, spr, pw, false, d_rows,
-                        static_cast<uint32_t>(rows_cap));
+        for_chunks(live, [&](const CallArgs &c, uint64_t, uint32_t max_cap) {
+            timed("gather_rows", [&] { gather_rows_call(cur, c, d_slots.ptr, spr, pw, max_cap); });
         });
     } else {
         // decode.rs:135-159 — crop to whole rows, resample_with_filter(NoFilter)
-        const uint64_t aligned = w / spr * spr;
-        uint64_t n_out = out_len_nosync(w);
-        if (n_out > rows_cap_floats) n_out = rows_cap_floats;
-        if (l2 > 1) {
-            timed("final_resample", [&] {
-                resample_generic(cur, sl.filtered.ptr, aligned, d_one.ptr, 1, l2, m2, d_rows, n_out);
-            });
-        } else {
-            timed("final_decimate", [&] {
-                fir_decimate(cur, sl.filtered.ptr, aligned, d_one.ptr, 1, m2, d_rows, n_out);
-            });
+        for (int i : live) {
+            Slot &sl = slots[static_cast<size_t>(slot0 + i)];
+            const uint64_t w = wlen[static_cast<size_t>(i)];
+            const uint64_t aligned = w / spr * spr;
+            uint64_t n_out = out_len_nosync(w);
+            if (n_out > rows_cap_floats[i]) n_out = rows_cap_floats[i];
+            if (l2 > 1) {
+                timed("final_resample", [&] {
+                    resample_generic(cur, sl.filtered.ptr, aligned, d_one.ptr, 1, l2, m2, d_rows[i], n_out);
+                });
+            } else {
+                timed("final_decimate", [&] {
+                    fir_decimate(cur, sl.filtered.ptr, aligned, d_one.ptr, 1, m2, d_rows[i], n_out);
+                });
+            }
+            set_result(cur, d_results.ptr + slot0 + i,
+                       Result{APTGPU_OK, 0, static_cast<uint32_t>(n_out / 2080u), 0, w, n_out});
         }
-        set_result(cur, res,
-                   Result{APTGPU_OK, 0, static_cast<uint32_t>(n_out / 2080u), 0, w, n_out});
     }
-    return slot;
+    // a launch that failed (bad grid / LDS size, an earlier fault) would otherwise leave a stale or
+    // zeroed — i.e. "OK" — result record behind
+    apt::hip_check(hipGetLastError(), "kernel launch (decode chain)");
 }
 
 // ------------------------------------------------------------------ image stage
@@ -516,8 +611,7 @@ void aptgpu_plan::enqueue_image(int i, const float *d_rows, uint64_t rows_cap_fl
     const uint64_t ws_cap = std::max<uint64_t>(static_cast<uint64_t>(max_rows) * 2080u,
                                                out_len_nosync(work_len_for(max_samples)) + 16);
     if (!d_image_results.ptr) {
-        // (no memset: a null-stream memset is not ordered with the plan's non-blocking streams and
-        // could land after the kernels below; the first kernel of every variant resets its record)
+        // (no memset: the first kernel of every variant resets its record)
         d_image_results.alloc(slots.size());
     }
     if (!sl.image_ws.ptr) sl.image_ws.alloc(image_ws_bytes(ws_cap));
@@ -538,60 +632,5 @@ void aptgpu_plan::enqueue_image(int i, const float *d_rows, uint64_t rows_cap_fl
     else
         timed("image_minmax", [&] { image_minmax(cur, d_rows, res, 0, cap, ws, out); });
     timed("image_map_u8", [&] { image_map_u8(cur, d_rows, res, 0, cap, ws, rotate, d_image, out); });
-}
-
-// ------------------------------------------------------------------ batched front end
-bool aptgpu_plan::enqueue_batch(int count, const Input *ins, float *const *d_rows, const uint64_t *rows_cap_floats)
-{
-    using namespace apt::gpu;
-    if (fused != 1 || fused_f16 || !stream_front || count < 2 || count > max_batch) return false;
-    if (!fused_batch_supported(l, m, static_cast<uint32_t>(taps_resample.size()),
-                               static_cast<uint32_t>(taps_lowpass.size()), pw))
-        return false;
-    const bool pcm16 = ins[0].codec == static_cast<int>(apt::WavCodec::I16);
-    for (int i = 0; i < count; ++i) {
-        const Input &in = ins[i];
-        const bool is_pcm = in.codec == static_cast<int>(apt::WavCodec::I16) && in.channels == 1 &&
-                            (reinterpret_cast<uintptr_t>(in.ptr) & 3u) == 0;
-        if (pcm16 ? !is_pcm : in.codec >= 0) return false;          // one input kind per launch
-        if (work_len_for(in.n) < 10ull * spr) return false;         // error paths stay per recording
-    }
-    if (!h_batch)
-        apt::hip_check(hipHostMalloc(reinterpret_cast<void **>(&h_batch),
-                                     4 * static_cast<size_t>(max_batch) * sizeof(FusedRec), hipHostMallocDefault),
-                       "hipHostMalloc");
-    FusedRec *recs = h_batch + (batch_calls++ % 4) * static_cast<size_t>(max_batch);
-    std::vector<int> slot(static_cast<size_t>(count));
-    uint64_t max_w = 0;
-    const bool want_sync = sync && work_is_multiple;
-    for (int i = 0; i < count; ++i) {
-        slot[static_cast<size_t>(i)] = static_cast<int>(seq++ % slots.size());
-        last_slots[static_cast<size_t>(i)] = slot[static_cast<size_t>(i)];
-        Slot &sl = slots[static_cast<size_t>(slot[static_cast<size_t>(i)])];
-        // the launch overwrites this slot: its previous chain must be over
-        if (sl.ev_free_recorded) apt::hip_check(hipStreamWaitEvent(stream_front, sl.ev_free, 0), "hipStreamWaitEvent");
-        const uint64_t w = work_len_for(ins[i].n);
-        max_w = std::max(max_w, w);
-        recs[i] = FusedRec{ins[i].ptr, ins[i].n, sl.filtered.ptr, want_sync ? sl.correlation.ptr : nullptr,
-                           want_sync ? sl.gm.ptr : nullptr, w, w - n_sync_taps};
-    }
-    if (user_stream) apt::hip_check(hipStreamWaitEvent(stream_front, ev_user, 0), "hipStreamWaitEvent");
-    apt::hip_check(hipMemcpyAsync(d_batch.ptr, recs, static_cast<size_t>(count) * sizeof(FusedRec),
-                                  hipMemcpyHostToDevice, stream_front),
-                   "hipMemcpyAsync batch records");
-    timer.begin(stream_front, "fused_front_end", true);
-    const bool ok = fused_front_end_batch(stream_front, l, m, static_cast<uint32_t>(taps_resample.size()),
-                                          static_cast<uint32_t>(taps_lowpass.size()), pw, pcm16, d_batch.ptr, count,
-                                          max_w, d_taps_branch.ptr, d_taps_lowpass.ptr, d_taps_lowpass_pairs.ptr,
-                                          cosphi2, sinphi, inv_sinphi, fused_f16 ? f16_unscale : 0.f);
-    timer.end(stream_front);
-    if (!ok) throw apt::Error{apt::ErrorKind::Internal, "batched front end: no kernel for this geometry"};
-    apt::hip_check(hipEventRecord(ev_front, stream_front), "hipEventRecord");
-    for (int i = 0; i < count; ++i) {
-        const int sidx = slot[static_cast<size_t>(i)];
-        hipStream_t cur = streams[static_cast<size_t>(sidx) % streams.size()];
-        apt::hip_check(hipStreamWaitEvent(cur, ev_front, 0), "hipStreamWaitEvent");
-        enqueue(i, ins[i], d_rows[i], rows_cap_floats[i], false, sidx, true);
-    }
-    return true;
+    apt::hip_check(hipGetLastError(), "kernel launch (image stage)");
 }

@@ -83,27 +83,19 @@ private:
 struct aptgpu_plan {
     int device = 0;
     int mode = APTGPU_MODE_STRICT;
-    // Software pipeline over consecutive recordings: a recording's whole chain (front end ->
-    // picker -> gather) runs in order on ONE of `depth` streams, recordings go round-robin over
-    // them (slot k -> stream k % depth).  The front end of recording i+1 therefore overlaps the
-    // latency-bound picker/gather of recording i without any cross-stream events, and a slot
-    // is only ever reused by a later recording on its own stream (in-order => no hazards).
+    // Pipeline over consecutive calls: the recordings of ONE decode_device call go through ONE launch
+    // per stage (front end -> k_sync_nodes -> k_sync_orbit -> k_gather_rows; blockIdx.y / .x picks
+    // the recording, per-recording arguments travel by value in the kernel arguments), in order on
+    // one of `depth` streams; consecutive calls go round-robin over the streams, so the front end
+    // of call j+1 overlaps the latency-bound picker of call j.  Stream k owns the workspace slots
+    // [k*max_batch, (k+1)*max_batch): a slot is only ever reused by a later call on its own stream
+    // (in-order => no hazards, no cross-stream events, nothing for the host to wait on).
     std::vector<hipStream_t> streams;
-    // Batched calls (count >= 2, specialised fused kernel): ONE front-end launch over all
-    // recordings on `stream_front`, then every recording's picker/gather chain on its slot's
-    // stream.  Slot hand-over between the two uses one event per slot (recorded when a chain
-    // ends; the batched launch waits for the slots it is about to overwrite) and one event per
-    // call (chains wait for the front end).  Plans with max_batch >= 2 own 2*max_batch slots so
-    // that the front end of call j+1 overlaps the chains of call j.
-    hipStream_t stream_front = nullptr;
-    hipEvent_t ev_front = nullptr;
-    apt::DeviceBuffer<apt::gpu::FusedRec> d_batch;
-    apt::gpu::FusedRec *h_batch = nullptr;  // pinned ring: 4 calls x max_batch records
-    uint64_t batch_calls = 0;
-    hipStream_t stream = nullptr;       // = streams[0] (host-API helpers, timing collection)
+    hipStream_t stream = nullptr;       // = streams[0] (host-API helpers, plan-creation uploads)
     hipStream_t user_stream = nullptr;  // ctx.stream: inputs are ordered after it (may be null)
     hipEvent_t ev_user = nullptr;
-    uint64_t seq = 0;               // recordings enqueued so far (slot = seq % slots.size())
+    uint64_t calls = 0;             // calls enqueued so far (stream = calls % depth)
+    int last_stream = 0;            // stream index of the most recent call
     std::vector<int> last_slots;    // slot of recording i of the most recent decode_device call
 
     aptgpu_settings settings{};
@@ -127,40 +119,39 @@ struct aptgpu_plan {
     uint64_t max_work_len = 0;
     uint32_t max_rows = 0;
     int max_batch = 1;
-    float inv_sinphi = 0.f;  // RN(1/sinphi) if the fast exact divide verified for it, else 0 (apt_envelope.hpp)
-    bool fused_f16 = false;  // APTGPU_MODE_FP16_TAPS served by the specialised fused kernel (fp16 stage 1)
+    // strict: RN(1/sinphi) if the exactly rounded fast divide verified for it, else 0 (apt_envelope.hpp);
+    // fast mode: RN(1/sinphi)
+    float inv_sinphi = 0.f;
+    bool fused_f16 = false;   // APTGPU_MODE_FP16_TAPS served by the specialised fused kernel (fp16 stage 1)
+    bool fused_fast = false;  // APTGPU_MODE_FAST served by the specialised fused kernel
     int fused = 0;  // 0 unfused generic kernels, 1 compile-time specialised k_fused, 2 run-time k_fused_any
-    // the front end is launched as this many consecutive tile ranges: each kernel boundary lets
-    // the previous recording's single-workgroup orbit kernel (147 KB of LDS) grab a CU
-    int picker_force = 0;  // 0 global-memory picker; APTGPU_FORCE_WALK=1 -> 1; APTGPU_PICKER_LDS=1 -> 4
-  // APTGPU_FORCE_WALK=1: exercise the picker's fallback path
+    int picker_force = 0;  // 0 parallel picker; APTGPU_FORCE_WALK=1 -> 1 (the sequential fallback)
 
     apt::DeviceBuffer<float> d_taps_resample, d_taps_lowpass, d_one, d_taps_branch, d_taps_lowpass_pairs, d_taps_any;
     apt::DeviceBuffer<uint16_t> d_taps_f16;  // APTGPU_MODE_FP16_TAPS
     float f16_unscale = 1.f;
     struct Slot {
-        apt::DeviceBuffer<float> resampled, demodulated, filtered, correlation;
+        apt::DeviceBuffer<float> resampled, demodulated, filtered;
+        apt::DeviceBuffer<float> correlation;  // unfused kernels / step export only (the fused front ends never write it)
         apt::DeviceBuffer<uint64_t> bits;     // 64-bit terminal words (generic-mode picker)
         apt::DeviceBuffer<uint32_t> peaks;
-        apt::DeviceBuffer<float> gm;          // per-group maxima of the correlation
+        apt::DeviceBuffer<apt::gpu::GroupMax> gm;  // per-group maxima of the correlation
         apt::DeviceBuffer<uint64_t> words;    // 52-bit terminal words
         apt::DeviceBuffer<uint32_t> slot_nt, slot_cnt, flags, orbit_ws;
-        hipEvent_t ev_free = nullptr;      // batch-capable plans: the chain using this slot has finished
-        bool ev_free_recorded = false;
         apt::DeviceBuffer<char> image_ws;  // scratch of the image stage, allocated on first use
         apt::DeviceBuffer<float> ingest;   // WAV -> f32 staging when the fused PCM16 path does not apply
     };
     std::vector<Slot> slots;
+    apt::DeviceBuffer<apt::gpu::SlotPtrs> d_slots;  // the slots' pointers, for the per-call launches
+    apt::DeviceBuffer<apt::gpu::FusedParams> d_fused_params;  // parameters of the specialised front end
+    void upload_slot_table();                       // (re)writes d_slots + d_fused_params; synchronises plan->stream
     apt::DeviceBuffer<apt::gpu::Result> d_results;
     apt::DeviceBuffer<apt::gpu::ImageResult> d_image_results;  // one per slot, on first use
     // image stage (contrast limits -> u8, telemetry) of recording i of the last call, enqueued
     // behind its decode on the same stream
     void enqueue_image(int i, const float *d_rows, uint64_t rows_cap_floats, int contrast, float percent,
                        bool rotate, uint8_t *d_image);
-    hipStream_t stream_of(int i)
-    {
-        return streams[static_cast<size_t>(last_slots[static_cast<size_t>(i)]) % streams.size()];
-    }
+    hipStream_t stream_of(int) { return streams[static_cast<size_t>(last_stream)]; }
 
     apt::KernelTimer timer;
 
@@ -168,8 +159,6 @@ struct aptgpu_plan {
     uint64_t work_len_for(uint64_t n) const;
     uint64_t out_len_nosync(uint64_t work_len) const;
 
-    // enqueue the whole decode() of one device-resident recording (recording `i` of the
-    // current call) into the next pipeline slot; returns the slot used
     // what a recording looks like in HBM: the f32 Signal (codec < 0), or the payload of a WAV
     // data chunk (codec = apt::WavCodec) that is converted on the device — inside the fused
     // front end for mono PCM16, through the slot's staging buffer otherwise
@@ -179,21 +168,12 @@ struct aptgpu_plan {
         uint32_t channels = 1, bytes_per_sample = 4;
         int codec = -1;
     };
-    int enqueue(int i, const Input &in, float *d_rows, uint64_t rows_cap_floats, bool keep_steps,
-                int forced_slot = -1, bool front_done = false);
-    // one front-end launch for all `count` recordings; false when the call has to go recording by
-    // recording (no specialised kernel, mixed input kinds, a recording that must report an error)
-    bool enqueue_batch(int count, const Input *ins, float *const *d_rows, const uint64_t *rows_cap_floats);
-    int enqueue(int i, const float *d_signal, uint64_t n, float *d_rows, uint64_t rows_cap_floats,
-                bool keep_steps)
-    {
-        Input in;
-        in.ptr = d_signal;
-        in.n = n;
-        return enqueue(i, in, d_rows, rows_cap_floats, keep_steps);
-    }
-    void begin_call(int count);     // orders the front-end stream after ctx.stream
-    void sync_all();                // waits for both internal streams
+    // enqueue the whole decode() of the `count` device-resident recordings of one call (count <=
+    // max_batch) on the next stream; never synchronises with the host.  keep_steps: unfused kernels,
+    // every intermediate stays in the slot (Context::step export).
+    void run_call(int count, const Input *ins, float *const *d_rows, const uint64_t *rows_cap_floats,
+                  bool keep_steps);
+    void sync_all();                // waits for every internal stream
     Slot &slot_of(int i) { return slots[static_cast<size_t>(last_slots[static_cast<size_t>(i)])]; }
     apt::gpu::Result *result_of(int i) { return d_results.ptr + last_slots[static_cast<size_t>(i)]; }
 };
@@ -203,6 +183,6 @@ namespace apt {
 // Builds a plan; throws apt::Error with the reference's messages.
 aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &settings,
                          uint32_t input_rate, bool sync, size_t max_samples, int max_batch,
-                         int depth = 0 /* recordings in flight; 0 = default (6, or APTGPU_STREAMS) */);
+                         int depth = 0 /* calls in flight; 0 = default (APTGPU_STREAMS overrides) */);
 
 }  // namespace apt

@@ -42,6 +42,12 @@ def test_config3_one_hour_96khz(oracle):
     assert np.all(np.diff(ost["sync_pos"].astype(np.int64)) >= 0)
     assert st.n_sync == ost["sync_pos"].size
     assert _same_bits(got, want), "config 3 output differs from the oracle"
+    # the same recording in APTGPU_MODE_FAST, against the tolerance of SURVEY.md §8(d)
+    from test_gpu_fast import check_tolerance, decode_on_plan
+    rows, pos, res, fused = decode_on_plan(x, rate, apt.MODE_FAST)
+    assert fused == 1 and res.status == 0
+    frac, err = check_tolerance(rows, pos, want, ost["sync_pos"], "config 3 fast")
+    print(f"config 3 fast: positions identical {frac:.5f}, max px err {err:.3e} of full scale")
 
 
 def test_config4_one_gpu_share(oracle):
@@ -77,4 +83,18 @@ def test_config4_one_gpu_share(oracle):
         assert res[i].n_sync == ost["sync_pos"].size
         assert _same_bits(d_out[i][:res[i].n_out].cpu().numpy(), want), f"batch item {i} (recording {j})"
         assert plan.sync_positions(i).tolist() == ost["sync_pos"].tolist()
+    plan.close()
+    # the same share in APTGPU_MODE_FAST, against the tolerance of SURVEY.md §8(d)
+    from test_gpu_fast import check_tolerance
+    with torch.cuda.stream(stream):
+        plan = apt.Plan(apt.Settings(), apt.Rate.hz(rate), True, max_samples=n, max_batch=batch,
+                        stream=stream.cuda_stream, mode=apt.MODE_FAST)
+        plan.decode_device([d_in[j].data_ptr() for j in order], [n] * batch,
+                           [t.data_ptr() for t in d_out], [cap] * batch)
+        res = plan.results(batch)
+    for i, j in enumerate(order):
+        want, ost = wants[j]
+        assert res[i].status == 0
+        check_tolerance(d_out[i][:res[i].n_out].cpu().numpy(), plan.sync_positions(i), want, ost["sync_pos"],
+                        f"config 4 fast, item {i}")
     plan.close()

@@ -28,6 +28,18 @@ def assert_bitexact(got, want, what=""):
                              f"{got[bad[0]]!r} vs {want[bad[0]]!r}")
 
 
+def assert_same_values(got, want, what=""):
+    """Bit-exact on every non-NaN element, NaN exactly where the oracle has NaN (the sign and
+    payload of a generated NaN are not part of IEEE arithmetic: x86 and gfx950 differ there)."""
+    got = np.asarray(got, f32)
+    want = np.asarray(want, f32)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    gn, wn = np.isnan(got), np.isnan(want)
+    assert np.array_equal(gn, wn), (what, "NaN positions differ", int(np.flatnonzero(gn != wn)[0]))
+    ok = ~wn
+    assert np.array_equal(_bits(got)[ok], _bits(want)[ok]), what
+
+
 @pytest.fixture(scope="module")
 def ctx():
     assert apt.device_count() >= 1, "no HIP device: the GPU tests must run on the GPU box"
@@ -138,6 +150,74 @@ def test_find_sync_adversarial(ctx, oracle, name, work_rate):
     assert got_pos.tolist() == want_pos.tolist()
 
 
+def _nonfinite_cases():
+    """Float WAVs (wav.rs:41-50) can carry NaN / +-Inf samples; they reach the picker as NaN / Inf
+    correlations.  `corr > last` is false for a NaN on either side (decode.rs:250): a NaN position is
+    never replaced once it is the peak, and never replaces one."""
+    rng = np.random.default_rng(11)
+    n = 60000
+    base = (rng.standard_normal(n) * 50).astype(f32)
+    out = {}
+    v = base.copy()
+    for s0 in (100, 5000, 5003, 17000, 30500, 59990):
+        v[s0:s0 + 30] = np.nan
+    out["nan_bursts"] = v
+    v = base.copy()
+    v[rng.integers(0, n, 40)] = np.nan
+    out["nan_sparse"] = v
+    v = base.copy()
+    idx = rng.integers(0, n, 60)
+    v[idx[:20]] = np.inf
+    v[idx[20:40]] = -np.inf
+    v[idx[40:]] = np.nan
+    out["inf_mix"] = v
+    out["pos_inf_only"] = np.where(rng.random(n) < 0.001, np.inf, base).astype(f32)
+    out["neg_zero"] = np.full(n, -0.0, f32)
+    out["mixed_zero"] = np.where(rng.random(n) < 0.5, -0.0, 0.0).astype(f32)
+    out["all_nan"] = np.full(n, np.nan, f32)
+    v = base.copy()
+    v[:200] = np.nan       # the picker's first window, position 0 included
+    v[-400:] = np.nan      # the last positions
+    out["nan_edges"] = v
+    return out
+
+
+@pytest.mark.parametrize("name", list(_nonfinite_cases().keys()))
+@pytest.mark.parametrize("work_rate", [4160, 12480])
+def test_find_sync_nonfinite(ctx, oracle, name, work_rate, monkeypatch):
+    f = _nonfinite_cases()[name]
+    want_pos, want_corr = oracle.find_sync(f, work_rate, return_correlation=True)
+    got_pos, got_corr = apt.find_sync(ctx, f, apt.Rate.hz(work_rate), return_correlation=True)
+    assert_same_values(got_corr, want_corr, "correlation")
+    assert got_pos.tolist() == want_pos.tolist()
+    # ... and through the reference-shaped picker and the sequential fallback
+    gen = apt.Context(device=0, mode=apt.MODE_GENERIC)
+    assert apt.find_sync(gen, f, apt.Rate.hz(work_rate)).tolist() == want_pos.tolist()
+    monkeypatch.setenv("APTGPU_FORCE_WALK", "1")
+    assert apt.find_sync(apt.Context(device=0), f, apt.Rate.hz(work_rate)).tolist() == want_pos.tolist()
+
+
+@pytest.mark.parametrize("rate,fused_any", [(48000, False), (48000, True), (96000, False), (11025, True)])
+@pytest.mark.parametrize("kind", ["nan", "inf"])
+def test_decode_nonfinite_samples(oracle, monkeypatch, rate, fused_any, kind):
+    """A float Signal with NaN / Inf bursts through the whole decode(): the fused front ends leave
+    NaNs out of the group maxima and flag the group, k_sync_nodes re-evaluates the correlation
+    of the flagged groups, and the rows come out as the reference's — NaNs where it has NaNs."""
+    if fused_any:
+        monkeypatch.setenv("APTGPU_FUSED_ANY", "1")
+    x = synth_apt(rate, 16, seed=61)
+    rng = np.random.default_rng(5)
+    bad = np.nan if kind == "nan" else np.inf
+    for s0 in rng.integers(rate, x.size - rate, 9):
+        x[s0:s0 + int(rng.integers(1, 400))] = bad if rng.random() < 0.7 else -bad
+    x[3] = bad  # inside the very first tile / first group
+    want, st = oracle.decode(x, rate, True, want_steps=True)
+    got, stats = apt.decode(apt.Context(device=0), apt.Settings(), x, apt.Rate.hz(rate), True, return_stats=True)
+    assert stats.n_sync == st["sync_pos"].size
+    assert_same_values(got, want, f"decode with {kind} bursts at {rate} Hz")
+    assert np.isnan(want).any()
+
+
 @pytest.mark.parametrize("name", ["zeros", "noise", "ramp_up", "plateaus", "rising_sine"])
 def test_find_sync_alternate_pickers(oracle, name, monkeypatch):
     """The same answers from the reference-shaped picker (MODE_GENERIC: full sliding-window
@@ -147,9 +227,6 @@ def test_find_sync_alternate_pickers(oracle, name, monkeypatch):
     gen = apt.Context(device=0, mode=apt.MODE_GENERIC)
     assert apt.find_sync(gen, f, apt.Rate.hz(4160)).tolist() == want
     monkeypatch.setenv("APTGPU_FORCE_WALK", "1")
-    assert apt.find_sync(apt.Context(device=0), f, apt.Rate.hz(4160)).tolist() == want
-    monkeypatch.delenv("APTGPU_FORCE_WALK")
-    monkeypatch.setenv("APTGPU_PICKER_LDS", "1")  # the LDS-resident picker (with the global kernel as overflow)
     assert apt.find_sync(apt.Context(device=0), f, apt.Rate.hz(4160)).tolist() == want
 
 
@@ -197,16 +274,13 @@ def test_decode_bitexact(ctx, oracle, rate, seconds, seed, profile, kw, sync):
     assert got.size % 2080 == 0
 
 
-@pytest.mark.parametrize("mode", ["generic", "walk", "lds"])
+@pytest.mark.parametrize("mode", ["generic", "walk"])
 def test_decode_alternate_paths(oracle, mode, monkeypatch):
     """decode() through the unfused generic kernels, and with the picker's fallback walk."""
     x = synth_apt(48000, 14, 2)
     want = oracle.decode(x, 48000, True)
     if mode == "walk":
         monkeypatch.setenv("APTGPU_FORCE_WALK", "1")
-        c = apt.Context(device=0)
-    elif mode == "lds":
-        monkeypatch.setenv("APTGPU_PICKER_LDS", "1")
         c = apt.Context(device=0)
     else:
         c = apt.Context(device=0, mode=apt.MODE_GENERIC)
@@ -263,8 +337,8 @@ def test_runtime_fused_kernel_long_and_ragged(oracle, monkeypatch):
 
 
 def test_decode_long_recordings(ctx, oracle):
-    """Sizes past the LDS picker's capacity (15 min @ 48 kHz, 5 min @ 96 kHz): the
-    global-memory picker has no size limit and stays bit-exact."""
+    """Long recordings (15 min @ 48 kHz, 5 min @ 96 kHz): the picker's tables live in HBM and have
+    no size limit."""
     for rate, seconds, seed in ((48000, 900, 41), (96000, 300, 42)):
         x = synth_apt(rate, seconds, seed)
         want = oracle.decode(x, rate, True)
@@ -363,6 +437,65 @@ def test_steps_export(ctx, oracle):
     assert_bitexact(by["sync_result"][0][1], st["aligned"])
     assert by["resample_filter"][1][1].tolist() == [1.0]
     assert_bitexact(by["resample_decimated"][1][1], want_rows)
+
+
+def test_steps_export_nosync(ctx, oracle):
+    """The no-sync branch exports the same step sequence as the reference: the dummy
+    sync_correlation (decode.rs:139), the cropped signal, then the steps of the final
+    resample_with_filter(NoFilter) (dsp.rs:96-122)."""
+    x = synth_apt(48000, 12, 33)
+    got = []
+    c = apt.Context(step_callback=lambda i, v, d, r: got.append((i, v, d, r)), device=0)
+    rows = apt.decode(c, apt.Settings(export_wav=True), x, apt.Rate.hz(48000), False)
+    want_rows, st = oracle.decode(x, 48000, False, want_steps=True)
+    assert_bitexact(rows, want_rows)
+    ids = [g[0] for g in got]
+    assert ids == ["input", "resample_filter", "resample_filtered", "resample_decimated",
+                   "demodulation_result", "filter_filter", "filter_result", "sync_correlation",
+                   "sync_result", "resample_filter", "filter_filter", "filter_result",
+                   "resample_filtered", "resample_decimated"]
+    by = {}
+    for i, v, d, r in got:
+        by.setdefault(i, []).append((v, d, r))
+    assert by["sync_correlation"][0][1].size == 0 and by["sync_correlation"][0][2] == 12480
+    aligned = st["filtered"][:st["filtered"].size // 6240 * 6240]
+    assert_bitexact(by["sync_result"][0][1], aligned)
+    assert by["resample_filter"][1][1].tolist() == [1.0] and by["filter_filter"][1][1].tolist() == [1.0]
+    # filter([1.]): 0.0 + x*1.0 and sample 0 dropped by the `i > j` guard (dsp.rs:399)
+    fr = aligned.copy()
+    fr[0] = 0.0
+    assert_bitexact(by["filter_result"][1][1], fr)
+    assert_bitexact(by["resample_filtered"][1][1], fr)
+    assert by["resample_filtered"][1][2] == 12480
+    assert_bitexact(by["resample_decimated"][1][1], want_rows)
+    # a work rate that is not a multiple of 4160: the final stage is fast_resampling (l > 1)
+    got.clear()
+    apt.decode(c, apt.Settings(export_wav=True, work_rate=11025), x, apt.Rate.hz(48000), False)
+    ids = [g[0] for g in got]
+    assert ids[-4:] == ["sync_result", "resample_filter", "resample_filtered", "resample_decimated"]
+    assert got[-2][2].size == 0 and got[-2][3] == 11025 * 832  # l2 = 4160 / gcd(11025, 4160) = 832
+
+
+def test_rows_cap_clamps_the_result_record(oracle):
+    """A rows buffer smaller than the recording: the record reports what was written (reason 4)."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    x = synth_apt(48000, 14, 2)
+    want = oracle.decode(x, 48000, True)
+    plan = apt.Plan(apt.Settings(), apt.Rate.hz(48000), True, max_samples=x.size)
+    d_in = torch.from_numpy(x).to(dev)
+    cap = 7
+    d_out = torch.full(((cap + 1) * 2080,), -7.0, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    plan.decode_device([d_in.data_ptr()], [x.size], [d_out.data_ptr()], [cap])
+    res = plan.results(1)[0]
+    assert res.status == 0 and res.reason == 4 and res.n_rows == cap and res.n_out == cap * 2080
+    out = d_out.cpu().numpy()
+    assert_bitexact(out[:cap * 2080], want[:cap * 2080], "clamped rows")
+    assert np.all(out[cap * 2080:] == -7.0)  # nothing written past the caller's capacity
+    plan.close()
+    with pytest.raises(apt.AptError):
+        apt.Plan(apt.Settings(work_rate=1), apt.Rate.hz(48000), False, max_samples=48000)  # spr == 0
 
 
 def test_picker_paths_direct_and_doubling(oracle):

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Pipeline sweep on one GPU: the same synthetic recordings through plans of different mode /
+recordings-per-call / calls-in-flight, one process, inputs generated once.
+
+    python tools/sweep.py --configs strict:1:6,strict:8:3,fast:1:6,fast:8:3 --steps 40
+
+Each config is mode:batch:streams.  Prints one JSON line per config: ms per recording in the
+pipelined loop, Msamples/s, and the per-kernel times with one call in flight at a time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="strict:1:6,fast:1:6")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rate", type=int, default=48000)
+    ap.add_argument("--seconds", type=float, default=600.0)
+    ap.add_argument("--inputs", type=int, default=4)
+    ap.add_argument("--pcm16", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import noaa_apt_amd as apt
+    from noaa_apt_amd.testing.synth import synth_apt
+
+    dev = torch.device("cuda", 0)
+    t0 = time.perf_counter()
+    xs = [synth_apt(args.rate, args.seconds, seed=2 + 1000 * j) for j in range(args.inputs)]
+    n = xs[0].size
+    if args.pcm16:
+        d_xs = [torch.from_numpy(v.astype(np.int16)).to(dev) for v in xs]
+    else:
+        d_xs = [torch.from_numpy(v).to(dev) for v in xs]
+    torch.cuda.synchronize()
+    print(json.dumps({"inputs": args.inputs, "samples": n, "synth_s": round(time.perf_counter() - t0, 1)}), flush=True)
+    modes = {"strict": apt.MODE_STRICT, "fast": apt.MODE_FAST, "fp16taps": apt.MODE_FP16_TAPS,
+             "generic": apt.MODE_GENERIC}
+    spec = apt.WavSpec(1, 16, 2, 0, args.rate, 1, 0, 2 * n, n, n)
+
+    for cfg in args.configs.split(","):
+        mode_s, b_s, st_s = cfg.split(":")
+        B, S = int(b_s), int(st_s)
+        os.environ["APTGPU_STREAMS"] = str(S)
+        plan = apt.Plan(apt.Settings(), apt.Rate.hz(args.rate), True, max_samples=n, max_batch=B, mode=modes[mode_s])
+        cap = int(plan.info.max_rows)
+        # every call in flight needs its own output buffers
+        outs = [[torch.empty(cap * 2080, dtype=torch.float32, device=dev) for _ in range(B)] for _ in range(S)]
+        torch.cuda.synchronize()
+        k = [0]
+
+        def step():
+            j = k[0]
+            k[0] += 1
+            sig = [d_xs[(j * B + b) % args.inputs].data_ptr() for b in range(B)]
+            out = [t.data_ptr() for t in outs[j % S]]
+            if args.pcm16:
+                plan.decode_device_wav(sig, [spec] * B, out, [cap] * B)
+            else:
+                plan.decode_device(sig, [n] * B, out, [cap] * B)
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        t_enq = time.perf_counter()
+        torch.cuda.synchronize()
+        b = time.perf_counter()
+        plan.enable_timing(2)
+        for _ in range(8):
+            step()
+            torch.cuda.synchronize()
+        alone = plan.collect_timing()
+        plan.enable_timing(0)
+        res = plan.results(B)
+        ms_rec = 1e3 * (b - a) / (args.steps * B)
+        print(json.dumps({
+            "config": cfg, "ms_per_recording": round(ms_rec, 5), "Msamples_per_s": round(n / ms_rec / 1e3, 1),
+            "host_enqueue_ms_per_call": round(1e3 * (t_enq - a) / args.steps, 4),
+            "status": [int(r.status) for r in res][:4], "rows": int(res[0].n_rows), "fused": int(plan.info.fused),
+            "alone_ms_per_call": {kk: round(v[0], 5) for kk, v in sorted(alone.items())},
+        }), flush=True)
+        plan.close()
+
+
+if __name__ == "__main__":
+    main()
