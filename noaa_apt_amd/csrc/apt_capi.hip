@@ -617,14 +617,15 @@ int aptgpu_find_sync(const aptgpu_context *ctx, const float *signal, size_t n,
         apt::gpu::correlate(sc.stream, d_f.ptr, n_corr, pw, d_c.ptr);
         if (ctx && ctx->mode == APTGPU_MODE_GENERIC) {
             apt::gpu::terminals(sc.stream, d_c.ptr, n_corr, md, d_bits.ptr);
-            apt::gpu::orbit_walk(sc.stream, d_bits.ptr, n_corr, n, spr, md, d_peaks.ptr, cap, d_res.ptr);
+            apt::gpu::orbit_walk(sc.stream, d_bits.ptr, d_c.ptr, n_corr, n, spr, md, d_peaks.ptr, cap, d_res.ptr);
         } else {
             const uint64_t ng = n_corr / apt::gpu::sync_group_size() + 2;
             const uint64_t chunks = ng / apt::gpu::sync_chunk_groups() + 2;
             apt::DeviceBuffer<apt::gpu::GroupMax> d_gm;
             d_gm.alloc(ng + 64);
-            apt::DeviceBuffer<uint64_t> d_words;
+            apt::DeviceBuffer<uint64_t> d_words, d_nanw;
             d_words.alloc(ng + 64);
+            d_nanw.alloc(ng + 64);
             apt::DeviceBuffer<uint32_t> d_slot, d_cnt, d_flags;
             d_slot.alloc(chunks * apt::gpu::sync_slot_cap());
             d_cnt.alloc(chunks);
@@ -639,6 +640,7 @@ int aptgpu_find_sync(const aptgpu_context *ctx, const float *signal, size_t n,
             sp.gm = d_gm.ptr;
             sp.corr = d_c.ptr;
             sp.words = d_words.ptr;
+            sp.nanw = d_nanw.ptr;
             sp.slot_nt = d_slot.ptr;
             sp.slot_cnt = d_cnt.ptr;
             sp.flags = d_flags.ptr;

@@ -68,6 +68,7 @@ struct SlotPtrs {
     GroupMax *gm;           // per-group correlation maxima
     const float *corr;      // full correlation (unfused path / step export only), else nullptr
     uint64_t *words;        // 52-bit terminal words
+    uint64_t *nanw;         // 52-bit words: positions whose correlation is NaN
     uint32_t *slot_nt, *slot_cnt, *flags, *orbit_ws, *peaks;
     Result *res;
     uint32_t peaks_cap;
@@ -91,12 +92,13 @@ void demodulate(hipStream_t s, const float *x, uint64_t n, float cosphi2, float 
 // the cross-correlation of find_sync, decode.rs:225-233 (pw = work_rate / 4160)
 void correlate(hipStream_t s, const float *f, uint64_t n_corr, uint32_t pw, float *corr);
 // terminal flags of the peak picker: bit i of `bits` set <=> no corr[j] > corr[i] for
-// j in (i, i+md]; corr[0] is clamped to >= 0 (the initial (0, 0.) peak, decode.rs:208).
+// j in (i, i+md]; corr[0] is clamped to >= 0 (the initial (0, 0.) peak, decode.rs:208); NaNs
+// read as -inf (never a record; orbit_walk handles a phase that starts on one).
 // md must be a multiple of 64; needs 2*md*4 bytes of LDS.
 void terminals(hipStream_t s, const float *corr, uint64_t n_corr, uint32_t md, uint64_t *bits);
 // the orbit of the peak picker over the terminal bitmask (one wave): writes the peak list
 // (find_sync's return value) and fills the result record.
-void orbit_walk(hipStream_t s, const uint64_t *bits, uint64_t n_corr, uint64_t work_len,
+void orbit_walk(hipStream_t s, const uint64_t *bits, const float *corr, uint64_t n_corr, uint64_t work_len,
                 uint32_t spr, uint32_t md, uint32_t *peaks, uint32_t peaks_cap, Result *res);
 // row gather (decode.rs:120-134) taking every pw-th sample; raw = plain copy (the
 // "sync_result" step), !raw = through the final NoFilter stage (decode.rs:158-159)

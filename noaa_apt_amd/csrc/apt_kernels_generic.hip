@@ -230,6 +230,9 @@ k_terminals(const float *__restrict__ corr, uint64_t n_corr, uint32_t md,
         if (g < n_corr) {
             v = corr[g];
             if (g == 0 && !(v > 0.f)) v = 0.f;
+            // a NaN is never a record (`corr > last` is false, decode.rs:250): a tracking phase passes
+            // over it as if it held -inf; a phase that STARTS on one keeps it (k_orbit_walk)
+            if (v != v) v = kNegInf;
         }
         lds[i] = v;
     }
@@ -246,6 +249,7 @@ k_terminals(const float *__restrict__ corr, uint64_t n_corr, uint32_t md,
         if (i < md && b0 + i < n_corr) {
             float v = corr[b0 + i];  // the scan overwrote own[]; L2-hot re-read
             if (b0 + i == 0 && !(v > 0.f)) v = 0.f;
+            if (v != v) v = kNegInf;
             // window (i, i+md] = own[i+1 .. md) U nxt[0 .. i]
             const float wmax = fmaxf((i + 1 < md) ? own[i + 1] : kNegInf, nxt[i]);
             term = !(wmax > v);
@@ -287,8 +291,8 @@ __device__ __forceinline__ uint64_t first_terminal(const uint64_t *__restrict__ 
 }
 
 __global__ void __launch_bounds__(64)
-k_orbit_walk(const uint64_t *__restrict__ bits, uint64_t n_corr, uint64_t work_len, uint32_t spr,
-             uint32_t md, uint32_t *__restrict__ peaks, uint32_t peaks_cap,
+k_orbit_walk(const uint64_t *__restrict__ bits, const float *__restrict__ corr, uint64_t n_corr,
+             uint64_t work_len, uint32_t spr, uint32_t md, uint32_t *__restrict__ peaks, uint32_t peaks_cap,
              Result *__restrict__ res)
 {
     const int lane = threadIdx.x & 63;
@@ -311,7 +315,9 @@ k_orbit_walk(const uint64_t *__restrict__ bits, uint64_t n_corr, uint64_t work_l
         for (uint64_t q = len + lane; q + 1 < c; q += 64)
             if (q < peaks_cap) peaks[q] = static_cast<uint32_t>(s);
         if (s + spr < work_len) fit += c - len - 1;
-        u = first_terminal(bits, n_words, s);
+        // a phase that starts on a NaN keeps it: nothing is ever `>` a NaN peak (decode.rs:250)
+        const float cs = corr[s];
+        u = (cs != cs) ? s : first_terminal(bits, n_words, s);
         if (lane == 0 && c - 1 < peaks_cap) peaks[c - 1] = static_cast<uint32_t>(u);
         last_fit = (u + spr < work_len) ? 1 : 0;
         fit += last_fit;
@@ -473,10 +479,10 @@ void terminals(hipStream_t s, const float *corr, uint64_t n_corr, uint32_t md, u
                        bits);
 }
 
-void orbit_walk(hipStream_t s, const uint64_t *bits, uint64_t n_corr, uint64_t work_len,
+void orbit_walk(hipStream_t s, const uint64_t *bits, const float *corr, uint64_t n_corr, uint64_t work_len,
                 uint32_t spr, uint32_t md, uint32_t *peaks, uint32_t peaks_cap, Result *res)
 {
-    hipLaunchKernelGGL(k_orbit_walk, dim3(1), dim3(64), 0, s, bits, n_corr, work_len, spr, md,
+    hipLaunchKernelGGL(k_orbit_walk, dim3(1), dim3(64), 0, s, bits, corr, n_corr, work_len, spr, md,
                        peaks, peaks_cap, res);
 }
 

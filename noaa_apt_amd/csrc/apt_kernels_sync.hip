@@ -20,6 +20,14 @@
 //      a run of terminals.  So only NODE TERMINALS matter: heads, terminals t with t-md-1
 //      terminal, and terminals on the grid — a few per image row.
 //
+// NaN correlations (float WAVs can carry NaN / Inf samples): `corr > last` is false with a NaN on
+// either side (decode.rs:250).  A NaN position is therefore never a record — a tracking phase
+// passes over it as if it held -inf — and, once it IS the peak (which only happens when a phase
+// STARTS on it), it is never replaced.  So: terminals are computed with NaN read as -inf, and
+// firstT(s) = s when corr[s] is NaN (s > 0; the root's peak is (0, 0.) whatever corr[0] is).  NaN
+// positions that can be starts (on the grid, or md+1 behind a terminal or another NaN) travel in
+// the node-terminal lists with bit 31 set: such an entry only matches a search that starts on it.
+//
 // Kernels (GS = 52 correlation positions per group; md = 32*pw groups, spr = 40*pw groups):
 //   k_group_max   corr -> GM (unfused path only; the fused front end emits GM itself)
 //   k_sync_nodes  coarse: a group can hold a terminal only if GM[g] is not exceeded by the
@@ -74,6 +82,8 @@ constexpr int kNodesThreads = 128;
 constexpr int kNodesWaves = kNodesThreads / 64;
 constexpr int kChunkGroups = 128;  // own groups per workgroup
 constexpr int kSlotCap = 64;       // node terminals kept per chunk before "overflow"
+constexpr uint32_t kNanStartTag = 0x80000000u;  // slot entry = NaN position: only matches a search starting on it
+constexpr uint32_t kPosMask = 0x7FFFFFFFu;      // (positions are < 2^31: longer recordings take the walk)
 
 // floats of LDS one wave needs to re-evaluate the correlation of one candidate: two F windows
 // (the candidate group and the group md ahead) of GS + 38*pw - 1 samples each
@@ -81,11 +91,15 @@ __host__ __device__ constexpr uint32_t nodes_window(uint32_t pw) { return (GS + 
 
 // NL: 64-lane loads per F window kept in registers while a wave has four candidates in flight
 // (window <= 64*NL samples); 0: any window, one candidate at a time straight into LDS.
-template <int NL>
+// PWC: the pixel width at compile time (the stock profiles: 3, 4, 5) — the 114..190-term correlation
+// chains then unroll and their LDS reads pipeline (run-time loops wait for every read: 8x slower);
+// 0: run-time pw.
+template <int NL, int PWC>
 __global__ void __launch_bounds__(kNodesThreads, 4)  // <= 128 VGPRs: must fit beside the front end's waves
-k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t pw,
+k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t pw_arg,
              uint32_t r_groups /* md/GS */, uint32_t grid_groups /* spr/GS */, int fast, int use_corr)
 {
+    const uint32_t pw = PWC > 0 ? static_cast<uint32_t>(PWC) : pw_arg;
     const RecArgs rec = call.rec[blockIdx.y];
     const uint64_t w = rec.w;
     const uint64_t n_corr = w - 38ull * pw;
@@ -96,6 +110,7 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
     const float *__restrict__ corr = use_corr ? sp.corr : nullptr;  // nullptr: re-evaluate from F
     const float *__restrict__ fsig = sp.f;
     uint64_t *__restrict__ words_out = sp.words;
+    uint64_t *__restrict__ nanw_out = sp.nanw;
     uint32_t *__restrict__ slot_nt = sp.slot_nt;
     uint32_t *__restrict__ slot_cnt = sp.slot_cnt;
     uint32_t *__restrict__ flags = sp.flags;
@@ -111,9 +126,12 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
     uint16_t *s_cand = reinterpret_cast<uint16_t *>(s_wm + (kChunkGroups + R + 1));  // [CG + R + 1]
     uint8_t *s_nan = reinterpret_cast<uint8_t *>(s_cand + (kChunkGroups + R + 1));   // [CG + R + 1]
     const uint32_t wlen = nodes_window(pw);
-    // per wave: two F windows (16-byte aligned; plain pointer arithmetic keeps these LDS accesses)
-    const uint32_t win_ofs = (static_cast<uint32_t>(kChunkGroups + R + 1) * 15u +
-                              static_cast<uint32_t>(kChunkGroups + 2 * R + 2) * 4u + 15u) & ~15u;
+    // NaN bits of the groups of the window, then per wave two F windows (16-byte aligned; plain
+    // pointer arithmetic keeps these LDS accesses)
+    const uint32_t nanw_ofs = (static_cast<uint32_t>(kChunkGroups + R + 1) * 15u +
+                               static_cast<uint32_t>(kChunkGroups + 2 * R + 2) * 4u + 15u) & ~15u;
+    uint64_t *s_nanw = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(lds_nodes) + nanw_ofs);  // [CG + R + 1]
+    const uint32_t win_ofs = (nanw_ofs + static_cast<uint32_t>(kChunkGroups + R + 1) * 8u + 15u) & ~15u;
     float *s_win = reinterpret_cast<float *>(reinterpret_cast<char *>(lds_nodes) + win_ofs);
     __shared__ uint32_t s_ncand;
     __shared__ uint32_t s_scan[kNodesWaves];
@@ -157,8 +175,9 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
         const float wm = fmaxf(fmaxf(w0, w1), fmaxf(w2, w3));
         s_wm[q] = wm;
         s_words[q] = 0ull;
+        s_nanw[q] = 0ull;
         const bool valid = g >= 0 && g < static_cast<int64_t>(ng);
-        // a group whose finite maximum is exceeded can still hold a terminal: a NaN position
+        // a group that holds a NaN is evaluated too: its NaN positions may be starts (see the top)
         if (valid && (!(wm > s_gm[q]) || s_nan[q])) s_cand[atomicAdd(&s_ncand, 1u)] = static_cast<uint16_t>(q);
     }
     __syncthreads();
@@ -279,7 +298,11 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
                 }
             }
             if (inv[e] && gw0 + qv[e] == 0 && lane == 0 && !(cv[e] > 0.f)) cv[e] = 0.f;  // the peak (0, 0.)
-            // suffix max over lanes > lane (rest of this group); fmaxf drops NaNs: a NaN never exceeds
+            // NaN: remembered for the start test, -inf for every comparison
+            const unsigned long long nanword = __ballot(inv[e] && cv[e] != cv[e]) & kGroupMask;
+            if (cv[e] != cv[e]) cv[e] = kNegInf;
+            if (c2v[e] != c2v[e]) c2v[e] = kNegInf;
+            // suffix max over lanes > lane (rest of this group)
             float sfx = cv[e];
             for (int d = 1; d < 64; d <<= 1) {
                 const float o = __shfl_down(sfx, d, 64);
@@ -294,10 +317,12 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
                 if (lane >= d) pfx = fmaxf(pfx, o);
             }
             const float wmax = fmaxf(fmaxf(sfx_ex, s_wm[qv[e]]), pfx);
-            // (a NaN position is a terminal: `wmax > NaN` is false, as `corr > last` is in decode.rs:250)
             const bool term = inv[e] && !(wmax > cv[e]);
             const unsigned long long word = __ballot(term) & kGroupMask;
-            if (lane == 0) s_words[qv[e]] = word;
+            if (lane == 0) {
+                s_words[qv[e]] = word;
+                s_nanw[qv[e]] = nanword;
+            }
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -307,18 +332,24 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
     // terminals on the grid
     const int q = tid + R + 1;  // own group index inside the window
     const int64_t g = g0 + tid;
-    uint64_t nw = 0;
+    uint64_t nw = 0, ns = 0;
     if (g < static_cast<int64_t>(ng)) {
         const uint64_t wd = s_words[q];
+        const uint64_t nb = s_nanw[q];
         const uint64_t prev_bit = s_words[q - 1] >> (GS - 1);
         const uint64_t heads = wd & ~(((wd << 1) | prev_bit) & kGroupMask);
+        // positions md+1 behind a terminal or behind a NaN position, and the grid: where a phase can start
         const uint64_t shifted = ((s_words[q - R] << 1) | (s_words[q - R - 1] >> (GS - 1))) & kGroupMask;
+        const uint64_t shifted_nan = ((s_nanw[q - R] << 1) | (s_nanw[q - R - 1] >> (GS - 1))) & kGroupMask;
         const uint64_t on_grid = (g % grid_groups == 0) ? 1ull : 0ull;
-        nw = wd & (heads | shifted | on_grid);
+        const uint64_t starts = shifted | shifted_nan | on_grid;
+        nw = wd & (heads | starts);
+        ns = nb & starts & ~wd;  // NaN positions a phase can start on (position 0 was clamped: never NaN)
         words_out[g] = wd;
+        nanw_out[g] = nb;
     }
-    // ordered compaction of the node-terminal positions of this chunk
-    const uint32_t cnt = static_cast<uint32_t>(__popcll(nw));
+    // ordered compaction of the node-terminal positions of this chunk (NaN starts tagged with bit 31)
+    const uint32_t cnt = static_cast<uint32_t>(__popcll(nw | ns));
     uint32_t inc = cnt;
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t o = __shfl_up(inc, d, 64);
@@ -331,13 +362,13 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
     uint32_t total = 0;
     for (int wv = 0; wv < kNodesWaves; ++wv) total += s_scan[wv];
     uint32_t ofs = base + inc - cnt;
-    uint64_t bitsleft = nw;
+    uint64_t bitsleft = nw | ns;
     while (bitsleft) {
         const int bpos = __ffsll(static_cast<long long>(bitsleft)) - 1;
         bitsleft &= bitsleft - 1;
         if (ofs < kSlotCap)
             slot_nt[static_cast<uint64_t>(blockIdx.x) * kSlotCap + ofs] =
-                static_cast<uint32_t>(static_cast<uint64_t>(g) * GS + bpos);
+                static_cast<uint32_t>(static_cast<uint64_t>(g) * GS + bpos) | (((ns >> bpos) & 1ull) ? kNanStartTag : 0u);
         ++ofs;
     }
     if (tid == 0) {
@@ -380,10 +411,12 @@ __device__ __forceinline__ uint64_t first_terminal52(const uint64_t *__restrict_
 }
 
 // sequential orbit over the terminal words, one wave (any input, any size)
-__device__ void orbit_walk52(const uint64_t *__restrict__ words, const OrbitGeom &gq,
-                             uint32_t *__restrict__ peaks, uint32_t peaks_cap,
+__device__ void orbit_walk52(const uint64_t *__restrict__ words, const uint64_t *__restrict__ nanw,
+                             const OrbitGeom &gq, uint32_t *__restrict__ peaks, uint32_t peaks_cap,
                              Result *__restrict__ res)
 {
+    // a phase that starts on a NaN position keeps it (see the top of the file)
+    auto nan_at = [&](uint64_t s) -> bool { return (nanw[s / GS] >> (s % GS)) & 1ull; };
     const int lane = threadIdx.x & 63;
     const uint64_t n_groups = (gq.n_corr + GS - 1) / GS;
     const uint64_t spr = gq.spr, md = gq.md;
@@ -402,7 +435,7 @@ __device__ void orbit_walk52(const uint64_t *__restrict__ words, const OrbitGeom
         for (uint64_t q = len + lane; q + 1 < c; q += 64)
             if (q < peaks_cap) peaks[q] = static_cast<uint32_t>(s);
         if (s + spr < gq.work_len) fit += c - len - 1;
-        u = first_terminal52(words, n_groups, s);
+        u = nan_at(s) ? s : first_terminal52(words, n_groups, s);
         if (lane == 0 && c - 1 < peaks_cap) peaks[c - 1] = static_cast<uint32_t>(u);
         last_fit = (u + spr < gq.work_len) ? 1 : 0;
         fit += last_fit;
@@ -519,8 +552,13 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
                     const uint32_t k0 = 4 * (j + e);
                     const uint32_t vals[4] = {v[e].x, v[e].y, v[e].z, v[e].w};
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (k0 + t < lim && vals[t] >= sv) { *uval = vals[t]; return ch * kSlotCap + k0 + t; }
+                    for (int t = 0; t < 4; ++t) {
+                        const uint32_t pos = vals[t] & kPosMask;  // a tagged entry only matches its own position
+                        if (k0 + t < lim && pos >= sv && (!(vals[t] & kNanStartTag) || pos == sv)) {
+                            *uval = pos;
+                            return ch * kSlotCap + k0 + t;
+                        }
+                    }
                 }
             }
         }
@@ -530,7 +568,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
     auto node_start = [&](uint32_t v, uint32_t *cell) -> uint32_t {
         if (v == 0) { *cell = 1; return 0; }
         if (v < base_d) { *cell = v + 1; return (v + 1) * spr; }
-        const uint32_t sv = slot_nt[v - base_d] + md + 1;
+        const uint32_t sv = (slot_nt[v - base_d] & kPosMask) + md + 1;
         *cell = div_spr(sv);
         return sv;
     };
@@ -594,7 +632,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
     stamp(0);  // reachable set closed
 
     if (walk) {
-        if (wave == 0) orbit_walk52(words, gq, peaks, peaks_cap, res);
+        if (wave == 0) orbit_walk52(words, sp.nanw, gq, peaks, peaks_cap, res);
         if (tid == 0) {
             flags[1] = 1u;  // report which path ran
             flags[0] = 0u;  // re-arm the overflow flag for the next decode
@@ -719,20 +757,21 @@ void sync_nodes(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, ui
     const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
     const uint32_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
     const uint32_t r = md / GS;
-    const size_t lds = static_cast<size_t>(kChunkGroups + r + 1) * (8 + 4 + 2 + 1) +
-                       static_cast<size_t>(kChunkGroups + 2 * r + 2) * 4 + 32 +
+    const size_t lds = static_cast<size_t>(kChunkGroups + r + 1) * (8 + 4 + 2 + 1 + 8) +
+                       static_cast<size_t>(kChunkGroups + 2 * r + 2) * 4 + 48 +
                        static_cast<size_t>(kNodesWaves) * 2 * nodes_window(pw) * sizeof(float);
     const dim3 grid(chunks, call.count);
     const uint32_t wneed = GS + 38u * pw - 1u;
-    if (wneed <= 192)
-        hipLaunchKernelGGL(k_sync_nodes<3>, grid, dim3(kNodesThreads), lds, s, call, d_slots, pw, r, spr / GS,
-                           fast ? 1 : 0, use_corr ? 1 : 0);
-    else if (wneed <= 256)
-        hipLaunchKernelGGL(k_sync_nodes<4>, grid, dim3(kNodesThreads), lds, s, call, d_slots, pw, r, spr / GS,
-                           fast ? 1 : 0, use_corr ? 1 : 0);
-    else
-        hipLaunchKernelGGL(k_sync_nodes<0>, grid, dim3(kNodesThreads), lds, s, call, d_slots, pw, r, spr / GS,
-                           fast ? 1 : 0, use_corr ? 1 : 0);
+#define APT_NODES_LAUNCH(NL, PWC)                                                                              \
+    hipLaunchKernelGGL((k_sync_nodes<NL, PWC>), grid, dim3(kNodesThreads), lds, s, call, d_slots, pw, r, spr / GS, \
+                       fast ? 1 : 0, use_corr ? 1 : 0)
+    if (pw == 3) APT_NODES_LAUNCH(3, 3);        // standard profile
+    else if (pw == 4) APT_NODES_LAUNCH(4, 4);   // fast profile
+    else if (pw == 5) APT_NODES_LAUNCH(4, 5);   // slow profile
+    else if (wneed <= 192) APT_NODES_LAUNCH(3, 0);
+    else if (wneed <= 256) APT_NODES_LAUNCH(4, 0);
+    else APT_NODES_LAUNCH(0, 0);
+#undef APT_NODES_LAUNCH
 }
 
 // node-terminal capacity and uint32 words of scratch k_sync_orbit needs for a work signal of w samples

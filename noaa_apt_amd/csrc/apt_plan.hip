@@ -287,6 +287,7 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
             const uint64_t chunks = ng / gpu::sync_chunk_groups() + 2;
             sl.gm.alloc(ng + 64);
             sl.words.alloc(ng + 64);
+            sl.nanw.alloc(ng + 64);
             sl.slot_nt.alloc(chunks * gpu::sync_slot_cap());
             sl.slot_cnt.alloc(chunks);
             sl.orbit_ws.alloc(gpu::sync_orbit_ws_words(w, plan->spr));
@@ -319,6 +320,7 @@ void aptgpu_plan::upload_slot_table()
         t.gm = sl.gm.ptr;
         t.corr = sl.correlation.ptr;
         t.words = sl.words.ptr;
+        t.nanw = sl.nanw.ptr;
         t.slot_nt = sl.slot_nt.ptr;
         t.slot_cnt = sl.slot_cnt.ptr;
         t.flags = sl.flags.ptr;
@@ -558,7 +560,8 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
                 const uint64_t n_corr = w - n_sync_taps;
                 timed("terminals", [&] { terminals(cur, sl.correlation.ptr, n_corr, md, sl.bits.ptr); });
                 timed("orbit_walk", [&] {
-                    orbit_walk(cur, sl.bits.ptr, n_corr, w, spr, md, sl.peaks.ptr, static_cast<uint32_t>(sl.peaks.count),
+                    orbit_walk(cur, sl.bits.ptr, sl.correlation.ptr, n_corr, w, spr, md, sl.peaks.ptr,
+                               static_cast<uint32_t>(sl.peaks.count),
                                d_results.ptr + slot0 + i);
                 });
             }

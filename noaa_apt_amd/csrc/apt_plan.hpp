@@ -137,6 +137,7 @@ struct aptgpu_plan {
         apt::DeviceBuffer<uint32_t> peaks;
         apt::DeviceBuffer<apt::gpu::GroupMax> gm;  // per-group maxima of the correlation
         apt::DeviceBuffer<uint64_t> words;    // 52-bit terminal words
+        apt::DeviceBuffer<uint64_t> nanw;     // 52-bit words of NaN correlation positions
         apt::DeviceBuffer<uint32_t> slot_nt, slot_cnt, flags, orbit_ws;
         apt::DeviceBuffer<char> image_ws;  // scratch of the image stage, allocated on first use
         apt::DeviceBuffer<float> ingest;   // WAV -> f32 staging when the fused PCM16 path does not apply

@@ -33,14 +33,20 @@ template <typename At>
 __device__ __forceinline__ float sync_corr_strict(uint32_t pw, At &&at)
 {
 #pragma clang fp contract(off)
+    // (with a compile-time pw the loops unroll completely and the reads pipeline; run-time pw loops)
     const uint32_t pulse = 2 * pw;
     float c = 0.f;
     uint32_t j = 0;
+#pragma unroll
     for (uint32_t e = 0; e < pulse; ++e, ++j) c = c - at(j);
+#pragma unroll
     for (int rep = 0; rep < 7; ++rep) {
+#pragma unroll
         for (uint32_t e = 0; e < pulse; ++e, ++j) c = c - at(j);
+#pragma unroll
         for (uint32_t e = 0; e < pulse; ++e, ++j) c = c + at(j);
     }
+#pragma unroll
     for (uint32_t e = 0; e < 8 * pw; ++e, ++j) c = c - at(j);
     return c;
 }
@@ -51,6 +57,7 @@ __device__ __forceinline__ float sync_pulse_sum(uint32_t pw, At &&at)
 {
 #pragma clang fp contract(off)
     float b = at(0) + at(1);
+#pragma unroll
     for (uint32_t e = 1; e < pw; ++e) b = b + (at(2 * e) + at(2 * e + 1));
     return b;
 }
