@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 #pragma clang fp contract(off)
@@ -145,8 +146,23 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
     if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
         if (mode == kModeF16Taps)  // fp16-tap stage 1: hb is the half2 table of fused_f16_branch_taps
             pcm16 ? fused_launch_48k_f16taps_i16(a) : fused_launch_48k_f16taps_f32(a);
-        else if (mode == kModeFast)
-            pcm16 ? fused_launch_48k_fast_i16(a) : fused_launch_48k_fast_f32(a);
+        else if (mode == kModeFast) {
+#ifdef APT_WITH_PROBES
+            static const int probe = [] {
+                const char *e = std::getenv("APTGPU_PROBE_STOP");
+                return e ? std::atoi(e) : 0;
+            }();
+            if (!pcm16 && probe >= 1 && probe <= 7) {
+                void (*const fn[7])(const FusedLaunch &) = {fused_launch_probe1, fused_launch_probe2, fused_launch_probe3,
+                                                            fused_launch_probe4, fused_launch_probe5, fused_launch_probe6,
+                                                            fused_launch_probe7};
+                fn[probe - 1](a);
+            } else
+#endif
+            {
+                pcm16 ? fused_launch_48k_fast_i16(a) : fused_launch_48k_fast_f32(a);
+            }
+        }
         else
             pcm16 ? fused_launch_48k_i16(a) : fused_launch_48k_f32(a);
         return true;

@@ -21,6 +21,11 @@ namespace apt::gpu {
 namespace {
 
 
+// Probe builds (apt_kernels_fused_probe*.hip, timing experiments only): the kernel stops after stage
+// APT_FUSED_STOP — 1 tile in LDS, 2 resampler, 3 envelope, 4 low-pass, 5 F stored; 0 = the real kernel.
+#ifndef APT_FUSED_STOP
+#define APT_FUSED_STOP 0
+#endif
 #ifndef APT_FUSED_MIN_WAVES
 #define APT_FUSED_MIN_WAVES 3
 #endif
@@ -127,16 +132,25 @@ __host__ __device__ constexpr bool sync_plus(int j)
 //                native v_sqrt_f32 and a multiplication by 1/sin(phi), and the +-1 correlation is
 //                evaluated from pulse sums (apt_sync_corr.hpp): ~1/3 of the strict VALU
 //                instructions.  Tolerance-based; deterministic.
-// One launch covers the `count` recordings of a call: blockIdx.y picks the recording, whose
-// tiles are blockIdx.x < ceil(w / OWN_K); the per-recording arguments travel by value in the
-// kernel-argument segment, the workspace pointers come from the plan's slot table.
+// One launch covers the `count` recordings of a call; the per-recording arguments travel by value
+// in the kernel-argument segment, the workspace pointers come from the plan's slot table.
+// One workgroup per tile: blockIdx.y picks the recording, whose tiles are blockIdx.x < ceil(w / OWN_K).
+// The tile's input goes through registers (all loads issued before the first LDS write).  (A
+// persistent form that walked the tiles with a fixed grid and kept the NEXT tile's input in
+// registers while the stages ran was measured and dropped: 0-5 % slower in every mode, see
+// DESIGN.md §5.1 — the kernel is bound by VALU issue at three waves per SIMD, not by exposed loads.)
 template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
 // (104 VGPRs: three workgroups per CU then leave 200 registers per SIMD lane free, which is what lets
 // the picker's kernels of the previous call — one 1024-thread workgroup among them — run beside this one)
 __global__ void __launch_bounds__(NTHR, ((sizeof(XT) == 2 ? 4 : APT_FUSED_MIN_WAVES) * NTHR + 255) / 256)
-__attribute__((amdgpu_num_vgpr(104)))
-k_fused(const CallArgs call, const FusedParams *__restrict__ prm)
+k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 {
+    // The call's arguments are read where they lie, in the kernel-argument segment (constant address
+    // space, scalar loads with a run-time index).  (`call_by_value` is the first argument: offset 0
+    // of the segment.)
+    typedef const CallArgs APT_CONST_AS *ccall_ptr;
+    const ccall_ptr callp = (ccall_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+#define call (*callp)
     // Only the stage-1 tap table is fetched from `prm` here; everything the later stages need is
     // loaded after stage 1 (see `late`): an SGPR held across stage 1 is one its tap pipeline cannot
     // use, and the register allocator answered the extra pressure by spilling the table pointer
@@ -147,70 +161,80 @@ k_fused(const CallArgs call, const FusedParams *__restrict__ prm)
     constexpr int kOwnThreads = Gm::kOwnThreads;
     constexpr bool F16 = MODE == kModeF16Taps;
     constexpr bool FAST = MODE == kModeFast;
-    // (field by field: only what the stages below need is loaded, and the output pointers are
-    // fetched from the slot table after stage 3 — every SGPR held across stage 1 is one the tap
-    // pipeline cannot use)
-    const uint64_t w = call.rec[blockIdx.y].w;
-    if (static_cast<uint64_t>(blockIdx.x) * Gm::OWN_K >= w) return;
-    const XT *__restrict__ x = static_cast<const XT *>(call.rec[blockIdx.y].x);
-    const uint64_t n = call.rec[blockIdx.y].n;
-    const uint64_t n_corr = w - Gm::G;  // w >= 10 rows of samples > G (checked on the host)
     extern __shared__ float lds[];
     float *P = lds;                  // x tile -> R -> F
     float *Q = lds + Gm::D_OFF;      // D (inside the dead part of the x tile), later the pulse sums (fast mode)
-
     const int tid = threadIdx.x;
-    const int64_t tile = blockIdx.x;
+    auto rel = [](int64_t v) -> int { return v < -(1 << 30) ? -(1 << 30) : (v > (1 << 30) ? (1 << 30) : static_cast<int>(v)); };
+
+    // ---- stage 0a: a tile's input -> registers (coalesced 16-byte loads, zero outside [0, n));
+    // f32: 4 samples per register quad, PCM16: 4 samples per register pair
+    constexpr int NXR = (Gm::XT_PAD / 4 + kFusedThreads - 1) / kFusedThreads;
+    using XReg = std::conditional_t<sizeof(XT) == 4, float4, uint2>;
+    auto load_tile = [&](uint32_t ri, int64_t tile, XReg (&xr)[NXR]) {
+        const XT *__restrict__ x = static_cast<const XT *>(call.rec[ri].x);
+        const uint64_t n = call.rec[ri].n;
+        const int64_t k0 = tile * Gm::OWN_K - Gm::PRE_K;   // first work sample of the tile (< 0 in tile 0)
+        const int64_t xs0 = (k0 / L) * M;                  // first input sample of the tile
+        const int x_lo = rel(-xs0);                               // tile index of input sample 0
+        const int x_hi = rel(static_cast<int64_t>(n) - xs0);      // tile index of input sample n
+        const XT *xt = x + xs0;  // only dereferenced inside [x_lo, x_hi)
+        if (x_lo <= 0 && x_hi >= Gm::XT_PAD) {
+            // interior tile (wave-uniform): every load is a whole, unguarded 16 / 8 bytes
+#pragma unroll
+            for (int e = 0; e < NXR; ++e) {
+                const int q = (tid + e * kFusedThreads) * 4;
+                if constexpr (sizeof(XT) == 4) {
+                    xr[e] = (q < Gm::XT_PAD) ? *reinterpret_cast<const float4 *>(xt + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    // PCM16: x is 4-byte aligned and xs0, q are even, so sample pairs move as dwords
+                    xr[e] = (q < Gm::XT_PAD) ? *reinterpret_cast<const uint2 *>(xt + q) : make_uint2(0u, 0u);
+                }
+            }
+        } else {
+            // first / last tiles of a recording: sample by sample, zero outside [0, n)
+#pragma unroll
+            for (int e = 0; e < NXR; ++e) {
+                const int q = (tid + e * kFusedThreads) * 4;
+                auto at = [&](int i) -> XT { return (i < Gm::XT_PAD && i >= x_lo && i < x_hi) ? xt[i] : XT(0); };
+                if constexpr (sizeof(XT) == 4) {
+                    xr[e] = make_float4(at(q), at(q + 1), at(q + 2), at(q + 3));
+                } else {
+                    auto u = [&](int i) -> uint32_t { return static_cast<uint32_t>(static_cast<uint16_t>(at(i))); };
+                    xr[e] = make_uint2(u(q) | (u(q + 1) << 16), u(q + 2) | (u(q + 3) << 16));
+                }
+            }
+        }
+    };
+    // ---- stage 0b: registers -> LDS (PCM16: the tile stays int16 in LDS; `*x as f32` happens when
+    // stage 1 reads it)
+    auto tile_to_lds = [&](const XReg (&xr)[NXR]) {
+#pragma unroll
+        for (int e = 0; e < NXR; ++e) {
+            const int q = (tid + e * kFusedThreads) * 4;
+            if (q < Gm::XT_PAD) {
+                if constexpr (sizeof(XT) == 4) *reinterpret_cast<float4 *>(P + q) = xr[e];
+                else *reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(lds) + q / 2) = xr[e];
+            }
+        }
+    };
+
+    // ---- one tile through the four stages
+    auto run_tile = [&](uint32_t ri, int64_t tile, XReg (&xr)[NXR]) {
+    // (field by field: only what the stages below need is loaded, and the output pointers are
+    // fetched from the slot table after stage 3)
+    const uint64_t w = call.rec[ri].w;
+    const uint64_t n_corr = w - Gm::G;  // w >= 10 rows of samples > G (checked on the host)
     const int64_t o0 = tile * Gm::OWN_K;            // first owned work sample
     const int64_t k0 = o0 - Gm::PRE_K;              // first work sample of the tile (< 0 in tile 0)
-    const int64_t xs0 = (k0 / L) * M;               // first input sample of the tile
     // everything below indexes relative to the tile with 32-bit integers; the global limits
     // become wave-uniform scalars
-    auto rel = [](int64_t v) -> int { return v < -(1 << 30) ? -(1 << 30) : (v > (1 << 30) ? (1 << 30) : static_cast<int>(v)); };
-    const int x_lo = rel(-xs0);                                   // tile index of input sample 0
-    const int x_hi = rel(static_cast<int64_t>(n) - xs0);          // tile index of input sample n
     const int k_lo = rel(-k0);                                    // tile index of work sample 0
     const int k_hi = rel(static_cast<int64_t>(w) - k0);           // tile index of work sample w
     const int c_hi = rel(static_cast<int64_t>(n_corr) - k0);      // tile index of position n_corr
-
-    // ---- stage 0: input tile -> LDS (coalesced 16-byte loads, zero outside [0, n))
-    if constexpr (sizeof(XT) == 4) {
-        const float *xt = x + xs0;  // only dereferenced inside [x_lo, x_hi)
-        for (int q = tid * 4; q < Gm::XT_PAD; q += kFusedThreads * 4) {
-            float4 v;
-            if (q >= x_lo && q + 3 < x_hi) {
-                v = *reinterpret_cast<const float4 *>(xt + q);
-            } else {
-                v.x = (q >= x_lo && q < x_hi) ? xt[q] : 0.f;
-                v.y = (q + 1 >= x_lo && q + 1 < x_hi) ? xt[q + 1] : 0.f;
-                v.z = (q + 2 >= x_lo && q + 2 < x_hi) ? xt[q + 2] : 0.f;
-                v.w = (q + 3 >= x_lo && q + 3 < x_hi) ? xt[q + 3] : 0.f;
-            }
-            *reinterpret_cast<float4 *>(P + q) = v;
-        }
-    } else {
-        // PCM16: the tile stays int16 in LDS (`*x as f32` happens when stage 1 reads it).  x is
-        // 4-byte aligned and xs0, q are even, so sample pairs move as dwords.
-        const int16_t *xt = x + xs0;
-        uint32_t *X32 = reinterpret_cast<uint32_t *>(lds);
-        for (int q = tid * 4; q < Gm::XT_PAD; q += kFusedThreads * 4) {
-            uint32_t a, b;
-            if (q >= x_lo && q + 3 < x_hi) {
-                const uint32_t *pp = reinterpret_cast<const uint32_t *>(xt + q);
-                a = pp[0];
-                b = pp[1];
-            } else {
-                auto at = [&](int i) -> uint32_t {
-                    return (i >= x_lo && i < x_hi) ? static_cast<uint32_t>(static_cast<uint16_t>(xt[i])) : 0u;
-                };
-                a = at(q) | (at(q + 1) << 16);
-                b = at(q + 2) | (at(q + 3) << 16);
-            }
-            X32[q / 2] = a;
-            X32[q / 2 + 1] = b;
-        }
-    }
+    tile_to_lds(xr);
     __syncthreads();
+    if constexpr (APT_FUSED_STOP == 1) return;
 
     // ---- stage 1: polyphase resampler, L outputs per thread (dsp.rs:252-263)
     // Sample-stationary form: window sample q is broadcast (op_sel) against a PAIR of taps
@@ -436,6 +460,7 @@ k_fused(const CallArgs call, const FusedParams *__restrict__ prm)
     for (int b = 0; b < L; ++b) P[tid * L + b] = r[b];
     __syncthreads();
 
+    if constexpr (APT_FUSED_STOP == 2) return;
     // the parameters of the later stages, fetched now (the empty asm keeps the loads from being hoisted)
     typedef const FusedParams APT_CONST_AS *cprm_ptr;
     cprm_ptr late = (cprm_ptr)(prm);
@@ -489,7 +514,7 @@ k_fused(const CallArgs call, const FusedParams *__restrict__ prm)
         }
     }
     __syncthreads();
-
+    if constexpr (APT_FUSED_STOP == 3) return;
     // ---- stage 3: causal low-pass with the `i > j` guard (dsp.rs:396-404)
     // Same sample-stationary pairing: envelope sample d = D[kt-(T2-1)+qq] meets output b at
     // tap j = (T2-1)+b-qq, so outputs (b, b+1) take the tap pair (h2[m], h2[m+1]); walking qq
@@ -592,9 +617,9 @@ k_fused(const CallArgs call, const FusedParams *__restrict__ prm)
 #pragma unroll
     for (int b = 0; b < L; ++b) P[tid * L + b] = f[b];  // R is dead: P now holds F
     __syncthreads();
-
+    if constexpr (APT_FUSED_STOP == 4) return;
     // owned F -> HBM, coalesced 16-byte stores
-    uint32_t slot_late = call.rec[blockIdx.y].slot;
+    uint32_t slot_late = call.rec[ri].slot;
     asm volatile("" : "+s"(slot_late));  // keeps the loads below from being hoisted above stage 1
     float *__restrict__ f_out = slots[slot_late].f;
     {
@@ -608,7 +633,7 @@ k_fused(const CallArgs call, const FusedParams *__restrict__ prm)
             }
         }
     }
-
+    if constexpr (APT_FUSED_STOP == 5) return;
     // ---- stage 4: sync cross-correlation (decode.rs:225-233) -> per-group maxima.  The correlation
     // itself never leaves the CU: k_sync_nodes re-evaluates it (same arithmetic, apt_sync_corr.hpp)
     // for the few candidate groups the picker has to look at.
@@ -727,6 +752,15 @@ k_fused(const CallArgs call, const FusedParams *__restrict__ prm)
         if ((tid & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads && kq < c_hi)
             gm_out[o0 / Gm::GS + (tid - kPreThreads) / 4] = GroupMax{mx, hn ? 1.f : 0.f};
     }
+    };  // run_tile
+
+    XReg xr[NXR];
+    const uint32_t ri = blockIdx.y;
+    const int64_t tile = blockIdx.x;
+    if (static_cast<uint64_t>(tile) * Gm::OWN_K >= call.rec[ri].w) return;
+    load_tile(ri, tile, xr);
+    run_tile(ri, tile, xr);
+#undef call
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the function: set it once

@@ -30,5 +30,16 @@ void fused_launch_48k_fast_f32(const FusedLaunch &a);
 void fused_launch_48k_fast_i16(const FusedLaunch &a);
 void fused_launch_96k_fast_f32(const FusedLaunch &a);
 void fused_launch_96k_fast_i16(const FusedLaunch &a);
+#ifdef APT_WITH_PROBES
+// timing probes (make PROBES=1; APTGPU_PROBE_STOP=1..7; sources under tools/probes/): the fast 48 kHz f32
+// kernel cut off after a stage (1..5), or complete with 128 / 192-thread workgroups (6, 7)
+void fused_launch_probe1(const FusedLaunch &a);
+void fused_launch_probe2(const FusedLaunch &a);
+void fused_launch_probe3(const FusedLaunch &a);
+void fused_launch_probe4(const FusedLaunch &a);
+void fused_launch_probe5(const FusedLaunch &a);
+void fused_launch_probe6(const FusedLaunch &a);
+void fused_launch_probe7(const FusedLaunch &a);
+#endif
 
 }  // namespace apt::gpu

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=600.0)
     ap.add_argument("--inputs", type=int, default=4)
     ap.add_argument("--pcm16", action="store_true")
+    ap.add_argument("--no-sync", action="store_true", help="decode(sync=false): front end without stage 4, no picker")
     args = ap.parse_args()
 
     import torch
@@ -52,7 +53,7 @@ def main():
         mode_s, b_s, st_s = cfg.split(":")
         B, S = int(b_s), int(st_s)
         os.environ["APTGPU_STREAMS"] = str(S)
-        plan = apt.Plan(apt.Settings(), apt.Rate.hz(args.rate), True, max_samples=n, max_batch=B, mode=modes[mode_s])
+        plan = apt.Plan(apt.Settings(), apt.Rate.hz(args.rate), not args.no_sync, max_samples=n, max_batch=B, mode=modes[mode_s])
         cap = int(plan.info.max_rows)
         # every call in flight needs its own output buffers
         outs = [[torch.empty(cap * 2080, dtype=torch.float32, device=dev) for _ in range(B)] for _ in range(S)]
