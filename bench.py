@@ -208,6 +208,35 @@ def main():
             }
             step(0)
             plan.results(1)
+            # (3) host-fed: recordings in ordinary (pageable) host memory -> aptgpu_decode_batch, which uploads
+            # call k+1 while call k decodes and copies the rows back; once as f32 Signals, once as PCM16 WAV
+            # file images (half the PCIe bytes).  End-to-end, PCIe-inclusive: never part of `value`.
+            from noaa_apt_amd.testing.wavfile import make_wav
+            PCIE_GBS = 63.0  # PCIe Gen5 x16 (MI355X_MICROARCH.md)
+            host_recs = [xs[j % n_inputs] for j in range(8)]
+            host_wavs = [make_wav(v.astype(np.int16), args.rate) for v in xs]
+            host_wavs = [host_wavs[j % n_inputs] for j in range(8)]
+            for key, inputs, workers in (("host_fed_f32", host_recs, 1), ("host_fed_f32_two_workers", host_recs, 2),
+                                         ("host_fed_pcm16_wav", host_wavs, 1), ("host_fed_pcm16_wav_two_workers", host_wavs, 2)):
+                apt.decode_batch(apt.Context(device=local_rank, mode=mode), settings, inputs[:2], rate, True,
+                                 devices=(local_rank,))  # warm-up (first-touch of the host pages, HIP pools)
+                got, hres, hst = apt.decode_batch(apt.Context(device=local_rank, mode=mode), settings, inputs, rate, True,
+                                                  devices=(local_rank,) * workers, recordings_per_call=4,
+                                                  return_stats=True)
+                ok = all(not isinstance(g, Exception) and g.size == ref_rows.numel() for g in got)
+                same0 = bool(ok and np.array_equal(got[0].view(np.uint32), ref_rows.cpu().numpy().view(np.uint32)))
+                moved = hst.h2d_bytes + hst.d2h_bytes
+                extras[key] = {
+                    "what": f"{len(inputs)} recordings from pageable host memory, {workers} worker(s) on this GPU, "
+                            f"4 recordings per call; rows copied back to the host",
+                    "seconds": round(hst.seconds, 5),
+                    "value": round(hst.samples / hst.seconds / 1e6, 3), "unit": "Msamples/s",
+                    "pcie_bytes": int(moved),
+                    "pcie_GBps": round(moved / hst.seconds / 1e9, 2),
+                    "frac_of_pcie_peak": round(moved / hst.seconds / 1e9 / PCIE_GBS, 4),
+                    "h2d_GBps_inside_copies": round(hst.h2d_bytes / max(hst.h2d_seconds, 1e-9) / 1e9 * workers, 2),
+                    "rows_identical_to_device_resident": same0,
+                }
         pflags = plan.read_internal("picker_flags", np.uint32, 32)
 
     from noaa_apt_amd import shard

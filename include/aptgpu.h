@@ -161,8 +161,10 @@ typedef struct aptgpu_plan_info {
  * with aptgpu_plan_results). */
 typedef struct aptgpu_result {
     int32_t status;    /* APTGPU_OK, or APTGPU_ERR_INTERNAL (<10 rows / <5 sync frames) */
-    int32_t reason;    /* 0 ok, 1 "<10 rows", 2 "<5 sync frames"                          */
-    uint32_t n_rows;   /* image rows written (n_out / 2080 when sync != 0)                  */
+    int32_t reason;    /* 0 ok, 1 "<10 rows", 2 "<5 sync frames", 3 work_rate not a multiple of
+                          4160, 4 ok but rows truncated to the caller's rows_cap; -1 while the
+                          recording's kernels have not finished                              */
+    uint32_t n_rows;   /* image rows written (n_out / 2080 when sync != 0; never more than rows_cap) */
     uint32_t n_sync;   /* peaks.len() of find_sync, 0 when sync == 0                         */
     uint64_t work_len; /* samples after the first resample                                   */
     uint64_t n_out;    /* floats written to d_rows                                           */
@@ -228,6 +230,52 @@ int aptgpu_plan_collect_timing(aptgpu_plan *plan, aptgpu_kernel_time *out, size_
  * and returns the buffer's size in *size_out. */
 int aptgpu_plan_read_internal(aptgpu_plan *plan, int i, const char *name, void *host_out,
                               size_t bytes, size_t *size_out);
+
+/* ====================================================================== */
+/* 2b. host-fed batch decode over one or more GPUs                          */
+/* ====================================================================== */
+/* The batch variant of decode(): what a driver that loops `load(); decode();` over many recordings
+ * (the reference's CLI does it for one, src/main.rs:102-104) binds instead of the loop.  Recordings are
+ * independent, so they are sharded over `devices` (ordinals, repeats allowed: {0, 0} = two workers on
+ * GPU 0; n_devices == 0 = ctx->device) longest-first onto the least loaded entry, with NO collective of
+ * any kind; every entry gets a host thread and a plan, uploads call k+1's inputs while call k decodes
+ * (recordings_per_call recordings per call, <= 0 = 8), and copies the rows back.  All recordings of
+ * a batch share (settings, input_rate_hz, sync); ctx supplies mode (and the device when n_devices == 0),
+ * callbacks are not used.
+ *   rows_out[i] / n_out[i]: malloc'd rows of recording i (aptgpu_free), NULL / 0 when status[i] != 0;
+ *   status[i]: APTGPU_OK, or the error decode() would have returned for that recording
+ *              (APTGPU_ERR_INTERNAL: too short / too few sync frames; for WAV images also the
+ *              reference's WAV errors, and APTGPU_ERR_INVALID for a rate other than input_rate_hz);
+ *   results[i] (nullable): the device-side record (rows, sync frames found, work length).
+ * Returns APTGPU_OK when every worker ran (per-recording failures are in status[]), else the first
+ * worker-level error (HIP failure, bad argument).  Host buffers may be pageable; pinned ones
+ * (aptgpu_host_alloc) are DMA'd directly. */
+typedef struct aptgpu_batch_stats {
+    double seconds;        /* wall time of the whole call                                   */
+    uint64_t samples;      /* input samples of the recordings that were handed to a worker  */
+    uint64_t h2d_bytes, d2h_bytes;
+    double h2d_seconds;    /* host time inside the H2D copy calls, summed over the workers  */
+    double d2h_seconds;
+    int32_t workers;
+    int32_t recordings_per_call;
+} aptgpu_batch_stats;
+
+int aptgpu_decode_batch(const aptgpu_context *ctx, const aptgpu_settings *settings,
+                        uint32_t input_rate_hz, int sync, int count, const float *const *signals,
+                        const size_t *n, const int32_t *devices, int n_devices, int recordings_per_call,
+                        float **rows_out, size_t *n_out, int32_t *status,
+                        aptgpu_result *results /* nullable */, aptgpu_batch_stats *stats /* nullable */,
+                        char *err, size_t err_cap);
+/* The same on WAV file images (noaa_apt::load + decode per file): the data chunk is uploaded as it
+ * is — 2 bytes per sample for PCM16 — and converted on the device (wav.rs:30-51). */
+int aptgpu_decode_batch_wav(const aptgpu_context *ctx, const aptgpu_settings *settings,
+                            uint32_t input_rate_hz, int sync, int count, const void *const *wav_images,
+                            const size_t *wav_bytes, const int32_t *devices, int n_devices,
+                            int recordings_per_call, float **rows_out, size_t *n_out, int32_t *status,
+                            aptgpu_result *results, aptgpu_batch_stats *stats, char *err, size_t err_cap);
+/* Pinned host memory (hipHostMalloc) for inputs that should cross PCIe by direct DMA; NULL on failure. */
+void *aptgpu_host_alloc(size_t bytes);
+void aptgpu_host_free(void *p);
 
 /* ====================================================================== */
 /* 3. the dsp.rs / filters.rs / decode.rs building blocks (host buffers)    */

@@ -30,7 +30,7 @@ from .api import (  # noqa: F401
     decode, resample_with_filter, resample, demodulate, filter, find_sync, generate_sync_frame,
     Contrast, Rotate, Telemetry, ImageResult,
     get_min, get_max, percent, map_signal_u8, read_telemetry, process,
-    Plan, PlanInfo, Result, KernelTime,
+    Plan, PlanInfo, Result, KernelTime, decode_batch, BatchStats, host_alloc_f32, host_free,
     lib, lib_path, build, device_count, version,
     MODE_STRICT, MODE_GENERIC, MODE_FP16_TAPS, MODE_FAST,
 )

@@ -126,6 +126,13 @@ class WavSpec(C.Structure):
                 ("data_len", C.c_uint64), ("n_samples", C.c_uint64), ("n_frames", C.c_uint64)]
 
 
+class BatchStats(C.Structure):
+    """aptgpu_batch_stats: what a host-fed batch moved and how long it took."""
+    _fields_ = [("seconds", C.c_double), ("samples", C.c_uint64), ("h2d_bytes", C.c_uint64),
+                ("d2h_bytes", C.c_uint64), ("h2d_seconds", C.c_double), ("d2h_seconds", C.c_double),
+                ("workers", C.c_int32), ("recordings_per_call", C.c_int32)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("avg_ms", C.c_double), ("launches", C.c_uint64)]
 
@@ -219,6 +226,15 @@ def lib():
     L.aptgpu_resample_wav_file.argtypes = [cp, C.c_char_p, C.c_char_p, u32, f, f, C.c_char_p, sz]
     L.aptgpu_plan_decode_device_wav.argtypes = [vp, i32, C.POINTER(vp), wsp, C.POINTER(vp),
                                                 C.POINTER(sz), C.c_char_p, sz]
+    i32p = C.POINTER(C.c_int32)
+    for name in ("aptgpu_decode_batch", "aptgpu_decode_batch_wav"):
+        getattr(L, name).argtypes = [cp, C.POINTER(_CSettings), u32, i32, i32, C.POINTER(vp), C.POINTER(sz), i32p, i32,
+                                     i32, C.POINTER(_f32p), C.POINTER(sz), i32p, C.POINTER(Result),
+                                     C.POINTER(BatchStats), C.c_char_p, sz]
+    L.aptgpu_host_alloc.argtypes = [sz]
+    L.aptgpu_host_alloc.restype = vp
+    L.aptgpu_host_free.argtypes = [vp]
+    L.aptgpu_host_free.restype = None
     L.aptgpu_get_min.argtypes = [cp, _f32p, sz, _f32p, C.c_char_p, sz]
     L.aptgpu_get_max.argtypes = [cp, _f32p, sz, _f32p, C.c_char_p, sz]
     L.aptgpu_percent.argtypes = [cp, _f32p, sz, f, _f32p, _f32p, C.c_char_p, sz]
@@ -667,6 +683,70 @@ def process(context, signal, contrast_adjustment, rotate=Rotate.NO, color=None, 
                                      C.byref(n), C.byref(info), err, _ERRCAP), err)
     out = _take(img, n.value, np.uint8).reshape(-1, PX_PER_ROW)
     return (out, info) if return_info else out
+
+
+# ------------------------------------------------------------------ host-fed batch over GPUs
+def decode_batch(context: Optional[Context], settings: Settings, inputs, input_rate: Rate, sync: bool,
+                 devices: Sequence[int] = (), recordings_per_call: int = 0, return_stats=False):
+    """aptgpu_decode_batch / aptgpu_decode_batch_wav: independent recordings — f32 Signals (numpy arrays) or
+    WAV file images (bytes) — decoded on `devices` (ordinals, repeats allowed; empty = the context's
+    device), no collectives.  Returns a list with one entry per recording: the rows (flat f32 array), or
+    the AptError decode() would have raised for it; optionally also the result records and BatchStats."""
+    cctx = (context or Context())._c()
+    cs = settings._c()
+    k = len(inputs)
+    wav = k > 0 and isinstance(inputs[0], (bytes, bytearray, memoryview))
+    keep, ptrs, sizes = [], (C.c_void_p * max(k, 1))(), (C.c_size_t * max(k, 1))()
+    for i, x in enumerate(inputs):
+        if wav:
+            b = bytes(x)
+            keep.append(b)
+            ptrs[i] = C.cast(C.c_char_p(b), C.c_void_p)
+            sizes[i] = len(b)
+        else:
+            a, ap = _as_f32(x)
+            keep.append(a)
+            ptrs[i] = C.cast(ap, C.c_void_p)
+            sizes[i] = a.size
+    devs = (C.c_int32 * max(len(devices), 1))(*devices)
+    rows = (_f32p * max(k, 1))()
+    n_out = (C.c_size_t * max(k, 1))()
+    status = (C.c_int32 * max(k, 1))()
+    results = (Result * max(k, 1))()
+    stats = BatchStats()
+    err = C.create_string_buffer(_ERRCAP)
+    fn = lib().aptgpu_decode_batch_wav if wav else lib().aptgpu_decode_batch
+    _check(fn(C.byref(cctx), C.byref(cs), input_rate.get_hz(), int(sync), k, ptrs, sizes, devs, len(devices),
+              int(recordings_per_call), rows, n_out, status, results, C.byref(stats), err, _ERRCAP), err)
+    out = []
+    for i in range(k):
+        if status[i] == 0:
+            out.append(_take(rows[i], n_out[i]))
+        else:
+            reason = {1: "Got less than 10 rows of samples, audio file is too short",
+                      2: "Found less than 5 sync frames, audio file is too short or too noisy",
+                      3: "work_rate is not multiple of FINAL_RATE"}.get(results[i].reason, "")
+            out.append(_ERRORS.get(status[i], AptError)(reason or f"recording {i}: status {status[i]}"))
+    return (out, list(results)[:k], stats) if return_stats else out
+
+
+def host_alloc_f32(n: int) -> np.ndarray:
+    """A pinned (hipHostMalloc) f32 buffer of n samples as a numpy array; free with host_free(array)."""
+    p = lib().aptgpu_host_alloc(int(n) * 4)
+    if not p:
+        raise HipError("aptgpu_host_alloc failed")
+    arr = np.ctypeslib.as_array(C.cast(p, _f32p), shape=(int(n),))
+    _PINNED[arr.ctypes.data] = p
+    return arr
+
+
+def host_free(arr: np.ndarray):
+    p = _PINNED.pop(arr.ctypes.data, None)
+    if p:
+        lib().aptgpu_host_free(p)
+
+
+_PINNED = {}
 
 
 # ------------------------------------------------------------------ plans (device-resident)
