@@ -159,31 +159,90 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
     }
     __syncthreads();
 
-    // coarse: WM[g] = max(GM[g+1 .. g+R-1]) — the full groups inside every window of group g
-    for (int q = tid; q < nwin; q += kNodesThreads) {
-        const int64_t g = gw0 + q;
-        float w0 = kNegInf, w1 = kNegInf, w2 = kNegInf, w3 = kNegInf;
-        int d = 1;
-#pragma unroll 4
-        for (; d + 3 < R; d += 4) {
-            w0 = fmaxf(w0, s_gm[q + d]);
-            w1 = fmaxf(w1, s_gm[q + d + 1]);
-            w2 = fmaxf(w2, s_gm[q + d + 2]);
-            w3 = fmaxf(w3, s_gm[q + d + 3]);
+    // coarse: WM[g] = max(GM[g+1 .. g+R-1]) — the full groups inside every window of group g — as a
+    // sliding-window maximum by the two-block method: with blocks of W = R-1 groups, a window is the
+    // suffix maximum of its first block from its start plus the prefix maximum of its second block up to
+    // its end.  Each block's two scans are one wave's work (shuffles); the suffix maxima borrow the NaN
+    // words' LDS until the windows are combined.
+    {
+        const int W = R - 1;              // window length, >= 1 for every legal md
+        const int N = nwin + R;           // entries of s_gm
+        float *s_suf = reinterpret_cast<float *>(s_nanw);  // [nwin + 1], dead before s_nanw is zeroed
+        const int per = (W + 63) / 64;    // consecutive elements per lane (<= 8: md <= 26 k samples, the plan checks)
+        for (int blk = wave; blk * W < N; blk += kNodesWaves) {
+            const int p0 = blk * W;
+            // forward: pre[p] = max(s_gm[p0 .. p]) -> s_wm[p - W] (the window that ENDS at p starts at p - W + 1)
+            {
+                float loc[8];
+                float run = kNegInf;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int e = lane * per + t;
+                    if (t < per && e < W && p0 + e < N) run = fmaxf(run, s_gm[p0 + e]);
+                    loc[t] = run;
+                }
+                float inc = run;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const float o = __shfl_up(inc, d, 64);
+                    if (lane >= d) inc = fmaxf(inc, o);
+                }
+                float carry = __shfl_up(inc, 1, 64);
+                if (lane == 0) carry = kNegInf;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int e = lane * per + t;
+                    const int pidx = p0 + e;
+                    if (t < per && e < W && pidx < N && pidx - W >= 0 && pidx - W < nwin)
+                        s_wm[pidx - W] = fmaxf(loc[t], carry);
+                }
+            }
+            // backward: suf[p] = max(s_gm[p .. block end]) -> s_suf[p]
+            {
+                float loc[8];
+                float run = kNegInf;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int e = W - 1 - (lane * per + t);  // walk the block from its end
+                    if (t < per && e >= 0 && p0 + e < N) run = fmaxf(run, s_gm[p0 + e]);
+                    loc[t] = run;
+                }
+                float inc = run;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const float o = __shfl_up(inc, d, 64);
+                    if (lane >= d) inc = fmaxf(inc, o);
+                }
+                float carry = __shfl_up(inc, 1, 64);
+                if (lane == 0) carry = kNegInf;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int e = W - 1 - (lane * per + t);
+                    const int pidx = p0 + e;
+                    if (t < per && e >= 0 && pidx < N && pidx <= nwin) s_suf[pidx] = fmaxf(loc[t], carry);
+                }
+            }
         }
-        for (; d < R; ++d) w0 = fmaxf(w0, s_gm[q + d]);
-        const float wm = fmaxf(fmaxf(w0, w1), fmaxf(w2, w3));
-        s_wm[q] = wm;
-        s_words[q] = 0ull;
-        s_nanw[q] = 0ull;
-        const bool valid = g >= 0 && g < static_cast<int64_t>(ng);
-        // a group that holds a NaN is evaluated too: its NaN positions may be starts (see the top)
-        if (valid && (!(wm > s_gm[q]) || s_nan[q])) s_cand[atomicAdd(&s_ncand, 1u)] = static_cast<uint16_t>(q);
+        __syncthreads();
+        // window of group q = [q+1, q+W]: suffix of the block holding q+1 from q+1, prefix of the block holding
+        // q+W up to q+W (the same block when q+1 starts one: then the prefix alone is the whole window)
+        for (int q = tid; q < nwin; q += kNodesThreads) {
+            const int64_t g = gw0 + q;
+            const float wm = fmaxf(s_suf[q + 1], s_wm[q]);
+            s_wm[q] = wm;
+            const bool valid = g >= 0 && g < static_cast<int64_t>(ng);
+            // a group that holds a NaN is evaluated too: its NaN positions may be starts (see the top)
+            if (valid && (!(wm > s_gm[q]) || s_nan[q])) s_cand[atomicAdd(&s_ncand, 1u)] = static_cast<uint16_t>(q);
+        }
+        __syncthreads();
+        for (int q = tid; q < nwin; q += kNodesThreads) {
+            s_words[q] = 0ull;
+            s_nanw[q] = 0ull;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // fine: exact terminal test for the candidate groups; each wave takes four candidates at
-    // a time so their loads are in flight together
+    // a time so their loads are in flight together.  The group md ahead (whose first positions close
+    // the window of this group's positions) is only evaluated when its maximum could matter.
     const uint32_t ncand = s_ncand;
     constexpr int kBatch = NL > 0 ? 4 : 1;
     constexpr int NLR = NL > 0 ? NL : 1;
@@ -193,11 +252,48 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
     float *wa = s_win + static_cast<size_t>(wave) * 2 * wlen;  // window of the candidate group
     float *wb = wa + wlen;                                     // ... of the group md ahead
     const uint32_t wneed = GS + 38u * pw - 1u;  // samples of a window
+    // correlation of the 52 positions of the group starting at `base` from the F window in `win`
+    auto eval_window = [&](float *win, bool on) -> float {
+        float c = kNegInf;
+        if (fast) {
+            // pulse sums in place: every value a lane needs is read before anything is written
+            const uint32_t blen = GS + 36u * pw;  // positions whose pulse sum is used
+            if constexpr (NL > 0) {
+                float bs[NLR];
+#pragma unroll
+                for (int t = 0; t < NL; ++t) {
+                    const uint32_t pq = lane + 64u * t;
+                    bs[t] = pq < blen ? sync_pulse_sum(pw, [&](uint32_t j) { return win[pq + j]; }) : 0.f;
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < NL; ++t) {
+                    const uint32_t pq = lane + 64u * t;
+                    if (pq < blen) win[pq] = bs[t];
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                // any pulse width: ascending sweeps of 64 positions; a sweep only overwrites positions
+                // below the ones later sweeps read
+                for (uint32_t p0 = 0; p0 < blen; p0 += 64) {
+                    const uint32_t pq = p0 + lane;
+                    const float bs = pq < blen ? sync_pulse_sum(pw, [&](uint32_t j) { return win[pq + j]; }) : 0.f;
+                    __builtin_amdgcn_wave_barrier();
+                    if (pq < blen) win[pq] = bs;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (on) c = sync_corr_from_pulses([&](int k) { return win[lane + k * 2 * pw]; });
+        } else {
+            if (on) c = sync_corr_strict(pw, [&](uint32_t j) { return win[lane + j]; });
+        }
+        return c;
+    };
     for (uint32_t c0 = wave * kBatch; c0 < ncand; c0 += kBatch * kNodesWaves) {
         int qv[kBatch];
         float cv[kBatch], c2v[kBatch];
         bool inv[kBatch];
-        float fa[kBatch][NLR], fb[kBatch][NLR];
+        float fa[kBatch][NLR];
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
             const uint32_t ci = c0 + e;
@@ -216,92 +312,34 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
 #pragma unroll
                 for (int t = 0; t < NL; ++t) {
                     const uint64_t j = static_cast<uint64_t>(g) * GS + lane + 64u * t;
-                    const bool take = qv[e] >= 0 && lane + 64u * t < wneed;
-                    fa[e][t] = (take && j < w) ? fsig[j] : 0.f;
-                    fb[e][t] = (take && j + md < w) ? fsig[j + md] : 0.f;
+                    fa[e][t] = (qv[e] >= 0 && lane + 64u * t < wneed && j < w) ? fsig[j] : 0.f;
                 }
             }
         }
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
             if (qv[e] < 0) continue;  // wave-uniform
+            const uint64_t base = static_cast<uint64_t>(gw0 + qv[e]) * GS;
+            const bool in2 = inv[e] && base + lane + md < n_corr;
             if (corr == nullptr) {
-                // F windows -> LDS (one wave: its LDS operations complete in order)
-                const uint64_t base = static_cast<uint64_t>(gw0 + qv[e]) * GS;
+                // F window of the candidate group -> LDS -> its 52 correlation values
                 if constexpr (NL > 0) {
 #pragma unroll
                     for (int t = 0; t < NL; ++t)
-                        if (lane + 64u * t < wlen) {
-                            wa[lane + 64 * t] = fa[e][t];
-                            wb[lane + 64 * t] = fb[e][t];
-                        }
+                        if (lane + 64u * t < wlen) wa[lane + 64 * t] = fa[e][t];
                 } else {
                     for (uint32_t t = lane; t < wlen; t += 64) {
                         const uint64_t j = base + t;
                         wa[t] = (t < wneed && j < w) ? fsig[j] : 0.f;
-                        wb[t] = (t < wneed && j + md < w) ? fsig[j + md] : 0.f;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
-                const bool in2 = inv[e] && base + lane + md < n_corr;
-                if (fast) {
-                    // pulse sums in place: every value a lane needs is read before anything is written
-                    const uint32_t blen = GS + 36u * pw;  // positions whose pulse sum is used
-                    if constexpr (NL > 0) {
-                        float ba[NLR], bb[NLR];
-#pragma unroll
-                        for (int t = 0; t < NL; ++t) {
-                            const uint32_t pq = lane + 64u * t;
-                            ba[t] = bb[t] = 0.f;
-                            if (pq < blen) {
-                                ba[t] = sync_pulse_sum(pw, [&](uint32_t j) { return wa[pq + j]; });
-                                bb[t] = sync_pulse_sum(pw, [&](uint32_t j) { return wb[pq + j]; });
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                        for (int t = 0; t < NL; ++t) {
-                            const uint32_t pq = lane + 64u * t;
-                            if (pq < blen) {
-                                wa[pq] = ba[t];
-                                wb[pq] = bb[t];
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    } else {
-                        // any pulse width: ascending sweeps of 64 positions; position p only reads
-                        // F[p .. p+2pw-1], which earlier sweeps (positions < p) never overwrite...
-                        // except through other lanes of the SAME sweep, all of which read first
-                        for (uint32_t p0 = 0; p0 < blen; p0 += 64) {
-                            const uint32_t pq = p0 + lane;
-                            float ba = 0.f, bb = 0.f;
-                            if (pq < blen) {
-                                ba = sync_pulse_sum(pw, [&](uint32_t j) { return wa[pq + j]; });
-                                bb = sync_pulse_sum(pw, [&](uint32_t j) { return wb[pq + j]; });
-                            }
-                            // positions pq+1 .. pq+2pw-1 of the next sweep's first lanes were read above
-                            // only by this sweep; the next sweep reads [p0+64, ...) which this sweep's
-                            // writes (< p0+64) do not touch
-                            __builtin_amdgcn_wave_barrier();
-                            if (pq < blen) {
-                                wa[pq] = ba;
-                                wb[pq] = bb;
-                            }
-                            __builtin_amdgcn_wave_barrier();
-                        }
-                    }
-                    if (inv[e]) cv[e] = sync_corr_from_pulses([&](int k) { return wa[lane + k * 2 * pw]; });
-                    if (in2) c2v[e] = sync_corr_from_pulses([&](int k) { return wb[lane + k * 2 * pw]; });
-                } else {
-                    if (inv[e]) cv[e] = sync_corr_strict(pw, [&](uint32_t j) { return wa[lane + j]; });
-                    if (in2) c2v[e] = sync_corr_strict(pw, [&](uint32_t j) { return wb[lane + j]; });
-                }
+                cv[e] = eval_window(wa, inv[e]);
             }
             if (inv[e] && gw0 + qv[e] == 0 && lane == 0 && !(cv[e] > 0.f)) cv[e] = 0.f;  // the peak (0, 0.)
             // NaN: remembered for the start test, -inf for every comparison
             const unsigned long long nanword = __ballot(inv[e] && cv[e] != cv[e]) & kGroupMask;
             if (cv[e] != cv[e]) cv[e] = kNegInf;
-            if (c2v[e] != c2v[e]) c2v[e] = kNegInf;
             // suffix max over lanes > lane (rest of this group)
             float sfx = cv[e];
             for (int d = 1; d < 64; d <<= 1) {
@@ -310,13 +348,27 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
             }
             float sfx_ex = __shfl_down(sfx, 1, 64);
             if (lane == 63) sfx_ex = kNegInf;
+            float wmax = fmaxf(sfx_ex, s_wm[qv[e]]);
+            // the group md ahead: its positions up to this lane's offset belong to the window.  None of them
+            // can exceed corr[i] unless the group's maximum does, so it is only evaluated when some lane
+            // that is still a terminal so far is below that maximum (on APT data: almost never).
+            const float gm_ahead = s_gm[qv[e] + R];
+            if (corr == nullptr && __ballot(in2 && !(wmax > cv[e]) && gm_ahead > cv[e]) != 0ull) {
+                for (uint32_t t = lane; t < wlen; t += 64) {
+                    const uint64_t j = base + md + t;
+                    wb[t] = (t < wneed && j < w) ? fsig[j] : 0.f;
+                }
+                __builtin_amdgcn_wave_barrier();
+                c2v[e] = eval_window(wb, in2);
+            }
+            if (c2v[e] != c2v[e]) c2v[e] = kNegInf;
             // prefix max over lanes <= lane of the group md positions ahead
             float pfx = c2v[e];
             for (int d = 1; d < 64; d <<= 1) {
                 const float o = __shfl_up(pfx, d, 64);
                 if (lane >= d) pfx = fmaxf(pfx, o);
             }
-            const float wmax = fmaxf(fmaxf(sfx_ex, s_wm[qv[e]]), pfx);
+            wmax = fmaxf(wmax, pfx);
             const bool term = inv[e] && !(wmax > cv[e]);
             const unsigned long long word = __ballot(term) & kGroupMask;
             if (lane == 0) {
@@ -552,7 +604,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
                     const uint32_t k0 = 4 * (j + e);
                     const uint32_t vals[4] = {v[e].x, v[e].y, v[e].z, v[e].w};
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < 8; ++t) {
                         const uint32_t pos = vals[t] & kPosMask;  // a tagged entry only matches its own position
                         if (k0 + t < lim && pos >= sv && (!(vals[t] & kNanStartTag) || pos == sv)) {
                             *uval = pos;
