@@ -22,7 +22,7 @@ CASES = {  # name -> (rate, seconds, seed)
 def main():
     out = os.path.join(ROOT, "oracle", "_ref", "in")
     os.makedirs(out, exist_ok=True)
-    shutil.copyfile(os.path.join(ROOT, "tests", "golden", "noise_48000hz.wav"), os.path.join(out, "noise_fixture.wav"))
+    shutil.copyfile(os.path.join(ROOT, "tests", "golden", "reference_fixture", "noise_48000hz.wav"), os.path.join(out, "noise_fixture.wav"))
     for name, (rate, seconds, seed) in CASES.items():
         x = synth_apt(rate, seconds, seed)  # integer-valued f32 within int16 range
         open(os.path.join(out, name + ".wav"), "wb").write(make_wav(x.astype(np.int16), rate))

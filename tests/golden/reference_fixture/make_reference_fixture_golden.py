@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Freeze the oracle's answers for the reference's one real WAV fixture (test/noise_48000hz.wav,
-copied to tests/golden/noise_48000hz.wav — despite its name 11 025 Hz, mono, 16 bit, 330 745 frames):
+copied next to this script — despite its name 11 025 Hz, mono, 16 bit, 330 745 frames):
 the commands of /root/reference/test/test.sh:46,50-51
 
     noaa-apt noise_48000hz.wav -o decoded_noise.png        -> decode() rows (before the PNG stage)
     noaa-apt noise_48000hz.wav -r 80000 -o upsampled.wav   -> resample tool output file
     noaa-apt noise_48000hz.wav -r 11025 -o downsampled.wav -> resample tool output file
 
-Writes tests/golden/reference_fixture.json (sha256 of the raw little-endian bytes + sizes).  The
+Writes reference_fixture.json next to this script (sha256 of the raw little-endian bytes + sizes).  The
 oracle is the C restatement of the reference (oracle/); the reference itself (Rust) cannot be run
 in this image, so these hashes pin "what the oracle said on the day they were frozen", not the
 reference binary — see DESIGN.md §3.
@@ -20,7 +20,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(HERE))))
 
 from oracle import binding as oracle  # noqa: E402
 from oracle import wav_binding as ow  # noqa: E402

@@ -1,9 +1,9 @@
 """The reference's one real WAV fixture (test/noise_48000hz.wav — despite its name 11 025 Hz, mono,
-16 bit, 330 745 frames; a copy sits in tests/golden/) through the commands of the reference's
+16 bit, 330 745 frames; a copy sits in tests/golden/reference_fixture/) through the commands of the reference's
 test/test.sh:46,50-51: decode, resample to 80 000 Hz, resample to 11 025 Hz.
 
-The CPU tests check the oracle against hashes frozen in tests/golden/reference_fixture.json
-(made by tests/golden/make_reference_fixture_golden.py); the GPU tests check the HIP path, through
+The CPU tests check the oracle against hashes frozen in tests/golden/reference_fixture/reference_fixture.json
+(made by make_reference_fixture_golden.py next to it); the GPU tests check the HIP path, through
 the C ABI on the file image exactly as it is on disk, against the oracle AND the frozen hashes.
 """
 import hashlib
@@ -16,8 +16,8 @@ import pytest
 import noaa_apt_amd as apt
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FIXTURE = os.path.join(HERE, "golden", "noise_48000hz.wav")
-GOLDEN = json.load(open(os.path.join(HERE, "golden", "reference_fixture.json")))
+FIXTURE = os.path.join(HERE, "golden", "reference_fixture", "noise_48000hz.wav")
+GOLDEN = json.load(open(os.path.join(HERE, "golden", "reference_fixture", "reference_fixture.json")))
 f32 = np.float32
 
 
