@@ -278,7 +278,7 @@ def main():
         # (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 2x read correction applied by
         # tools/summarize_pmc.py) for THIS workload and mode; null when no matching profile is committed
         traffic, traffic_src, sq = None, None, None
-        if (args.rate, args.seconds, args.profile, max(1, args.batch)) == (48000, 600.0, "standard", 1) \
+        if (args.rate, args.seconds, args.profile, max(1, args.batch)) == (48000, 600.0, "standard", 8) \
                 and dom[0] == "fused_front_end" and args.mode in ("strict", "fast"):
             try:
                 f = os.path.join(ROOT, "profiles", f"r02_hbm_traffic_{args.mode}.json")
