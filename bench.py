@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed-for-the-headline extra legs (PCM16 ingest, image stage)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-launch", action="store_true",
+                    help="skip the extra one-recording-per-launch measurement (profiling runs: every front-end "
+                         "launch of the process then has the bench's launch shape)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="experiment: leave the per-kernel HIP events out of the timed region")
     args = ap.parse_args()
@@ -144,7 +147,7 @@ def main():
         iso_times = plan.collect_timing()
         # the same kernel launched over ONE recording (the launch shape of round 1), one launch at a time
         single_ms = None
-        if B > 1 and not args.no_sync:
+        if B > 1 and not args.no_sync and not args.no_single_launch:
             plan1 = apt.Plan(settings, rate, True, max_samples=n, max_batch=1, device=local_rank, mode=mode)
             plan1.enable_timing(2)
             for j in range(16):

@@ -12,8 +12,8 @@ for MODE in strict fast; do
   (cd $R && python bench.py --mode $MODE > $O/bench_$MODE.json 2> $O/bench_$MODE.err)
   (cd $R && python bench.py --mode $MODE --steps 20 --warmup 5 --no-extras > $O/bench_${MODE}_steps20.json 2>> $O/bench_$MODE.err)
   # (2) kernel statistics of the same command: pipelined, and with ONE call in flight (durations then are GPU time per launch)
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$MODE -- python $R/bench.py --mode $MODE --no-cpu-baseline --no-extras --steps 100 > $O/stats_${MODE}_bench.json 2>/dev/null
-  APTGPU_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_${MODE}_streams1 -- python $R/bench.py --mode $MODE --no-cpu-baseline --no-extras --steps 100 > $O/stats_${MODE}_streams1_bench.json 2>/dev/null
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$MODE -- python $R/bench.py --mode $MODE --no-cpu-baseline --no-extras --no-single-launch --steps 100 > $O/stats_${MODE}_bench.json 2>/dev/null
+  APTGPU_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_${MODE}_streams1 -- python $R/bench.py --mode $MODE --no-cpu-baseline --no-extras --no-single-launch --steps 100 > $O/stats_${MODE}_streams1_bench.json 2>/dev/null
   # (3) HBM traffic per launch (FETCH_SIZE and WRITE_SIZE cannot share a pass)
   APTGPU_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$MODE -- python $R/bench.py --mode $MODE --no-cpu-baseline --no-extras --steps 6 --warmup 2 > /dev/null 2>&1
   APTGPU_STREAMS=1 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_$MODE -- python $R/bench.py --mode $MODE --no-cpu-baseline --no-extras --steps 6 --warmup 2 > /dev/null 2>&1
