@@ -118,6 +118,35 @@ def main():
                 counter[0] += 1
             plan.decode_device(sigs[j], nn, out, caps)
 
+        # ---- per-kernel measurement passes, BEFORE the warm-up steps (they are part of every run; placed
+        # here they also bring the GPU out of the idle clocks it fell to while the host generated inputs)
+        # (a) the dominant kernel with nothing else on the GPU — one step at a time, a host
+        # synchronisation after each, HIP events around every launch.  This per-launch duration
+        # is what `roofline` uses (a launch in the timed region below shares the GPU with the
+        # launches of the other calls in flight, so its duration there is not GPU time per launch).
+        plan.enable_timing(2)
+        for _ in range(24):
+            step()
+            torch.cuda.synchronize()
+        iso_times = plan.collect_timing()
+        # (b) the same kernel launched over ONE recording (the launch shape of round 1), one launch at a time
+        single_ms = None
+        if B > 1 and not args.no_sync and not args.no_single_launch:
+            plan1 = apt.Plan(settings, rate, True, max_samples=n, max_batch=1, device=local_rank, mode=mode)
+            plan1.enable_timing(2)
+            for j in range(16):
+                plan1.decode_device([d_xs[j % n_inputs].data_ptr()], [n], out[:1], caps[:1])
+                torch.cuda.synchronize()
+            single_ms = plan1.collect_timing().get("fused_front_end", (None, 0))[0]
+            plan1.close()
+        # (c) pipelined, with events around every kernel, for the per-kernel breakdown
+        plan.enable_timing(2)
+        for _ in range(10):
+            step()
+        ktimes = plan.collect_timing()
+        plan.enable_timing(0)
+
+        # ---- W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
@@ -136,30 +165,6 @@ def main():
             dist.barrier()
         t1 = time.perf_counter()
         dom_times = plan.collect_timing()
-        # untimed: the dominant kernel with nothing else on the GPU — one step at a time, a host
-        # synchronisation after each, HIP events around every launch.  This per-launch duration
-        # is what `roofline` uses (a launch in the timed region above shares the GPU with the
-        # launches of the other calls in flight, so its duration there is not GPU time per launch).
-        plan.enable_timing(2)
-        for _ in range(24):
-            step()
-            torch.cuda.synchronize()
-        iso_times = plan.collect_timing()
-        # the same kernel launched over ONE recording (the launch shape of round 1), one launch at a time
-        single_ms = None
-        if B > 1 and not args.no_sync and not args.no_single_launch:
-            plan1 = apt.Plan(settings, rate, True, max_samples=n, max_batch=1, device=local_rank, mode=mode)
-            plan1.enable_timing(2)
-            for j in range(16):
-                plan1.decode_device([d_xs[j % n_inputs].data_ptr()], [n], out[:1], caps[:1])
-                torch.cuda.synchronize()
-            single_ms = plan1.collect_timing().get("fused_front_end", (None, 0))[0]
-            plan1.close()
-        # untimed extra pass with events around every kernel, for the per-kernel breakdown
-        plan.enable_timing(2)
-        for _ in range(min(args.steps, 10)):
-            step()
-        ktimes = plan.collect_timing()
         plan.enable_timing(0)
         step(0)  # the recording that is compared with the oracle below
         res = plan.results(1)[0]

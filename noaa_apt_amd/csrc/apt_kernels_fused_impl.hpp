@@ -761,13 +761,6 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     const uint32_t ri = blockIdx.y;
     const int64_t tile = blockIdx.x;
     if (static_cast<uint64_t>(tile) * Gm::OWN_K >= call.rec[ri].w) return;
-    // Experiment knob (APTGPU_STAGGER, 0 in production): the workgroups of a launch start together and
-    // all do the same work, so the chip alternates between "everyone loads" and "everyone computes";
-    // delaying two thirds of them by one / two units of 64*stagger cycles spreads the phases.
-    if (const int stagger = prm->reserved; stagger > 0 && blockIdx.y == 0 && blockIdx.x < 768) {  // first round only
-        const uint32_t k = blockIdx.x % 3u;
-        for (uint32_t i = 0; i < k * static_cast<uint32_t>(stagger); ++i) __builtin_amdgcn_s_sleep(127);
-    }
     load_tile(ri, tile, xr);
     run_tile(ri, tile, xr);
 #undef call
