@@ -126,6 +126,16 @@ bool fused_f16_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint3
 bool fused_fast_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
 // Per-plan parameters of the specialised front end, resident in HBM (the kernel fetches each when
 // the stage that needs it starts, instead of holding them in SGPRs from its first instruction on).
+// Run-time geometry of the table-driven stage 1 (k_fused in TABLE mode; fused_table_geom fills it)
+struct TableGeom {
+    uint32_t l, m;             // interpolation / decimation factors
+    uint32_t jlim;             // taps the reference uses (2*off + 1)
+    uint32_t tpp;              // row stride of the phase-major table (>= taps per phase, odd)
+    uint32_t xt;               // input tile, floats (multiple of 4)
+    uint32_t off_x;            // LDS offset of the input tile in floats (the table sits at 0)
+    uint32_t step_q, step_r;   // (NTHR*m) / l and % l: x0 / phase update between a thread's outputs
+    uint32_t jl_a, jl_b;       // jlim / l and % l: taps of phase p = jl_a + (p < jl_b)
+};
 struct FusedParams {
     const float *hs;        // stage-1 table: tap pairs (fused_branch_taps), or the fp16 table
     const float *h2;        // low-pass taps [T2]
@@ -136,6 +146,8 @@ struct FusedParams {
     float f16_unscale;      // 2^-s of the fp16 tap prescale (fp16-tap mode)
     int32_t want_gm;        // sync search wanted: emit the per-group correlation maxima
     int32_t reserved;
+    const float *table;     // TABLE mode: phase-major tap table [l][tpp] (fused_any_table)
+    TableGeom tab;
 };
 // One launch over the recordings of `call`: x -> F (slot's filtered buffer) and, if prm->want_gm, the
 // per-group maxima of the sync cross-correlation.  Returns false if no specialisation matches.
@@ -143,6 +155,12 @@ struct FusedParams {
 // mode: 0 strict, 1 fp16 taps, 2 fast.
 bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, int mode,
                      bool pcm16, const CallArgs &call, const FusedParams *d_prm, uint64_t max_w);
+// Table-driven stage 1 + the specialised work-rate stages (k_fused in TABLE mode): any (l, m, taps) whose
+// phase-major table and input tile fit two 512-thread workgroups per CU, standard-profile work-rate
+// stages (37-tap low-pass, pw = 3).  11 025 Hz (l = 832) is the rate this exists for.
+bool fused_table_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom);
+bool fused_table_front_end(hipStream_t s, const TableGeom &geom, int mode, bool pcm16, const CallArgs &call,
+                           const FusedParams *d_prm, uint64_t max_w);
 
 // ---- fused front end for any rate / profile (apt_kernels_fused_any.hip) -------------
 // run-time parameters, taps phase-major in LDS; same outputs as fused_front_end

@@ -142,7 +142,7 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
     if (pcm16)  // dword loads of sample pairs
         for (uint32_t i = 0; i < call.count; ++i)
             if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 3u) return false;
-    const FusedLaunch a{s, &call, d_prm, max_w};
+    const FusedLaunch a{s, &call, d_prm, max_w, 0};
     if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
         if (mode == kModeF16Taps)  // fp16-tap stage 1: hb is the half2 table of fused_f16_branch_taps
             pcm16 ? fused_launch_48k_f16taps_i16(a) : fused_launch_48k_f16taps_f32(a);
@@ -176,6 +176,48 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
         return true;
     }
     return false;
+}
+
+
+// ---- table-driven stage 1 (k_fused in TABLE mode)
+bool fused_table_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom)
+{
+    constexpr uint32_t kThreads = 512, kPerThread = 13, kTile = kThreads * kPerThread;
+    constexpr uint32_t kLdsFloats = 20480;  // 80 KB: two workgroups per CU
+    if (l < 2 || m == 0 || t1 == 0 || t2 != 37 || pw != 3) return false;  // (work-rate stages: standard profile)
+    if (static_cast<uint64_t>(kTile + 4096) * m + l > 0x7fffffffull) return false;  // 32-bit in-tile index math
+    TableGeom g{};
+    g.l = l;
+    g.m = m;
+    g.jlim = 2 * ((t1 - 1) / 2) + 1;
+    const uint32_t per_phase = (g.jlim + l - 1) / l;
+    g.tpp = per_phase | 1u;  // odd stride: rows of consecutive phases start in different banks
+    g.xt = (static_cast<uint32_t>((static_cast<uint64_t>(kTile) * m + l - 1) / l) + per_phase + 8 + 3) & ~3u;
+    g.off_x = (l * g.tpp + 3u) & ~3u;
+    g.step_q = static_cast<uint32_t>((static_cast<uint64_t>(kThreads) * m) / l);
+    g.step_r = static_cast<uint32_t>((static_cast<uint64_t>(kThreads) * m) % l);
+    g.jl_a = g.jlim / l;
+    g.jl_b = g.jlim % l;
+    if (static_cast<uint64_t>(g.off_x) + g.xt > kLdsFloats) return false;
+    if (geom) *geom = g;
+    return true;
+}
+
+bool fused_table_front_end(hipStream_t s, const TableGeom &geom, int mode, bool pcm16, const CallArgs &call,
+                           const FusedParams *d_prm, uint64_t max_w)
+{
+    if (call.count == 0 || call.count > static_cast<uint32_t>(kMaxCall)) return false;
+    if (pcm16)
+        for (uint32_t i = 0; i < call.count; ++i)
+            if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 1u) return false;
+    const FusedLaunch a{s, &call, d_prm, max_w, static_cast<size_t>(geom.off_x) + geom.xt};
+    if (mode == kModeFast)
+        pcm16 ? fused_launch_tab_std_fast_i16(a) : fused_launch_tab_std_fast_f32(a);
+    else if (mode == kModeStrict)
+        pcm16 ? fused_launch_tab_std_i16(a) : fused_launch_tab_std_f32(a);
+    else
+        return false;
+    return true;
 }
 
 }  // namespace apt::gpu

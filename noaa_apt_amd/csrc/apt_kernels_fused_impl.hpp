@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <type_traits>
@@ -55,17 +56,20 @@ __host__ __device__ constexpr int branch_phase(int b)  // p_b = c_b*L - b*M
 
 // XB: bytes per input sample in the LDS tile (4: f32 Signal; 2: PCM16 kept as int16 — exact, and
 // half the tile, so the other regions set the footprint and 4 instead of 3 workgroups fit a CU)
+// M == 0 selects the table-driven stage 1 (TABLE mode, see k_fused): the resampling factors, tap count and
+// input tile are then run-time quantities (FusedParams::tab) and only the work-rate geometry is static.
 template <int L, int M, int T1, int T2, int PW, int NTHR, int XB = 4>
 struct FusedGeom {
+    static constexpr bool TABLE = M == 0;
     static constexpr int kFusedThreads = NTHR;
     static constexpr int kOwnThreads = NTHR - kPreThreads - kPostThreads;
     static constexpr int TP = (T1 + L - 1) / L;                       // taps per branch (max)
-    static constexpr int CLAST = branch_first<L, M>(L - 1);           // last branch's first sample
+    static constexpr int CLAST = TABLE ? 0 : branch_first<L, (TABLE ? 1 : M)>(L - 1);  // last branch's first sample
     static constexpr int WIN = CLAST + TP;                            // input window per thread
     static constexpr int TILE_K = kFusedThreads * L;                  // work samples per tile
     static constexpr int OWN_K = kOwnThreads * L;                     // owned work samples
     static constexpr int PRE_K = kPreThreads * L;
-    static constexpr int XT = (kFusedThreads - 1) * M + WIN + 2;          // input floats per tile
+    static constexpr int XT = TABLE ? 4 : (kFusedThreads - 1) * M + WIN + 2;  // input floats per tile
     static constexpr int XT_PAD = (XT + 3) & ~3;
     static constexpr int G = 38 * PW;                                 // sync template length
     static constexpr int FWIN = L + G - 1;                            // F window per thread
@@ -79,6 +83,8 @@ struct FusedGeom {
     static constexpr int PS = NP;                                     // f2 tap entries per window sample
     static constexpr int HL_OFF = 2 * ((CLAST + (T1 + L - 1) / L) * NP);  // float offset of the odd branch's taps
     static constexpr int DW = L + T2 - 1;                             // envelope window per thread
+    // TABLE mode: floats of LDS the work-rate stages need (the table + input tile may need more: launch time)
+    static constexpr int W_LDS_FLOATS = D_OFF + TILE_K + 36 * PW;
     static_assert(PRE_K >= T2 + 1, "pre-halo too small for the low-pass");
     static_assert((kFusedThreads - kPreThreads - kOwnThreads) * L >= G - 1, "post-halo too small");
     static_assert(OWN_K % 4 == 0, "owned range must be float4-aligned");
@@ -134,6 +140,11 @@ __host__ __device__ constexpr bool sync_plus(int j)
 //                instructions.  Tolerance-based; deterministic.
 // One launch covers the `count` recordings of a call; the per-recording arguments travel by value
 // in the kernel-argument segment, the workspace pointers come from the plan's slot table.
+// TABLE mode (M == 0; 11 025 Hz and other rates whose interpolation factor is far too large for one
+// accumulator per polyphase branch): stage 1 runs from a phase-major tap table in LDS with run-time L / M /
+// tap count — one output per thread and step, as in k_fused_any — and hands R to the SAME work-rate
+// stages (envelope, packed low-pass, correlation) as the specialised kernels; the template's L is then
+// just "work samples per thread" (13: four threads = one group of 52 positions).
 // One workgroup per tile: blockIdx.y picks the recording, whose tiles are blockIdx.x < ceil(w / OWN_K).
 // The tile's input goes through registers (all loads issued before the first LDS write).  (A
 // persistent form that walked the tiles with a fixed grid and kept the NEXT tile's input in
@@ -142,7 +153,8 @@ __host__ __device__ constexpr bool sync_plus(int j)
 template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
 // (104 VGPRs: three workgroups per CU then leave 200 registers per SIMD lane free, which is what lets
 // the picker's kernels of the previous call — one 1024-thread workgroup among them — run beside this one)
-__global__ void __launch_bounds__(NTHR, ((sizeof(XT) == 2 ? 4 : APT_FUSED_MIN_WAVES) * NTHR + 255) / 256)
+__global__ void __launch_bounds__(NTHR, M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
+                                               : ((sizeof(XT) == 2 ? 4 : APT_FUSED_MIN_WAVES) * NTHR + 255) / 256)
 k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 {
     // The call's arguments are read where they lie, in the kernel-argument segment (constant address
@@ -232,6 +244,132 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     const int k_lo = rel(-k0);                                    // tile index of work sample 0
     const int k_hi = rel(static_cast<int64_t>(w) - k0);           // tile index of work sample w
     const int c_hi = rel(static_cast<int64_t>(n_corr) - k0);      // tile index of position n_corr
+    const int kq = tid * L;        // this thread's first work sample, tile-relative
+    const int kt = kq - k_lo;      // ... and as a global work-sample index clamped to int
+    float r[L];
+    if constexpr (Gm::TABLE) {
+        // ---- stages 0 + 1, table-driven (dsp.rs:252-263): k*m - X0*l = v;  x0 - X0 = c = ceil(v / l);
+        // phase p = c*l - v; output k = sum_i table[p][i] * x[x0 + i] over the taps the reference uses
+        // (jl_a + (p < jl_b) of them), inputs at or past n zero-filled (exact: see k_fused_any).
+        typedef const FusedParams APT_CONST_AS *cprm_tab_ptr;
+        const cprm_tab_ptr tp = (cprm_tab_ptr)(prm);
+        TableGeom G;  // (field by field: a struct cannot be copied out of the constant address space)
+        G.l = tp->tab.l;
+        G.m = tp->tab.m;
+        G.jlim = tp->tab.jlim;
+        G.tpp = tp->tab.tpp;
+        G.xt = tp->tab.xt;
+        G.off_x = tp->tab.off_x;
+        G.step_q = tp->tab.step_q;
+        G.step_r = tp->tab.step_r;
+        G.jl_a = tp->tab.jl_a;
+        G.jl_b = tp->tab.jl_b;
+        const cfloat_ptr table = (cfloat_ptr)(tp->table);
+        const XT *__restrict__ x = static_cast<const XT *>(call.rec[ri].x);
+        const uint64_t n = call.rec[ri].n;
+        float *T = lds;
+        float *X = lds + G.off_x;
+        const int64_t kb = k0 > 0 ? k0 : 0;                           // first work sample that exists
+        const int idx0 = static_cast<int>(kb - k0);
+        const uint64_t kbm = static_cast<uint64_t>(kb) * G.m;         // kb*m = X0*l + rb
+        const uint64_t X0 = kbm / G.l;
+        const uint32_t rb = static_cast<uint32_t>(kbm - X0 * G.l);
+        const uint64_t xfirst = X0 + (rb ? 1 : 0);
+        const uint64_t xs0 = xfirst & ~3ull;                          // tile's first input, 16-byte aligned
+        const uint32_t xrel0 = static_cast<uint32_t>(X0 - xs0);       // may wrap by -1: only used with c >= 1 or rb == 0
+        {
+            const uint32_t nt = G.l * G.tpp, nt4 = nt / 4;
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            typedef const f4v APT_CONST_AS *cf4_ptr;
+            const cf4_ptr t4 = (cf4_ptr)(tp->table);
+            f4v *l4 = reinterpret_cast<f4v *>(T);
+#pragma unroll 4
+            for (uint32_t q = tid; q < nt4; q += kFusedThreads) l4[q] = t4[q];
+            for (uint32_t q = 4 * nt4 + tid; q < nt; q += kFusedThreads) T[q] = table[q];
+        }
+        if constexpr (sizeof(XT) == 4) {
+            const float *xf = reinterpret_cast<const float *>(x);
+            if ((reinterpret_cast<uintptr_t>(xf) & 15u) == 0) {
+                for (uint32_t q = tid * 4; q < G.xt; q += kFusedThreads * 4) {
+                    const uint64_t i = xs0 + q;
+                    float4 v;
+                    if (i + 3 < n) {
+                        v = *reinterpret_cast<const float4 *>(xf + i);
+                    } else {
+                        v.x = i < n ? xf[i] : 0.f;
+                        v.y = i + 1 < n ? xf[i + 1] : 0.f;
+                        v.z = i + 2 < n ? xf[i + 2] : 0.f;
+                        v.w = i + 3 < n ? xf[i + 3] : 0.f;
+                    }
+                    *reinterpret_cast<float4 *>(X + q) = v;
+                }
+            } else {
+                for (uint32_t q = tid; q < G.xt; q += kFusedThreads) X[q] = xs0 + q < n ? xf[xs0 + q] : 0.f;
+            }
+        } else {
+            // mono PCM16 payload (wav.rs:37: `*x as f32`)
+            for (uint32_t q = tid; q < G.xt; q += kFusedThreads) X[q] = xs0 + q < n ? static_cast<float>(x[xs0 + q]) : 0.f;
+        }
+        __syncthreads();
+        if constexpr (APT_FUSED_STOP == 1) return;
+        float s1[L];  // outputs tid, tid + NTHR, ...: consecutive lanes = consecutive outputs
+        {
+            uint32_t c = 0, ph = 0;
+            bool primed = false;
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                const int idx = tid + i * kFusedThreads;
+                float sum = 0.f;
+                if (idx >= idx0) {
+                    if (!primed) {
+                        const uint32_t v = rb + static_cast<uint32_t>(idx - idx0) * G.m;
+                        c = (v + G.l - 1) / G.l;
+                        ph = c * G.l - v;
+                        primed = true;
+                    } else {
+                        c += G.step_q;
+                        if (ph >= G.step_r) {
+                            ph -= G.step_r;
+                        } else {
+                            ph += G.l - G.step_r;
+                            c += 1;
+                        }
+                    }
+                    if (idx < k_hi) {
+                        const uint32_t cnt = G.jl_a + (ph < G.jl_b ? 1u : 0u);
+                        const float *row = T + ph * G.tpp;
+                        const float *xs = X + (xrel0 + c);
+                        // batches of 8 taps: sixteen LDS reads in flight, then the eight MACs in tap order
+                        uint32_t j = 0;
+                        for (; j + 8 <= cnt; j += 8) {
+                            float tv[8], xv[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                tv[e] = row[j + e];
+                                xv[e] = xs[j + e];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                if constexpr (FAST) sum = __builtin_fmaf(tv[e], xv[e], sum);
+                                else sum = sum + tv[e] * xv[e];
+                            }
+                        }
+                        for (; j < cnt; ++j) {
+                            if constexpr (FAST) sum = __builtin_fmaf(row[j], xs[j], sum);
+                            else sum = sum + row[j] * xs[j];
+                        }
+                    }
+                }
+                s1[i] = sum;
+            }
+        }
+        __syncthreads();  // everyone is done with the table and the input tile: R may land on them
+#pragma unroll
+        for (int i = 0; i < L; ++i) P[tid + i * kFusedThreads] = s1[i];
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < L; ++b) r[b] = P[kq + b];
+    } else {
     tile_to_lds(xr);
     __syncthreads();
     if constexpr (APT_FUSED_STOP == 1) return;
@@ -241,9 +379,6 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     // (one scalar-loaded SGPR pair) feeding a pair of accumulators, so every tap costs half
     // a v_pk_mul_f32 + half a v_pk_add_f32 and no register shuffling.  Each branch still
     // accumulates its own taps in ascending order, products and sums rounded separately.
-    const int kq = tid * L;        // this thread's first work sample, tile-relative
-    const int kt = kq - k_lo;      // ... and as a global work-sample index clamped to int
-    float r[L];
     if constexpr (F16) {
         typedef _Float16 h2v __attribute__((ext_vector_type(2)));
         constexpr int NQP = (Gm::WIN + 1) / 2;  // window sample pairs
@@ -462,6 +597,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 #pragma unroll
     for (int b = 0; b < L; ++b) P[tid * L + b] = r[b];
     __syncthreads();
+    }  // !TABLE
 
     if constexpr (APT_FUSED_STOP == 2) return;
     // the parameters of the later stages, fetched now (the empty asm keeps the loads from being hoisted)
@@ -761,7 +897,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     const uint32_t ri = blockIdx.y;
     const int64_t tile = blockIdx.x;
     if (static_cast<uint64_t>(tile) * Gm::OWN_K >= call.rec[ri].w) return;
-    load_tile(ri, tile, xr);
+    if constexpr (!Gm::TABLE) load_tile(ri, tile, xr);
     run_tile(ri, tile, xr);
 #undef call
 }
@@ -788,7 +924,8 @@ template <int L, int M, int T1, int T2, int PW, int NTHR, int MODE, typename XT>
 void launch_fused_args(const FusedLaunch &a)
 {
     using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
-    const size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
+    size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
+    if constexpr (Gm::TABLE) lds = std::max<size_t>(a.table_lds_floats, Gm::W_LDS_FLOATS) * sizeof(float);
     constexpr auto kern = k_fused<L, M, T1, T2, PW, NTHR, XT, MODE>;
     ensure_dynamic_lds<kern>(lds);
     const unsigned tiles = static_cast<unsigned>((a.max_w + Gm::OWN_K - 1) / Gm::OWN_K);

@@ -17,6 +17,7 @@ struct FusedLaunch {
     const CallArgs *call;      // host copy; passed to the kernel by value
     const FusedParams *prm;    // device-resident parameters of the plan
     uint64_t max_w;            // longest recording of the call, work samples (sizes grid.x)
+    size_t table_lds_floats;   // TABLE mode: floats of LDS the table and the input tile take
 };
 
 // one function per instantiation, each in its own translation unit
@@ -30,6 +31,11 @@ void fused_launch_48k_fast_f32(const FusedLaunch &a);
 void fused_launch_48k_fast_i16(const FusedLaunch &a);
 void fused_launch_96k_fast_f32(const FusedLaunch &a);
 void fused_launch_96k_fast_i16(const FusedLaunch &a);
+// table-driven stage 1 + standard-profile work-rate stages, 512-thread workgroups
+void fused_launch_tab_std_f32(const FusedLaunch &a);
+void fused_launch_tab_std_i16(const FusedLaunch &a);
+void fused_launch_tab_std_fast_f32(const FusedLaunch &a);
+void fused_launch_tab_std_fast_i16(const FusedLaunch &a);
 #ifdef APT_WITH_PROBES
 // timing probes (make PROBES=1; APTGPU_PROBE_STOP=1..7; sources under tools/probes/): the fast 48 kHz f32
 // kernel cut off after a stage (1..5), or complete with 128 / 192-thread workgroups (6, 7)

@@ -124,7 +124,10 @@ struct aptgpu_plan {
     float inv_sinphi = 0.f;
     bool fused_f16 = false;   // APTGPU_MODE_FP16_TAPS served by the specialised fused kernel (fp16 stage 1)
     bool fused_fast = false;  // APTGPU_MODE_FAST served by the specialised fused kernel
-    int fused = 0;  // 0 unfused generic kernels, 1 compile-time specialised k_fused, 2 run-time k_fused_any
+    // 0 unfused generic kernels, 1 compile-time specialised k_fused, 2 run-time k_fused_any,
+    // 3 k_fused with the table-driven stage 1 (run-time l / m / taps, specialised work-rate stages)
+    int fused = 0;
+    apt::gpu::TableGeom table_geom{};
     int picker_force = 0;  // 0 parallel picker; APTGPU_FORCE_WALK=1 -> 1 (the sequential fallback)
 
     apt::DeviceBuffer<float> d_taps_resample, d_taps_lowpass, d_one, d_taps_branch, d_taps_lowpass_pairs, d_taps_any;

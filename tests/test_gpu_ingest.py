@@ -106,8 +106,8 @@ def _pcm16(x):
     (96000, 12, dict(), 1),
     (48000, 20, dict(extra_chunks=[(b"junk", b"abc")]), 1),           # misaligned payload -> staging + fused f32
     (48000, 20, dict(channels=2), 1),                                 # stereo: first channel only
-    (11025, 30, dict(), 2),                                           # run-time fused kernel, int16 input
-    (11025, 30, dict(extra_chunks=[(b"junk", b"abc")]), 2),          # odd payload address -> staging
+    (11025, 30, dict(), 3),                                           # table-driven stage 1, int16 input
+    (11025, 30, dict(extra_chunks=[(b"junk", b"abc")]), 3),          # odd payload address -> staging + f32 table path
     (48000, 20, dict(is_float=True), 1),
     (48000, 20, dict(bits=32), 1),
 ])

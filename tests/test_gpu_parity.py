@@ -290,14 +290,72 @@ def test_decode_alternate_paths(oracle, mode, monkeypatch):
 
 
 def test_fused_specialisations_are_used(ctx):
-    """48 kHz and 96 kHz (standard profile) run the compile-time specialised front end (1);
-    every other rate/profile the run-time fused kernel (2); l == 1 the unfused kernels (0)."""
+    """48 kHz and 96 kHz (standard profile) run the compile-time specialised front end (1); 11 025 Hz
+    and the other rates whose tap table and input tile fit run the table-driven stage 1 in front of
+    the specialised work-rate stages (3); the rest the run-time fused kernel (2); l == 1 the unfused
+    kernels (0)."""
     for rate, profile, want in ((48000, "standard", 1), (96000, "standard", 1), (44100, "standard", 2),
-                                (11025, "standard", 2), (48000, "fast", 2), (48000, "slow", 2),
-                                (24960, "standard", 0)):
+                                (11025, "standard", 3), (8000, "standard", 3), (22050, "standard", 2),
+                                (48000, "fast", 2), (48000, "slow", 2), (24960, "standard", 0)):
         _, st = apt.decode(ctx, apt.Settings.profile(profile), synth_apt(rate, 11, 3), apt.Rate.hz(rate),
                            True, return_stats=True)
         assert st.fused == want, (rate, profile)
+
+
+TABLE_CASES = [  # (rate, seconds): rates served by k_fused's table-driven stage 1 (fused == 3)
+    (11025, 40), (8000, 40), (12000, 20), (15600, 20), (20800, 15), (16000, 20), (11025, 11),
+]
+
+
+@pytest.mark.parametrize("rate,seconds", TABLE_CASES)
+@pytest.mark.parametrize("sync", [True, False])
+def test_table_stage1_bitexact(ctx, oracle, rate, seconds, sync):
+    x = synth_apt(rate, seconds, seed=rate % 97 + seconds)
+    want = oracle.decode(x, rate, sync)
+    got, st = apt.decode(ctx, apt.Settings(), x, apt.Rate.hz(rate), sync, return_stats=True)
+    assert st.fused == 3, (rate, st.l, st.m, st.n_resample_taps)
+    assert_bitexact(got, want, f"table stage 1 {rate} sync={sync}")
+
+
+def test_table_stage1_long_ragged_batched_and_pcm16(oracle):
+    """Many tiles, lengths that end mid-tile / mid-group, several recordings per call, PCM16 payloads at
+    odd byte offsets, and the fast mode's tolerance — all at 11 025 Hz."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    recs = [synth_apt(11025, 900, seed=5), synth_apt(11025, 20, seed=6)[:11025 * 20 - 3],
+            synth_apt(11025, 33, seed=7)[:11025 * 33 - 1], synth_apt(11025, 64, seed=8)]
+    wants = [oracle.decode(r, 11025, True, want_steps=True) for r in recs]
+    nmax = max(r.size for r in recs)
+    for mode in (apt.MODE_STRICT, apt.MODE_FAST):
+        plan = apt.Plan(apt.Settings(), apt.Rate.hz(11025), True, max_samples=nmax, max_batch=len(recs), mode=mode)
+        assert plan.info.fused == 3
+        d_in = [torch.from_numpy(r).to(dev) for r in recs]
+        cap = int(plan.info.max_rows)
+        d_out = [torch.empty(cap * 2080, dtype=torch.float32, device=dev) for _ in recs]
+        torch.cuda.synchronize()
+        for _ in range(2):
+            plan.decode_device([t.data_ptr() for t in d_in], [r.size for r in recs], [t.data_ptr() for t in d_out],
+                               [cap] * len(recs))
+        res = plan.results(len(recs))
+        for i, (want, st) in enumerate(wants):
+            got = d_out[i][:res[i].n_out].cpu().numpy()
+            if mode == apt.MODE_STRICT:
+                assert_bitexact(got, want, f"table batch {i}")
+                assert plan.sync_positions(i).tolist() == st["sync_pos"].tolist()
+            else:
+                from test_gpu_fast import check_tolerance
+                check_tolerance(got, plan.sync_positions(i), want, st["sync_pos"], f"table fast {i}")
+        if mode == apt.MODE_STRICT:
+            # the same recordings as PCM16 payloads, the second one at an odd 2-byte offset
+            pcm = [torch.from_numpy(np.concatenate([np.zeros(1 if i == 1 else 0, np.int16), r.astype(np.int16)])).to(dev)
+                   for i, r in enumerate(recs)]
+            ptrs = [t.data_ptr() + (2 if i == 1 else 0) for i, t in enumerate(pcm)]
+            specs = [apt.WavSpec(1, 16, 2, 0, 11025, 1, 0, 2 * r.size, r.size, r.size) for r in recs]
+            plan.decode_device_wav(ptrs, specs, [t.data_ptr() for t in d_out], [cap] * len(recs))
+            res = plan.results(len(recs))
+            for i, (want, _) in enumerate(wants):
+                assert_bitexact(d_out[i][:res[i].n_out].cpu().numpy(), want, f"table pcm16 {i}")
+        plan.close()
 
 
 ANY_CASES = [  # (rate, seconds, profile): the run-time fused kernel on every kind of geometry
