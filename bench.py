@@ -124,6 +124,9 @@ def main():
         # synchronisation after each, HIP events around every launch.  This per-launch duration
         # is what `roofline` uses (a launch in the timed region below shares the GPU with the
         # launches of the other calls in flight, so its duration there is not GPU time per launch).
+        for _ in range(48):  # (the host spent seconds generating inputs: bring the clocks up before timing anything)
+            step()
+        torch.cuda.synchronize()
         plan.enable_timing(2)
         for _ in range(24):
             step()
@@ -262,6 +265,42 @@ def main():
                 }
         pflags = plan.read_internal("picker_flags", np.uint32, 32)
 
+        # ---- the same K steps in APTGPU_MODE_FAST (reported NEXT TO the strict headline, never as `value`):
+        # same inputs, same batch, same warm-up / timing protocol, its own isolated kernel timing, and its
+        # tolerance check against the oracle further down
+        fast_leg = None
+        if args.mode == "strict" and not args.no_extras and not args.no_sync and rank == 0:
+            planf = apt.Plan(settings, rate, True, max_samples=n, max_batch=B, device=local_rank, mode=apt.MODE_FAST)
+            if planf.info.fused in (1, 3):
+                def fstep(j):
+                    planf.decode_device(sigs[j % n_inputs], nn, out, caps)
+                for j in range(24):
+                    fstep(j)
+                torch.cuda.synchronize()
+                planf.enable_timing(2)
+                for j in range(16):
+                    fstep(j)
+                    torch.cuda.synchronize()
+                f_iso = planf.collect_timing()
+                planf.enable_timing(0)
+                for j in range(args.warmup):
+                    fstep(j)
+                torch.cuda.synchronize()
+                f0 = time.perf_counter()
+                for j in range(args.steps):
+                    fstep(j)
+                torch.cuda.synchronize()
+                f1 = time.perf_counter()
+                fstep(0)
+                fres = planf.results(1)[0]
+                fpos = planf.sync_positions(0)
+                torch.cuda.synchronize()
+                fast_leg = {"elapsed": f1 - f0, "alone_ms": f_iso.get("fused_front_end", (0.0, 0))[0],
+                            "rows": d_rows[:fres.n_out].clone(), "pos": fpos, "n_rows": int(fres.n_rows)}
+            planf.close()
+            step(0)  # d_rows holds the strict rows of recording 0 again
+            plan.results(1)
+
     from noaa_apt_amd import shard
     # whole-job figures: MAX elapsed over ranks, SUM of samples over ranks (no other collective)
     elapsed, total_samples_per_step = shard.reduce_job(t1 - t0, float(n) * max(1, args.batch), device=dev)
@@ -386,6 +425,19 @@ def main():
         }
         if extras:
             line["extras"] = extras
+        if fast_leg:
+            f_ms = 1e3 * fast_leg["elapsed"] / args.steps
+            f_frac = b_alg / (fast_leg["alone_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if fast_leg["alone_ms"] > 0 else None
+            line["fast_mode"] = {
+                "what": "the same workload and protocol with the plan in APTGPU_MODE_FAST (f32; fused multiply-adds, "
+                        "native sqrt, pulse-sum sync correlation; tolerance of SURVEY.md 8(d)) - reported next to the "
+                        "strict headline, not part of `value`",
+                "value": round(float(n) * max(1, args.batch) * args.steps / fast_leg["elapsed"] / 1e6, 3),
+                "unit": "Msamples/s", "ms_per_step": round(f_ms, 5),
+                "roofline": {"bound": "hbm", "kernel": "fused_front_end", "kernel_avg_ms": round(fast_leg["alone_ms"], 5),
+                             "achieved": round(f_frac * HBM_PEAK_GBS, 2) if f_frac else None, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(f_frac, 5) if f_frac else None},
+            }
         if not args.no_cpu_baseline:
             from oracle import binding as oracle
             os_ = {k: getattr(settings, k) for k in ("work_rate", "resample_atten",
@@ -454,6 +506,18 @@ def main():
                                       f"max |err| / max |px| = {err:.2e} (tolerance 1e-4): {'within' if ok else 'OUTSIDE'} tolerance")
             else:
                 line["parity"] = "bit-exact vs oracle" if parity else "MISMATCH vs oracle"
+            if fast_leg:
+                fg = fast_leg["rows"].cpu().numpy()
+                same_shape = fg.size == ref.size
+                ferr = float(np.max(np.abs(fg - ref)) / np.max(np.abs(ref))) if same_shape and ref.size else float("nan")
+                wp, gp = st["sync_pos"].astype(np.int64), fast_leg["pos"].astype(np.int64)
+                off = np.abs(gp - wp) if gp.size == wp.size else np.array([99])
+                ok = bool(same_shape and off.max(initial=0) <= 1 and (off == 0).mean() >= 0.999
+                          and (ferr <= 1e-4 or (off != 0).any()))
+                line["fast_mode"]["parity"] = (
+                    f"rows {'equal' if same_shape else 'DIFFER'} in count, sync positions identical "
+                    f"{float((off == 0).mean()):.5f} (max off {int(off.max(initial=0))}), max |err| / max |px| = {ferr:.2e} "
+                    f"(tolerance 1e-4): {'within' if ok else 'OUTSIDE'} tolerance")
         print(json.dumps(line), flush=True)
     plan.close()
     if dist is not None:
