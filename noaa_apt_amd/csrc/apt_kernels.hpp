@@ -33,15 +33,20 @@ struct ImageResult {
     float values_a[16], values_b[16];
 };
 
-// Per-group record the front ends hand to the picker: maximum of the sync correlation over the
-// group's positions ignoring NaNs (position 0 clamped to >= 0: the picker starts from the peak
-// (0, 0.), decode.rs:208), and whether any position of the group is NaN.  A NaN position is never
-// exceeded (`corr > NaN` is false, decode.rs:250), so it is a terminal of the picker whatever the
-// finite values around it are: its group must reach the exact test even when the group's finite
-// maximum loses the coarse comparison.
+// Per-group record the front ends hand to the picker: an interval [lo, hi] that holds the maximum of
+// the sync correlation over the group's positions, NaNs ignored (position 0 clamped to >= 0: the picker
+// starts from the peak (0, 0.), decode.rs:208).  lo == hi where the front end evaluated the very
+// arithmetic the picker re-evaluates (fast mode, the unfused kernels, k_fused_any); the strict
+// specialised front ends bound the reference's 114-term chain from pulse sums (apt_kernels_fused_impl.hpp,
+// stage 4).  k_sync_nodes prunes a group only when a later group's lo exceeds its hi, and settles every
+// comparison the bounds leave open with the exact chain: the intervals only decide how much is
+// re-evaluated, never the result.
+// [-inf, +inf] marks a group that must reach the exact test whatever its neighbours hold: one with a NaN
+// position (never exceeded — `corr > NaN` is false, decode.rs:250 — so a terminal of the picker whatever
+// the finite values around it are), or one whose F window is not finite.
 struct GroupMax {
-    float max;
-    float has_nan;  // 0.f or 1.f
+    float hi;
+    float lo;
 };
 
 // ---- one decode_device call = one launch per stage over all its recordings -----------
@@ -122,6 +127,8 @@ void fused_lowpass_pairs(const float *h2, uint32_t t2, float *h2p);
 uint32_t fused_f16_table_dwords(uint32_t l, uint32_t m, uint32_t t1);
 float fused_f16_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, uint32_t *table);
 bool fused_f16_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
+// strict front ends: |pulse-sum correlation - sequential chain| <= fused_gm_slack(pw) * sum|F| (see stage 4)
+float fused_gm_slack(uint32_t pw);
 // fast mode (APTGPU_MODE_FAST): availability (same tables as strict)
 bool fused_fast_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
 // Per-plan parameters of the specialised front end, resident in HBM (the kernel fetches each when
@@ -144,8 +151,8 @@ struct FusedParams {
     float cosphi2, sinphi;
     float inv_sinphi;       // strict: verified RN(1/sinphi) or 0 (apt_envelope.hpp); fast: RN(1/sinphi)
     float f16_unscale;      // 2^-s of the fp16 tap prescale (fp16-tap mode)
-    int32_t want_gm;        // sync search wanted: emit the per-group correlation maxima
-    int32_t reserved;
+    int32_t want_gm;        // sync search wanted: emit the per-group bounds of the correlation maxima
+    float gm_slack;         // strict modes: half-width of a group's bounds per unit of sum|F| (fused_gm_slack)
     const float *table;     // TABLE mode: phase-major tap table [l][tpp] (fused_any_table)
     TableGeom tab;
 };

@@ -130,6 +130,21 @@ bool fused_f16_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint3
     return l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3;
 }
 
+// Bound on |a - c| / sum|F| for a = the pulse-sum evaluation and c = the reference's sequential chain of
+// the 38*pw-term sync correlation: gamma(38 pw - 1) + gamma(pw + 18) with gamma(k) = k u / (1 - k u),
+// u = 2^-24, plus 3 % for the rounding of the bound's own arithmetic (the sum of |F|, the product, the
+// two additions that form lo and hi: < 40 u relative).  APTGPU_GM_SLACK_SCALE (tests) widens it so that
+// the picker's exact settlement of open comparisons is exercised on ordinary inputs.
+float fused_gm_slack(uint32_t pw)
+{
+    float scale = 1.f;
+    if (const char *e = std::getenv("APTGPU_GM_SLACK_SCALE")) {
+        const float v = std::strtof(e, nullptr);
+        if (v >= 1.f) scale = v;
+    }
+    return static_cast<float>(38u * pw - 1u + pw + 18u) * 1.03f * 0x1p-24f * 1.0001f * scale;
+}
+
 bool fused_fast_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
 {
     return fused_supported(l, m, t1, t2, pw);

@@ -371,7 +371,7 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
     __syncthreads();
 
     // ---- stage 5b: group maxima (the correlation itself stays on the CU: k_sync_nodes re-evaluates
-    // it for the candidate groups).  NaNs are left out of the maximum and reported separately.
+    // it for the candidate groups).  NaNs are left out of the maximum and reported as [-inf, +inf] bounds.
     for (uint32_t g = tid; g < G.own / kGS; g += NTHR) {
         const uint64_t k = static_cast<uint64_t>(o0) + static_cast<uint64_t>(g) * kGS;
         if (k >= n_corr) break;
@@ -390,7 +390,9 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
                 has_nan = has_nan || (v != v);
             }
         }
-        gm_out[static_cast<uint64_t>(o0) / kGS + g] = GroupMax{mx, has_nan ? 1.f : 0.f};
+        // exact values: lo = hi; a group with a NaN position must reach the picker's exact test
+        gm_out[static_cast<uint64_t>(o0) / kGS + g] =
+            has_nan ? GroupMax{__builtin_huge_valf(), -__builtin_huge_valf()} : GroupMax{mx, mx};
     }
 }
 

@@ -77,14 +77,14 @@ struct FusedGeom {
     static constexpr int D_OFF = (TILE_K + G + 3) & ~3;
     static constexpr int XT_LDS = XB == 2 ? (XT_PAD / 2 + 4) : XT_PAD;  // floats of LDS under the x tile
     // (+36*PW: the fast correlation's pulse-sum window of the last thread reaches past the tile)
-    static constexpr int LDS_FLOATS = XT_LDS > (D_OFF + TILE_K + 36 * PW) ? XT_LDS : (D_OFF + TILE_K + 36 * PW);
+    // (+NTHR: the per-thread |F| sums behind the strict modes' bounds of the group maxima)
+    static constexpr int W_LDS_FLOATS = D_OFF + TILE_K + 36 * PW + NTHR;  // what the work-rate stages need
+    static constexpr int LDS_FLOATS = XT_LDS > W_LDS_FLOATS ? XT_LDS : W_LDS_FLOATS;
     static constexpr int GS = 4 * L;                                  // correlation group size
     static constexpr int NP = L / 2;                                  // accumulator pairs (+1 single if L odd)
     static constexpr int PS = NP;                                     // f2 tap entries per window sample
     static constexpr int HL_OFF = 2 * ((CLAST + (T1 + L - 1) / L) * NP);  // float offset of the odd branch's taps
     static constexpr int DW = L + T2 - 1;                             // envelope window per thread
-    // TABLE mode: floats of LDS the work-rate stages need (the table + input tile may need more: launch time)
-    static constexpr int W_LDS_FLOATS = D_OFF + TILE_K + 36 * PW;
     static_assert(PRE_K >= T2 + 1, "pre-halo too small for the low-pass");
     static_assert((kFusedThreads - kPreThreads - kOwnThreads) * L >= G - 1, "post-halo too small");
     static_assert(OWN_K % 4 == 0, "owned range must be float4-aligned");
@@ -773,32 +773,55 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         }
     }
     if constexpr (APT_FUSED_STOP == 5) return;
-    // ---- stage 4: sync cross-correlation (decode.rs:225-233) -> per-group maxima.  The correlation
-    // itself never leaves the CU: k_sync_nodes re-evaluates it (same arithmetic, apt_sync_corr.hpp)
-    // for the few candidate groups the picker has to look at.
+    // ---- stage 4: sync cross-correlation (decode.rs:225-233) -> per-group bounds of its maximum.
+    // The correlation itself never leaves the CU: k_sync_nodes re-evaluates it (apt_sync_corr.hpp) for
+    // the few candidate groups the picker has to look at, so all the front end owes the picker is, per
+    // group of GS positions, an interval [lo, hi] that holds the group's maximum.  Every mode gets it from
+    // pulse sums (22 operations per position instead of the 114 of the reference's chain):
+    //   fast    the pulse-sum value IS that mode's correlation: lo = hi = max.
+    //   strict  the pulse-sum value a and the reference's sequentially rounded chain c are two
+    //           floating-point evaluations of the same sum of 38*PW terms +-F[i+j]; with u = 2^-24,
+    //           |c - S| <= gamma(38*PW - 1) * sum|F|  (first term exact) and |a - S| <= gamma(21) * sum|F|
+    //           (an F passes through at most 3 + 18 rounded additions), so |a - c| <= slack * A with
+    //           slack = 138 u at PW = 3 (fused_gm_slack: 134 u plus 3 % for the bound's own roundings) and
+    //           A = sum of |F| over the group's whole window.  No underflow term: floating-point
+    //           additions of subnormals are exact.  lo = max - slack*A, hi = max + slack*A; k_sync_nodes
+    //           prunes with lo against hi and settles what the bounds cannot with the exact chain.
+    //   a group whose window holds a non-finite F (NaN, +-Inf, or an overflowing sum) — where the two
+    //   evaluations may disagree about WHERE the NaNs are — gets [-inf, +inf]: always evaluated, never
+    //   pruning anything.
     if (want_gm) {
         GroupMax *__restrict__ gm_out = slots[slot_late].gm;
         float c[L];
-        if constexpr (FAST) {
-            // pulse sums of the thread's own L positions -> Q (D is dead), then 19 terms per output
-            constexpr int PUL = 2 * PW;
-            {
-                const float *src = P + tid * L;
-                float fw[L + PUL - 1];
+        constexpr int PUL = 2 * PW;
+        float *AB = lds + Gm::D_OFF + Gm::TILE_K + 36 * PW;  // [NTHR] per-thread sums of |F|
+        {
+            // pulse sums of the thread's own L positions -> Q (D is dead)
+            const float *src = P + tid * L;
+            float fw[L + PUL - 1];
 #pragma unroll
-                for (int e = 0; e < L + PUL - 1; ++e) fw[e] = src[e];  // (past the tile: unused garbage)
-                float b2[L + PUL - 2];
+            for (int e = 0; e < L + PUL - 1; ++e) fw[e] = src[e];  // (past the tile: unused garbage)
+            float b2[L + PUL - 2];
 #pragma unroll
-                for (int e = 0; e < L + PUL - 2; ++e) b2[e] = fw[e] + fw[e + 1];
+            for (int e = 0; e < L + PUL - 2; ++e) b2[e] = fw[e] + fw[e + 1];
 #pragma unroll
-                for (int b = 0; b < L; ++b) {
-                    float bs = b2[b] + b2[b + 2];
+            for (int b = 0; b < L; ++b) {
+                float bs = b2[b] + b2[b + 2];
 #pragma unroll
-                    for (int t = 2; t < PW; ++t) bs = bs + b2[b + 2 * t];
-                    Q[tid * L + b] = bs;
-                }
+                for (int t = 2; t < PW; ++t) bs = bs + b2[b + 2 * t];
+                Q[tid * L + b] = bs;
             }
-            __syncthreads();
+            if constexpr (!FAST) {
+                float a = 0.f;
+#pragma unroll
+                for (int b = 0; b < L; ++b)
+                    a = a + ((kq + b >= k_lo && kq + b < k_hi) ? __builtin_fabsf(fw[b]) : 0.f);
+                AB[tid] = a;
+            }
+        }
+        __syncthreads();
+        {
+            // 19 signed pulse sums per position
             constexpr int BW = L + 18 * PUL;  // pulse-sum window per thread
             constexpr int CH4 = 11;
             const float *src = Q + tid * L;
@@ -823,54 +846,9 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 });
                 __builtin_amdgcn_sched_barrier(0);
             });
-        } else {
-        // F sample q meets output b at template index j = q - b: outputs (b, b+1) add the
-        // same sample with the signs of T[j] and T[j-1] (neg_lo / neg_hi modifiers).
-        constexpr int CH4 = 6;
-        const float *src = P + tid * L;
-        f2 ca[Gm::NP > 0 ? Gm::NP : 1];
-        float cl = 0.f;
-#pragma unroll
-        for (int pp = 0; pp < Gm::NP; ++pp) ca[pp] = (f2){0.f, 0.f};
-        static_for<0, (Gm::FWIN + CH4 - 1) / CH4>([&](auto cc) {
-            constexpr int q0 = decltype(cc)::value * CH4;
-            float fv[CH4];
-#pragma unroll
-            for (int e = 0; e < CH4; ++e) fv[e] = (q0 + e < Gm::FWIN) ? src[q0 + e] : 0.f;
-            static_for<0, CH4>([&](auto ee) {
-                constexpr int q = q0 + decltype(ee)::value;
-                if constexpr (q < Gm::FWIN) {
-                    const float v = fv[decltype(ee)::value];
-                    static_for<0, Gm::NP>([&](auto pc) {
-                        constexpr int pp = decltype(pc)::value;
-                        constexpr int jx = q - 2 * pp, jy = q - 2 * pp - 1;
-                        constexpr bool va = jx >= 0 && jx < Gm::G;
-                        constexpr bool vb = jy >= 0 && jy < Gm::G;
-                        if constexpr (va && vb) {
-                            ca[pp] = ca[pp] + (f2){sync_plus<PW>(jx) ? v : -v, sync_plus<PW>(jy) ? v : -v};
-                        } else if constexpr (va) {
-                            ca[pp].x = sync_plus<PW>(jx) ? ca[pp].x + v : ca[pp].x - v;
-                        } else if constexpr (vb) {
-                            ca[pp].y = sync_plus<PW>(jy) ? ca[pp].y + v : ca[pp].y - v;
-                        }
-                    });
-                    if constexpr (L & 1) {
-                        constexpr int jl = q - (L - 1);
-                        if constexpr (jl >= 0 && jl < Gm::G) cl = sync_plus<PW>(jl) ? cl + v : cl - v;
-                    }
-                }
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-#pragma unroll
-        for (int pp = 0; pp < Gm::NP; ++pp) {
-            c[2 * pp] = ca[pp].x;
-            c[2 * pp + 1] = ca[pp].y;
         }
-        if constexpr (L & 1) c[L - 1] = cl;
-        }
-        // maximum over the group's positions, NaNs left out and reported separately (a NaN position
-        // is a terminal of the picker, decode.rs:250, whatever the finite maximum of its group is)
+        // maximum over the group's positions, NaNs left out and reported through the bounds (a NaN
+        // position is a terminal of the picker, decode.rs:250, whatever the finite maximum of its group is)
         float mx = kNegInfF;
         bool has_nan = false;
 #pragma unroll
@@ -888,8 +866,29 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         int hn = has_nan ? 1 : 0;
         hn |= __shfl_xor(hn, 1, 64);
         hn |= __shfl_xor(hn, 2, 64);
-        if ((tid & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads && kq < c_hi)
-            gm_out[o0 / Gm::GS + (tid - kPreThreads) / 4] = GroupMax{mx, hn ? 1.f : 0.f};
+        if ((tid & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads && kq < c_hi) {
+            float hi = mx, lo = mx;
+            if constexpr (!FAST) {
+                // |F| over the group's window: the threads that hold positions kq .. kq + GS + G - 2
+                constexpr int NT = (Gm::GS + Gm::G - 1 + L - 1) / L;
+                static_assert(NT - 1 <= 3 + kPostThreads, "the |F| window must end inside the tile");
+                float av[NT];
+#pragma unroll
+                for (int e = 0; e < NT; ++e) av[e] = AB[tid + e];
+                float A = av[0];
+#pragma unroll
+                for (int e = 1; e < NT; ++e) A = A + av[e];
+                const float err = A * late->gm_slack;
+                if (!(err < __builtin_huge_valf())) hn = 1;  // NaN or Inf somewhere in the window
+                hi = mx + err;
+                lo = mx - err;
+            }
+            if (hn) {
+                hi = __builtin_huge_valf();
+                lo = kNegInfF;
+            }
+            gm_out[o0 / Gm::GS + (tid - kPreThreads) / 4] = GroupMax{hi, lo};
+        }
     }
     };  // run_tile
 

@@ -30,12 +30,17 @@
 //
 // Kernels (GS = 52 correlation positions per group; md = 32*pw groups, spr = 40*pw groups):
 //   k_group_max   corr -> GM (unfused path only; the fused front end emits GM itself)
-//   k_sync_nodes  coarse: a group can hold a terminal only if GM[g] is not exceeded by the
-//                 next md/GS-1 group maxima (or it holds a NaN); fine: exact test on the few
-//                 candidates, whose correlation values are RE-EVALUATED from F with the front
-//                 end's own arithmetic (apt_sync_corr.hpp) — the fused front ends never write
-//                 the correlation to HBM; emits terminal words (fallback input) and ordered
-//                 node-terminal lists
+//   k_sync_nodes  coarse: GM[g] = [lo, hi] bounds the maximum of group g (lo = hi where the front
+//                 end evaluated the exact arithmetic; [-inf, +inf] = holds a NaN / not finite).  A
+//                 group can hold a terminal only if its hi is not exceeded by the lo of one of the
+//                 next md/GS-1 groups; fine: exact test on the few candidates, whose correlation
+//                 values are RE-EVALUATED from F (apt_sync_corr.hpp: the reference's chain, or the
+//                 fast mode's pulse sums) — the fused front ends never write the correlation to
+//                 HBM.  Where the bounds of the groups in between leave a candidate position's
+//                 comparison open (lo <= corr < hi: bounds from the strict front ends' pulse sums,
+//                 a few 1e-6 wide, or NaN groups), those groups are evaluated exactly too: the
+//                 result never depends on the bounds.  Emits terminal words (fallback input) and
+//                 ordered node-terminal lists
 //   k_sync_orbit  one workgroup per recording: builds the functional graph over start nodes,
 //                 extracts the orbit of the root (directly when the recording is confluent,
 //                 else by pointer doubling), writes the peak list and the result record;
@@ -47,6 +52,8 @@
 #include "apt_sync_corr.hpp"
 
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 namespace apt::gpu {
 
@@ -74,7 +81,7 @@ k_group_max(const float *__restrict__ corr, uint64_t n_corr, GroupMax *__restric
             has_nan = has_nan || (v != v);
         }
     }
-    gm[g] = GroupMax{mx, has_nan ? 1.f : 0.f};
+    gm[g] = has_nan ? GroupMax{-kNegInf, kNegInf} : GroupMax{mx, mx};  // exact values: lo = hi
 }
 
 // ------------------------------------------------------------------ k_sync_nodes
@@ -85,9 +92,65 @@ constexpr int kSlotCap = 64;       // node terminals kept per chunk before "over
 constexpr uint32_t kNanStartTag = 0x80000000u;  // slot entry = NaN position: only matches a search starting on it
 constexpr uint32_t kPosMask = 0x7FFFFFFFu;      // (positions are < 2^31: longer recordings take the walk)
 
-// floats of LDS one wave needs to re-evaluate the correlation of one candidate: two F windows
-// (the candidate group and the group md ahead) of GS + 38*pw - 1 samples each
+// floats of LDS one wave needs to re-evaluate the correlation of one group: an F window of
+// GS + 38*pw - 1 samples
 __host__ __device__ constexpr uint32_t nodes_window(uint32_t pw) { return (GS + 38u * pw - 1u + 3u) & ~3u; }
+
+// bytes of dynamic LDS of k_sync_nodes for r = md/GS groups of look-ahead: terminal words, hi and lo
+// bounds, window maxima, candidate list | NaN words | one F window per wave
+__host__ __device__ constexpr uint32_t nodes_nanw_ofs(uint32_t r)
+{
+    return ((kChunkGroups + r + 1) * (8u + 4u + 2u) + (kChunkGroups + 2 * r + 2) * 8u + 15u) & ~15u;
+}
+__host__ __device__ constexpr uint32_t nodes_win_ofs(uint32_t r)
+{
+    return (nodes_nanw_ofs(r) + (kChunkGroups + r + 1) * 8u + 15u) & ~15u;
+}
+
+// correlation of the 52 positions of a group from its F window in `win` (LDS, owned by one wave: its
+// LDS operations complete in program order, and the compiler keeps stores and loads of the same array
+// in order, so no barrier is needed between filling a window and reading it; wave_barrier() only pins
+// the phases for the scheduler).  fast: from pulse sums formed in place, exactly as the fast front end
+// does; else the reference's chain.  Lanes with !on return -inf.
+template <int NL, int PWC>
+__device__ __forceinline__ float nodes_eval_window(float *win, bool on, int lane, uint32_t pw, int fast)
+{
+    constexpr int NLR = NL > 0 ? NL : 1;
+    float c = kNegInf;
+    if (fast) {
+        // pulse sums in place: every value a lane needs is read before anything is written
+        const uint32_t blen = GS + 36u * pw;  // positions whose pulse sum is used
+        if constexpr (NL > 0) {
+            float bs[NLR];
+#pragma unroll
+            for (int t = 0; t < NL; ++t) {
+                const uint32_t pq = lane + 64u * t;
+                bs[t] = pq < blen ? sync_pulse_sum(pw, [&](uint32_t j) { return win[pq + j]; }) : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < NL; ++t) {
+                const uint32_t pq = lane + 64u * t;
+                if (pq < blen) win[pq] = bs[t];
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            // any pulse width: ascending sweeps of 64 positions; a sweep only overwrites positions
+            // below the ones later sweeps read
+            for (uint32_t p0 = 0; p0 < blen; p0 += 64) {
+                const uint32_t pq = p0 + lane;
+                const float bs = pq < blen ? sync_pulse_sum(pw, [&](uint32_t j) { return win[pq + j]; }) : 0.f;
+                __builtin_amdgcn_wave_barrier();
+                if (pq < blen) win[pq] = bs;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (on) c = sync_corr_from_pulses([&](int k) { return win[lane + k * 2 * pw]; });
+    } else {
+        if (on) c = sync_corr_strict(pw, [&](uint32_t j) { return win[lane + j]; });
+    }
+    return c;
+}
 
 // NL: 64-lane loads per F window kept in registers while a wave has four candidates in flight
 // (window <= 64*NL samples); 0: any window, one candidate at a time straight into LDS.
@@ -116,23 +179,20 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
     uint32_t *__restrict__ flags = sp.flags;
 
     // window of groups [gw0, gw0 + nwin): gw0 = g0 - R - 1, nwin = CG + R + 1.  LDS is sized
-    // at launch for the actual R and pw (7 KB at R = 96, pw = 3) so these workgroups fit beside
+    // at launch for the actual R and pw (8.9 KB at R = 96, pw = 3) so these workgroups fit beside
     // the front end of the next recording, which leaves only ~9 KB of LDS free per CU.
     extern __shared__ uint64_t lds_nodes[];
     const int R = static_cast<int>(r_groups);
     uint64_t *s_words = lds_nodes;                                           // [CG + R + 1]
-    float *s_gm = reinterpret_cast<float *>(s_words + (kChunkGroups + R + 1));  // [CG + 2R + 2]
-    float *s_wm = s_gm + (kChunkGroups + 2 * R + 2);                         // [CG + R + 1]
+    float *s_hi = reinterpret_cast<float *>(s_words + (kChunkGroups + R + 1));  // [CG + 2R + 2] upper bounds
+    float *s_lo = s_hi + (kChunkGroups + 2 * R + 2);                         // [CG + 2R + 2] lower bounds
+    float *s_wm = s_lo + (kChunkGroups + 2 * R + 2);                         // [CG + R + 1]
     uint16_t *s_cand = reinterpret_cast<uint16_t *>(s_wm + (kChunkGroups + R + 1));  // [CG + R + 1]
-    uint8_t *s_nan = reinterpret_cast<uint8_t *>(s_cand + (kChunkGroups + R + 1));   // [CG + R + 1]
     const uint32_t wlen = nodes_window(pw);
-    // NaN bits of the groups of the window, then per wave two F windows (16-byte aligned; plain
+    // NaN bits of the groups of the window, then one F window per wave (16-byte aligned; plain
     // pointer arithmetic keeps these LDS accesses)
-    const uint32_t nanw_ofs = (static_cast<uint32_t>(kChunkGroups + R + 1) * 15u +
-                               static_cast<uint32_t>(kChunkGroups + 2 * R + 2) * 4u + 15u) & ~15u;
-    uint64_t *s_nanw = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(lds_nodes) + nanw_ofs);  // [CG + R + 1]
-    const uint32_t win_ofs = (nanw_ofs + static_cast<uint32_t>(kChunkGroups + R + 1) * 8u + 15u) & ~15u;
-    float *s_win = reinterpret_cast<float *>(reinterpret_cast<char *>(lds_nodes) + win_ofs);
+    uint64_t *s_nanw = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(lds_nodes) + nodes_nanw_ofs(r_groups));  // [CG + R + 1]
+    float *s_win = reinterpret_cast<float *>(reinterpret_cast<char *>(lds_nodes) + nodes_win_ofs(r_groups));
     __shared__ uint32_t s_ncand;
     __shared__ uint32_t s_scan[kNodesWaves];
 
@@ -153,32 +213,32 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
     for (int q = tid; q < nwin + R; q += kNodesThreads) {
         const int64_t g = gw0 + q;
         const bool in = g >= 0 && g < static_cast<int64_t>(ng);
-        const GroupMax v = in ? gm[g] : GroupMax{kNegInf, 0.f};
-        s_gm[q] = v.max;
-        if (q < nwin) s_nan[q] = v.has_nan != 0.f ? 1 : 0;
+        const GroupMax v = in ? gm[g] : GroupMax{kNegInf, kNegInf};
+        s_hi[q] = v.hi;
+        s_lo[q] = v.lo;
     }
     __syncthreads();
 
-    // coarse: WM[g] = max(GM[g+1 .. g+R-1]) — the full groups inside every window of group g — as a
+    // coarse: WM[g] = max(lo[g+1 .. g+R-1]) — the full groups inside every window of group g — as a
     // sliding-window maximum by the two-block method: with blocks of W = R-1 groups, a window is the
     // suffix maximum of its first block from its start plus the prefix maximum of its second block up to
     // its end.  Each block's two scans are one wave's work (shuffles); the suffix maxima borrow the NaN
     // words' LDS until the windows are combined.
     {
         const int W = R - 1;              // window length, >= 1 for every legal md
-        const int N = nwin + R;           // entries of s_gm
+        const int N = nwin + R;           // entries of s_lo
         float *s_suf = reinterpret_cast<float *>(s_nanw);  // [nwin + 1], dead before s_nanw is zeroed
         const int per = (W + 63) / 64;    // consecutive elements per lane (<= 8: md <= 26 k samples, the plan checks)
         for (int blk = wave; blk * W < N; blk += kNodesWaves) {
             const int p0 = blk * W;
-            // forward: pre[p] = max(s_gm[p0 .. p]) -> s_wm[p - W] (the window that ENDS at p starts at p - W + 1)
+            // forward: pre[p] = max(s_lo[p0 .. p]) -> s_wm[p - W] (the window that ENDS at p starts at p - W + 1)
             {
                 float loc[8];
                 float run = kNegInf;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const int e = lane * per + t;
-                    if (t < per && e < W && p0 + e < N) run = fmaxf(run, s_gm[p0 + e]);
+                    if (t < per && e < W && p0 + e < N) run = fmaxf(run, s_lo[p0 + e]);
                     loc[t] = run;
                 }
                 float inc = run;
@@ -196,14 +256,14 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
                         s_wm[pidx - W] = fmaxf(loc[t], carry);
                 }
             }
-            // backward: suf[p] = max(s_gm[p .. block end]) -> s_suf[p]
+            // backward: suf[p] = max(s_lo[p .. block end]) -> s_suf[p]
             {
                 float loc[8];
                 float run = kNegInf;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const int e = W - 1 - (lane * per + t);  // walk the block from its end
-                    if (t < per && e >= 0 && p0 + e < N) run = fmaxf(run, s_gm[p0 + e]);
+                    if (t < per && e >= 0 && p0 + e < N) run = fmaxf(run, s_lo[p0 + e]);
                     loc[t] = run;
                 }
                 float inc = run;
@@ -229,8 +289,9 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
             const float wm = fmaxf(s_suf[q + 1], s_wm[q]);
             s_wm[q] = wm;
             const bool valid = g >= 0 && g < static_cast<int64_t>(ng);
-            // a group that holds a NaN is evaluated too: its NaN positions may be starts (see the top)
-            if (valid && (!(wm > s_gm[q]) || s_nan[q])) s_cand[atomicAdd(&s_ncand, 1u)] = static_cast<uint16_t>(q);
+            // pruned only when a later group certainly holds more than this one possibly does (a group
+            // that holds a NaN has hi = +inf: its NaN positions may be starts, see the top)
+            if (valid && !(wm > s_hi[q])) s_cand[atomicAdd(&s_ncand, 1u)] = static_cast<uint16_t>(q);
         }
         __syncthreads();
         for (int q = tid; q < nwin; q += kNodesThreads) {
@@ -246,49 +307,110 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
     const uint32_t ncand = s_ncand;
     constexpr int kBatch = NL > 0 ? 4 : 1;
     constexpr int NLR = NL > 0 ? NL : 1;
-    // One wave owns a window pair: its LDS operations complete in program order, and the compiler
-    // keeps stores and loads of the same array in order (they may alias), so no barrier is needed
-    // between filling a window and reading it; wave_barrier() only pins the phases for the scheduler.
-    float *wa = s_win + static_cast<size_t>(wave) * 2 * wlen;  // window of the candidate group
-    float *wb = wa + wlen;                                     // ... of the group md ahead
+    constexpr uint16_t kDeferred = 0x8000u;  // s_cand entry: to be settled in the second pass
+    float *wa = s_win + static_cast<size_t>(wave) * wlen;  // this wave's F window
     const uint32_t wneed = GS + 38u * pw - 1u;  // samples of a window
-    // correlation of the 52 positions of the group starting at `base` from the F window in `win`
-    auto eval_window = [&](float *win, bool on) -> float {
-        float c = kNegInf;
-        if (fast) {
-            // pulse sums in place: every value a lane needs is read before anything is written
-            const uint32_t blen = GS + 36u * pw;  // positions whose pulse sum is used
-            if constexpr (NL > 0) {
-                float bs[NLR];
-#pragma unroll
-                for (int t = 0; t < NL; ++t) {
-                    const uint32_t pq = lane + 64u * t;
-                    bs[t] = pq < blen ? sync_pulse_sum(pw, [&](uint32_t j) { return win[pq + j]; }) : 0.f;
-                }
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int t = 0; t < NL; ++t) {
-                    const uint32_t pq = lane + 64u * t;
-                    if (pq < blen) win[pq] = bs[t];
-                }
-                __builtin_amdgcn_wave_barrier();
-            } else {
-                // any pulse width: ascending sweeps of 64 positions; a sweep only overwrites positions
-                // below the ones later sweeps read
-                for (uint32_t p0 = 0; p0 < blen; p0 += 64) {
-                    const uint32_t pq = p0 + lane;
-                    const float bs = pq < blen ? sync_pulse_sum(pw, [&](uint32_t j) { return win[pq + j]; }) : 0.f;
-                    __builtin_amdgcn_wave_barrier();
-                    if (pq < blen) win[pq] = bs;
-                    __builtin_amdgcn_wave_barrier();
+    // F window of the group at `base` -> wa -> its correlation values
+    auto eval_group = [&](uint64_t base, bool on) -> float {
+        for (uint32_t t = lane; t < wlen; t += 64) {
+            const uint64_t j = base + t;
+            wa[t] = (t < wneed && j < w) ? fsig[j] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float v = nodes_eval_window<NL, PWC>(wa, on, lane, pw, fast);
+        __builtin_amdgcn_wave_barrier();
+        return v;
+    };
+    // Terminal word of candidate group q (window-relative) from its correlation values cv (c2v: those of
+    // the positions md ahead if already known, else -inf).  The full groups in between, g+1 .. g+R-1,
+    // exceed corr[i] for certain when the largest of their lower bounds does, and do not for certain
+    // when none of their upper bounds does; what the bounds leave open is settled by evaluating every
+    // group in between that could matter — with EXACT; without, the candidate is handed back (false) for
+    // the second pass, so that the four-candidates-in-flight loop stays free of that (rare) code.
+    auto settle = [&](auto exact_tag, int q, float cv, float c2v, bool in_v) -> bool {
+        constexpr bool EXACT = decltype(exact_tag)::value;
+        const uint64_t base = static_cast<uint64_t>(gw0 + q) * GS;
+        const bool in2 = in_v && base + lane + md < n_corr;
+        if (in_v && gw0 + q == 0 && lane == 0 && !(cv > 0.f)) cv = 0.f;  // the peak (0, 0.)
+        // NaN: remembered for the start test, -inf for every comparison
+        const unsigned long long nanword = __ballot(in_v && cv != cv) & kGroupMask;
+        if (cv != cv) cv = kNegInf;
+        // suffix max over lanes > lane (rest of this group)
+        float sfx = cv;
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_down(sfx, d, 64);
+            if (lane + d < 64) sfx = fmaxf(sfx, o);
+        }
+        float sfx_ex = __shfl_down(sfx, 1, 64);
+        if (lane == 63) sfx_ex = kNegInf;
+        float wm = s_wm[q];
+        const bool open_lo = in_v && !(sfx_ex > cv) && !(wm > cv);
+        if (__ballot(open_lo) != 0ull) {
+            float wm_hi = kNegInf;
+            for (int h = q + 1 + lane; h < q + R; h += 64) wm_hi = fmaxf(wm_hi, s_hi[h]);
+            for (int d = 32; d >= 1; d >>= 1) wm_hi = fmaxf(wm_hi, __shfl_xor(wm_hi, d, 64));
+            const bool open = open_lo && wm_hi > cv;
+            if (__ballot(open) != 0ull) {
+                if constexpr (!EXACT) {
+                    return false;
+                } else {
+                    // exact maximum (NaNs left out) over the groups in between whose upper bound exceeds the
+                    // smallest open value: the others cannot exceed any open position
+                    float thr = open ? cv : -kNegInf;
+                    for (int d = 32; d >= 1; d >>= 1) thr = fminf(thr, __shfl_xor(thr, d, 64));
+                    float ex = kNegInf;
+#pragma unroll 1
+                    for (int h0 = q + 1; h0 < q + R; h0 += 64) {
+                        // 64 groups per look: on APT data one or two of the 95 in between are above the threshold
+                        unsigned long long todo = __ballot(h0 + lane < q + R && s_hi[h0 + lane] > thr);
+                        while (todo) {
+                            const int h = h0 + __ffsll(static_cast<long long>(todo)) - 1;
+                            todo &= todo - 1;
+                            const int64_t gh = gw0 + h;  // >= 1
+                            if (gh >= static_cast<int64_t>(ng)) break;
+                            const uint64_t hb = static_cast<uint64_t>(gh) * GS;
+                            const bool on = lane < GS && hb + lane < n_corr;
+                            float v = kNegInf;
+                            if (corr != nullptr) {
+                                if (on) v = corr[hb + lane];
+                            } else {
+                                v = eval_group(hb, on);
+                            }
+                            if (v != v) v = kNegInf;
+                            ex = fmaxf(ex, v);
+                        }
+                    }
+                    for (int d = 32; d >= 1; d >>= 1) ex = fmaxf(ex, __shfl_xor(ex, d, 64));
+                    if (open) wm = ex;
+                    if (lane == 0) atomicAdd(&flags[7], 1u);  // how often the bounds were not enough (tests, tuning)
                 }
             }
-            if (on) c = sync_corr_from_pulses([&](int k) { return win[lane + k * 2 * pw]; });
-        } else {
-            if (on) c = sync_corr_strict(pw, [&](uint32_t j) { return win[lane + j]; });
         }
-        return c;
+        float wmax = fmaxf(sfx_ex, wm);
+        // the group md ahead: its positions up to this lane's offset belong to the window.  None of them
+        // can exceed corr[i] unless the group's maximum does, so it is only evaluated when some lane
+        // that is still a terminal so far is below the upper bound of that maximum (on APT data: almost
+        // never).
+        const float gm_ahead = s_hi[q + R];
+        if (corr == nullptr && __ballot(in2 && !(wmax > cv) && gm_ahead > cv) != 0ull) c2v = eval_group(base + md, in2);
+        if (c2v != c2v) c2v = kNegInf;
+        // prefix max over lanes <= lane of the group md positions ahead
+        float pfx = c2v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_up(pfx, d, 64);
+            if (lane >= d) pfx = fmaxf(pfx, o);
+        }
+        wmax = fmaxf(wmax, pfx);
+        const bool term = in_v && !(wmax > cv);
+        const unsigned long long word = __ballot(term) & kGroupMask;
+        if (lane == 0) {
+            s_words[q] = word;
+            s_nanw[q] = nanword;
+        }
+        __builtin_amdgcn_wave_barrier();
+        return true;
     };
+    bool any_deferred = false;
     for (uint32_t c0 = wave * kBatch; c0 < ncand; c0 += kBatch * kNodesWaves) {
         int qv[kBatch];
         float cv[kBatch], c2v[kBatch];
@@ -319,63 +441,48 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
             if (qv[e] < 0) continue;  // wave-uniform
-            const uint64_t base = static_cast<uint64_t>(gw0 + qv[e]) * GS;
-            const bool in2 = inv[e] && base + lane + md < n_corr;
             if (corr == nullptr) {
                 // F window of the candidate group -> LDS -> its 52 correlation values
                 if constexpr (NL > 0) {
 #pragma unroll
                     for (int t = 0; t < NL; ++t)
                         if (lane + 64u * t < wlen) wa[lane + 64 * t] = fa[e][t];
+                    __builtin_amdgcn_wave_barrier();
+                    cv[e] = nodes_eval_window<NL, PWC>(wa, inv[e], lane, pw, fast);
+                    __builtin_amdgcn_wave_barrier();  // the window is dead from here on: wa is reused
                 } else {
-                    for (uint32_t t = lane; t < wlen; t += 64) {
-                        const uint64_t j = base + t;
-                        wa[t] = (t < wneed && j < w) ? fsig[j] : 0.f;
+                    cv[e] = eval_group(static_cast<uint64_t>(gw0 + qv[e]) * GS, inv[e]);
+                }
+            }
+            if (!settle(std::false_type{}, qv[e], cv[e], c2v[e], inv[e])) {
+                if (lane == 0) s_cand[c0 + e] = static_cast<uint16_t>(qv[e]) | kDeferred;
+                any_deferred = true;
+            }
+        }
+    }
+    // second pass: the candidates whose comparison with the groups in between the bounds left open (each
+    // wave its own; one at a time, from scratch)
+    if (any_deferred) {
+#pragma unroll 1
+        for (uint32_t c0 = wave * kBatch; c0 < ncand; c0 += kBatch * kNodesWaves) {
+#pragma unroll 1
+            for (uint32_t ci = c0; ci < c0 + kBatch && ci < ncand; ++ci) {
+                const uint16_t ent = s_cand[ci];
+                if (!(ent & kDeferred)) continue;  // wave-uniform
+                const int q = ent & (kDeferred - 1);
+                const uint64_t base = static_cast<uint64_t>(gw0 + q) * GS;
+                const bool in_v = lane < GS && base + lane < n_corr;
+                float cv = kNegInf, c2v = kNegInf;
+                if (corr != nullptr) {
+                    if (in_v) {
+                        cv = corr[base + lane];
+                        if (base + lane + md < n_corr) c2v = corr[base + lane + md];
                     }
+                } else {
+                    cv = eval_group(base, in_v);
                 }
-                __builtin_amdgcn_wave_barrier();
-                cv[e] = eval_window(wa, inv[e]);
+                (void)settle(std::true_type{}, q, cv, c2v, in_v);
             }
-            if (inv[e] && gw0 + qv[e] == 0 && lane == 0 && !(cv[e] > 0.f)) cv[e] = 0.f;  // the peak (0, 0.)
-            // NaN: remembered for the start test, -inf for every comparison
-            const unsigned long long nanword = __ballot(inv[e] && cv[e] != cv[e]) & kGroupMask;
-            if (cv[e] != cv[e]) cv[e] = kNegInf;
-            // suffix max over lanes > lane (rest of this group)
-            float sfx = cv[e];
-            for (int d = 1; d < 64; d <<= 1) {
-                const float o = __shfl_down(sfx, d, 64);
-                if (lane + d < 64) sfx = fmaxf(sfx, o);
-            }
-            float sfx_ex = __shfl_down(sfx, 1, 64);
-            if (lane == 63) sfx_ex = kNegInf;
-            float wmax = fmaxf(sfx_ex, s_wm[qv[e]]);
-            // the group md ahead: its positions up to this lane's offset belong to the window.  None of them
-            // can exceed corr[i] unless the group's maximum does, so it is only evaluated when some lane
-            // that is still a terminal so far is below that maximum (on APT data: almost never).
-            const float gm_ahead = s_gm[qv[e] + R];
-            if (corr == nullptr && __ballot(in2 && !(wmax > cv[e]) && gm_ahead > cv[e]) != 0ull) {
-                for (uint32_t t = lane; t < wlen; t += 64) {
-                    const uint64_t j = base + md + t;
-                    wb[t] = (t < wneed && j < w) ? fsig[j] : 0.f;
-                }
-                __builtin_amdgcn_wave_barrier();
-                c2v[e] = eval_window(wb, in2);
-            }
-            if (c2v[e] != c2v[e]) c2v[e] = kNegInf;
-            // prefix max over lanes <= lane of the group md positions ahead
-            float pfx = c2v[e];
-            for (int d = 1; d < 64; d <<= 1) {
-                const float o = __shfl_up(pfx, d, 64);
-                if (lane >= d) pfx = fmaxf(pfx, o);
-            }
-            wmax = fmaxf(wmax, pfx);
-            const bool term = inv[e] && !(wmax > cv[e]);
-            const unsigned long long word = __ballot(term) & kGroupMask;
-            if (lane == 0) {
-                s_words[qv[e]] = word;
-                s_nanw[qv[e]] = nanword;
-            }
-            __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
@@ -689,6 +796,8 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
             flags[1] = 1u;  // report which path ran
             flags[0] = 0u;  // re-arm the overflow flag for the next decode
             flags[5] = 0u;
+            flags[11] = flags[7];  // candidates k_sync_nodes settled with exact window maxima; re-armed
+            flags[7] = 0u;
         }
         return;
     }
@@ -784,6 +893,8 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         flags[3] = n_nodes;
         flags[4] = count;
         flags[6] = direct ? 1u : 0u;
+        flags[11] = flags[7];  // candidates k_sync_nodes settled with exact window maxima; re-armed
+        flags[7] = 0u;
     }
     stamp(2);  // peaks written
 }
@@ -809,9 +920,7 @@ void sync_nodes(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, ui
     const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
     const uint32_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
     const uint32_t r = md / GS;
-    const size_t lds = static_cast<size_t>(kChunkGroups + r + 1) * (8 + 4 + 2 + 1 + 8) +
-                       static_cast<size_t>(kChunkGroups + 2 * r + 2) * 4 + 48 +
-                       static_cast<size_t>(kNodesWaves) * 2 * nodes_window(pw) * sizeof(float);
+    const size_t lds = nodes_win_ofs(r) + static_cast<size_t>(kNodesWaves) * nodes_window(pw) * sizeof(float);
     const dim3 grid(chunks, call.count);
     const uint32_t wneed = GS + 38u * pw - 1u;
 #define APT_NODES_LAUNCH(NL, PWC)                                                                              \

@@ -350,6 +350,7 @@ void aptgpu_plan::upload_slot_table()
         prm.inv_sinphi = inv_sinphi;
         prm.f16_unscale = fused_f16 ? f16_unscale : 0.f;
         prm.want_gm = (sync && work_is_multiple) ? 1 : 0;
+        prm.gm_slack = apt::gpu::fused_gm_slack(pw);
         if (!d_fused_params.ptr) d_fused_params.alloc(1);
         apt::hip_check(hipMemcpyAsync(d_fused_params.ptr, &prm, sizeof prm, hipMemcpyHostToDevice, stream),
                        "hipMemcpy fused params");

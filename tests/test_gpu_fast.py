@@ -74,6 +74,8 @@ CASES = [
     (96000, 12, dict(seed=3)),
     (48000, 20, dict(seed=8, noise_sigma=6000.0)),   # heavy noise: many near-tie maxima
     (48000, 20, dict(seed=9, amplitude=2000.0)),     # weak signal
+    (11025, 30, dict(seed=6)),                       # table-driven stage 1 (k_fused TABLE mode), fast work-rate stages
+    (8000, 30, dict(seed=7)),
 ]
 
 
@@ -82,7 +84,7 @@ def test_fast_mode_tolerance(oracle, rate, seconds, kw):
     x = synth_apt(rate, seconds, **kw)
     want, st = oracle.decode(x, rate, True, want_steps=True)
     rows, pos, res, fused = decode_on_plan(x, rate, apt.MODE_FAST)
-    assert fused == 1 and res.status == 0
+    assert fused == (1 if rate in (48000, 96000) else 3) and res.status == 0
     frac, err = check_tolerance(rows, pos, want, st["sync_pos"], f"{rate} {kw}")
     assert 0 < err <= PX_TOL  # it really is the reassociated arithmetic, and within tolerance
 
@@ -104,7 +106,7 @@ def test_fast_mode_is_deterministic():
 
 def test_fast_mode_other_rates_fall_back_to_strict(oracle):
     """Rates / profiles without a fast kernel are served by the strict kernels: bit-exact."""
-    for rate, profile in ((11025, "standard"), (48000, "fast")):
+    for rate, profile in ((44100, "standard"), (48000, "fast")):
         x = synth_apt(rate, 20, 6)
         s = apt.Settings.profile(profile)
         os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
