@@ -246,6 +246,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     const int c_hi = rel(static_cast<int64_t>(n_corr) - k0);      // tile index of position n_corr
     const int kq = tid * L;        // this thread's first work sample, tile-relative
     const int kt = kq - k_lo;      // ... and as a global work-sample index clamped to int
+    // Interior tile (wave-uniform; all but the first and the last two tiles of a recording): every work
+    // sample of the tile exists and is a correlation position, so the per-sample edge tests of the
+    // stages below (a v_cmp + v_cndmask each, ~200 per thread) are compiled out of the copies of the
+    // small loops that interior tiles run.
+    const bool interior = k_lo < 0 && c_hi >= Gm::TILE_K;
     float r[L];
     if constexpr (Gm::TABLE) {
         // ---- stages 0 + 1, table-driven (dsp.rs:252-263): k*m - X0*l = v;  x0 - X0 = c = ceil(v / l);
@@ -589,9 +594,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             r[2 * pp + 1] = acc[pp].y;
         }
         if constexpr (L & 1) r[L - 1] = accl;
+        if (!interior) {
 #pragma unroll
-        for (int b = 0; b < L; ++b)
-            if (kq + b < k_lo || kq + b >= k_hi) r[b] = 0.f;
+            for (int b = 0; b < L; ++b)
+                if (kq + b < k_lo || kq + b >= k_hi) r[b] = 0.f;
+        }
     }
     __syncthreads();  // everyone is done reading the x tile
 #pragma unroll
@@ -613,6 +620,8 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     const int want_gm = late->want_gm;
 
     // ---- stage 2: AM envelope from consecutive samples (dsp.rs:369-377)
+    auto envelope = [&](auto interior_tag) {
+    constexpr bool INT = decltype(interior_tag)::value;  // interior tile: no edge tests
     if constexpr (FAST) {
         // native v_sqrt_f32 (1 ulp) and a multiplication by RN(1/sin(phi)): ~2 ulp from the
         // correctly rounded value, no range checks (the radicand is >= (1-|cos phi|)(p^2+c^2) >= 0)
@@ -623,7 +632,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             const float curr = r[b];
             const float curr_sq = curr * curr;
             const float rad = __builtin_fmaf(-(prev * curr), cosphi2, prev_sq + curr_sq);
-            Q[tid * L + b] = (kq + b > k_lo) ? __builtin_amdgcn_sqrtf(rad) * inv_sinphi : 0.f;
+            Q[tid * L + b] = (INT || kq + b > k_lo) ? __builtin_amdgcn_sqrtf(rad) * inv_sinphi : 0.f;
             prev = curr;
             prev_sq = curr_sq;
         }
@@ -636,7 +645,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             const float curr = r[b];
             xr[b] = envelope_radicand(prev, curr, cosphi2);
             // (outputs outside the recording are zeroed below whatever their radicand is)
-            in_range = in_range && (envelope_in_range(xr[b]) || kq + b <= k_lo || kq + b >= k_hi);
+            in_range = in_range && (envelope_in_range(xr[b]) || (!INT && (kq + b <= k_lo || kq + b >= k_hi)));
             prev = curr;
         }
         // wave-uniform choice: the exactly rounded fast path (apt_envelope.hpp) when every value
@@ -645,13 +654,16 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 #pragma unroll
             for (int b = 0; b < L; ++b) {
                 // (positions at or past the end of the recording hold garbage: never read)
-                Q[tid * L + b] = (kq + b > k_lo) ? envelope_fast(xr[b], sinphi, inv_sinphi) : 0.f;
+                Q[tid * L + b] = (INT || kq + b > k_lo) ? envelope_fast(xr[b], sinphi, inv_sinphi) : 0.f;
             }
         } else {
 #pragma unroll
             for (int b = 0; b < L; ++b) Q[tid * L + b] = (kq + b > k_lo) ? envelope_general(xr[b], sinphi) : 0.f;
         }
     }
+    };
+    if (interior) envelope(std::true_type{});
+    else envelope(std::false_type{});
     __syncthreads();
     if constexpr (APT_FUSED_STOP == 3) return;
     // ---- stage 3: causal low-pass with the `i > j` guard (dsp.rs:396-404)
@@ -813,9 +825,14 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             }
             if constexpr (!FAST) {
                 float a = 0.f;
+                if (interior) {
 #pragma unroll
-                for (int b = 0; b < L; ++b)
-                    a = a + ((kq + b >= k_lo && kq + b < k_hi) ? __builtin_fabsf(fw[b]) : 0.f);
+                    for (int b = 0; b < L; ++b) a = a + __builtin_fabsf(fw[b]);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < L; ++b)
+                        a = a + ((kq + b >= k_lo && kq + b < k_hi) ? __builtin_fabsf(fw[b]) : 0.f);
+                }
                 AB[tid] = a;
             }
         }
@@ -847,16 +864,19 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
-        // maximum over the group's positions, NaNs left out and reported through the bounds (a NaN
-        // position is a terminal of the picker, decode.rs:250, whatever the finite maximum of its group is)
+        // the maximum over the group's positions — NaNs left out and reported through the bounds (a NaN
+        // position is a terminal of the picker, decode.rs:250, whatever the finite maximum of its group
+        // is) — and the group's record
+        auto group_bounds = [&](auto interior_tag) {
+        constexpr bool INT = decltype(interior_tag)::value;  // interior tile: no edge tests
         float mx = kNegInfF;
         bool has_nan = false;
 #pragma unroll
         for (int b = 0; b < L; ++b) {
             const int pq = kq + b;
             float v = c[b];
-            if (pq == k_lo && !(v > 0.f)) v = 0.f;  // the picker starts from the peak (0, 0.)
-            if (pq >= k_lo && pq < c_hi) {
+            if (!INT && pq == k_lo && !(v > 0.f)) v = 0.f;  // the picker starts from the peak (0, 0.)
+            if (INT || (pq >= k_lo && pq < c_hi)) {
                 mx = fmaxf(mx, v);
                 has_nan = has_nan || (v != v);
             }
@@ -866,7 +886,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         int hn = has_nan ? 1 : 0;
         hn |= __shfl_xor(hn, 1, 64);
         hn |= __shfl_xor(hn, 2, 64);
-        if ((tid & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads && kq < c_hi) {
+        if ((tid & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads && (INT || kq < c_hi)) {
             float hi = mx, lo = mx;
             if constexpr (!FAST) {
                 // |F| over the group's window: the threads that hold positions kq .. kq + GS + G - 2
@@ -889,6 +909,9 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             }
             gm_out[o0 / Gm::GS + (tid - kPreThreads) / 4] = GroupMax{hi, lo};
         }
+        };
+        if (interior) group_bounds(std::true_type{});
+        else group_bounds(std::false_type{});
     }
     };  // run_tile
 
