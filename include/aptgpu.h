@@ -112,7 +112,8 @@ typedef struct aptgpu_stats {
     uint32_t n_resample_taps, n_lowpass_taps;
     int32_t fused;          /* front end used: 0 unfused generic kernels, 1 compile-time
                                specialised fused kernel, 2 run-time fused kernel, 3 table-driven
-                               stage 1 in front of the specialised work-rate stages (11 025 Hz) */
+                               stage 1 in front of the specialised work-rate stages (11 025 Hz),
+                               4 phase-resident taps in stage 1, same work-rate stages (44 100 Hz) */
     int32_t orbit_path;     /* peak-picker path: 0 doubling (LDS), 1 bitmask walk */
 } aptgpu_stats;
 
@@ -155,7 +156,8 @@ typedef struct aptgpu_plan_info {
     uint64_t max_work_len;         /* work-rate samples at max_samples                   */
     uint64_t max_rows;             /* upper bound on rows for max_samples                */
     int32_t fused;                 /* front end: 0 unfused, 1 specialised fused, 2 run-time fused,
-                                      3 table-driven stage 1 + specialised work-rate stages */
+                                      3 table-driven / 4 phase-resident stage 1 + specialised
+                                      work-rate stages */
     int32_t max_batch;
 } aptgpu_plan_info;
 

@@ -169,6 +169,18 @@ bool fused_table_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uin
 bool fused_table_front_end(hipStream_t s, const TableGeom &geom, int mode, bool pcm16, const CallArgs &call,
                            const FusedParams *d_prm, uint64_t max_w);
 
+// Phase-resident stage 1 + the specialised work-rate stages (k_fused in PHASE mode): thread t < S = l*floor(256/l)
+// computes the outputs t, t+S, ... of a tile with the taps of their common polyphase branch in registers.
+// Needs l <= 256, <= 16 outputs per thread, <= 76 taps per branch, an input tile that leaves room for three
+// workgroups per CU, standard-profile work-rate stages.  44 100 Hz (l = 208) is the rate this exists for.
+// TableGeom use: step_r = S, step_q = S*m/l, tpp = row stride of the table (multiple of 4), off_x = f2 entries
+// per region of the paired input tile, xt = floats of the whole tile.
+bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom);
+uint32_t fused_phase_table_floats(uint32_t l, uint32_t t1);
+void fused_phase_table(uint32_t l, const float *coeff, uint32_t t1, float *table);  // host: [l][tpp], rows 16-byte aligned
+bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, int mode, bool pcm16, const CallArgs &call,
+                           const FusedParams *d_prm, uint64_t max_w);
+
 // ---- fused front end for any rate / profile (apt_kernels_fused_any.hip) -------------
 // run-time parameters, taps phase-major in LDS; same outputs as fused_front_end
 bool fused_any_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);

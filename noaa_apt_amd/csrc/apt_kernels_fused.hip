@@ -198,7 +198,13 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
 bool fused_table_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom)
 {
     constexpr uint32_t kThreads = 512, kPerThread = 13, kTile = kThreads * kPerThread;
-    constexpr uint32_t kLdsFloats = 20480;  // 80 KB: two workgroups per CU
+    // 80 KB: two workgroups per CU.  APTGPU_TABLE_LDS_KB (A/B switch, <= 160) lets larger tables / tiles in at
+    // one workgroup per CU.
+    uint32_t kLdsFloats = 20480;
+    if (const char *e = std::getenv("APTGPU_TABLE_LDS_KB")) {
+        const long kb = std::atol(e);
+        if (kb >= 16 && kb <= 160) kLdsFloats = static_cast<uint32_t>(kb) * 256u;
+    }
     if (l < 2 || m == 0 || t1 == 0 || t2 != 37 || pw != 3) return false;  // (work-rate stages: standard profile)
     if (static_cast<uint64_t>(kTile + 4096) * m + l > 0x7fffffffull) return false;  // 32-bit in-tile index math
     TableGeom g{};
@@ -230,6 +236,74 @@ bool fused_table_front_end(hipStream_t s, const TableGeom &geom, int mode, bool 
         pcm16 ? fused_launch_tab_std_fast_i16(a) : fused_launch_tab_std_fast_f32(a);
     else if (mode == kModeStrict)
         pcm16 ? fused_launch_tab_std_i16(a) : fused_launch_tab_std_f32(a);
+    else
+        return false;
+    return true;
+}
+
+
+// ---- phase-resident stage 1 (k_fused in PHASE mode)
+namespace {
+constexpr uint32_t kPhaseThreads = 256, kPhaseTile = kPhaseThreads * 13, kPhaseOutputs = 16, kPhaseTapsMax = 76;
+uint32_t phase_tpp(uint32_t l, uint32_t t1)
+{
+    const uint32_t jlim = 2 * ((t1 - 1) / 2) + 1;
+    return ((jlim + l - 1) / l + 3u) & ~3u;
+}
+}  // namespace
+
+bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom)
+{
+    if (l < 2 || l > kPhaseThreads || m == 0 || t1 == 0 || t2 != 37 || pw != 3) return false;  // (work-rate stages: standard profile)
+    if (static_cast<uint64_t>(kPhaseTile + 4096) * m + l > 0x7fffffffull) return false;  // 32-bit in-tile index math
+    TableGeom g{};
+    g.l = l;
+    g.m = m;
+    g.jlim = 2 * ((t1 - 1) / 2) + 1;
+    const uint32_t per_phase = (g.jlim + l - 1) / l;
+    if (per_phase > kPhaseTapsMax) return false;
+    g.tpp = phase_tpp(l, t1);
+    const uint32_t stride = l * (kPhaseThreads / l);  // outputs between a thread's consecutive outputs
+    if ((kPhaseTile + stride - 1) / stride > kPhaseOutputs) return false;
+    g.step_r = stride;
+    g.step_q = static_cast<uint32_t>(static_cast<uint64_t>(stride) * m / l);  // exact: l divides stride
+    // paired input tile: kPhaseOutputs / 2 regions of off_x f2 entries — a thread's window starts at most
+    // step_q + 4 entries into its region and is per_phase long
+    g.off_x = g.step_q + per_phase + 8;
+    if (g.off_x > 4 * kPhaseThreads) return false;  // (the tile loader covers a region in four rounds)
+    g.xt = (kPhaseOutputs / 2) * 2 * g.off_x;
+    if (g.xt > 13600) return false;  // 53 KB: three workgroups per CU
+    g.jl_a = g.jlim / l;
+    g.jl_b = g.jlim % l;
+    if (geom) *geom = g;
+    return true;
+}
+
+uint32_t fused_phase_table_floats(uint32_t l, uint32_t t1) { return l * phase_tpp(l, t1); }
+
+void fused_phase_table(uint32_t l, const float *coeff, uint32_t t1, float *table)
+{
+    const uint32_t jlim = 2 * ((t1 - 1) / 2) + 1;
+    const uint32_t tpp = phase_tpp(l, t1);
+    for (uint32_t p = 0; p < l; ++p)
+        for (uint32_t i = 0; i < tpp; ++i) {
+            const uint64_t j = p + static_cast<uint64_t>(i) * l;
+            table[static_cast<size_t>(p) * tpp + i] = j < jlim ? coeff[j] : 0.f;
+        }
+}
+
+bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, int mode, bool pcm16, const CallArgs &call,
+                           const FusedParams *d_prm, uint64_t max_w)
+{
+    if (call.count == 0 || call.count > static_cast<uint32_t>(kMaxCall)) return false;
+    if (pcm16)
+        for (uint32_t i = 0; i < call.count; ++i)
+            if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 1u) return false;
+    const FusedLaunch a{s, &call, d_prm, max_w, static_cast<size_t>(geom.xt)};
+    if (mode == kModeFast)
+        pcm16 ? fused_launch_phase_std_fast_i16(a) : fused_launch_phase_std_fast_f32(a);
+    else if (mode == kModeStrict)
+        pcm16 ? fused_launch_phase_std_i16(a) : fused_launch_phase_std_f32(a);
     else
         return false;
     return true;

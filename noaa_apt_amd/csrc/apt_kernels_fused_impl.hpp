@@ -60,7 +60,8 @@ __host__ __device__ constexpr int branch_phase(int b)  // p_b = c_b*L - b*M
 // input tile are then run-time quantities (FusedParams::tab) and only the work-rate geometry is static.
 template <int L, int M, int T1, int T2, int PW, int NTHR, int XB = 4>
 struct FusedGeom {
-    static constexpr bool TABLE = M == 0;
+    static constexpr bool TABLE = M <= 0;   // run-time resampling factors (table-driven or phase-resident stage 1)
+    static constexpr bool PHASE = M == -1;  // ... with the taps of a thread's polyphase branch in registers
     static constexpr int kFusedThreads = NTHR;
     static constexpr int kOwnThreads = NTHR - kPreThreads - kPostThreads;
     static constexpr int TP = (T1 + L - 1) / L;                       // taps per branch (max)
@@ -145,6 +146,14 @@ __host__ __device__ constexpr bool sync_plus(int j)
 // tap count — one output per thread and step, as in k_fused_any — and hands R to the SAME work-rate
 // stages (envelope, packed low-pass, correlation) as the specialised kernels; the template's L is then
 // just "work samples per thread" (13: four threads = one group of 52 positions).
+// PHASE mode (M == -1; 44 100 Hz: l = 208 — too large for one accumulator per branch, and its table + input
+// tile overflow two workgroups per CU in TABLE mode, which at one workgroup per CU is bound by the latency of
+// its two LDS reads per multiply-add): thread t < S = l * floor(NTHR / l) computes the NB outputs
+// t, t + S, t + 2S, ... of the tile.  They all use the SAME polyphase branch (S is a multiple of l), so the
+// ~70 taps of that branch are fetched once per tile into REGISTERS (16-byte loads from the L2-resident
+// phase-major table) and every tap then costs one LDS read of a sample per output and — outputs taken in
+// pairs — half a v_pk_mul_f32 + half a v_pk_add_f32 (or half a v_pk_fma_f32), as in the specialised kernels.
+// Each output still accumulates its taps in ascending order: bit-identical in strict mode.
 // One workgroup per tile: blockIdx.y picks the recording, whose tiles are blockIdx.x < ceil(w / OWN_K).
 // The tile's input goes through registers (all loads issued before the first LDS write).  (A
 // persistent form that walked the tiles with a fixed grid and kept the NEXT tile's input in
@@ -153,7 +162,8 @@ __host__ __device__ constexpr bool sync_plus(int j)
 template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
 // (104 VGPRs: three workgroups per CU then leave 200 registers per SIMD lane free, which is what lets
 // the picker's kernels of the previous call — one 1024-thread workgroup among them — run beside this one)
-__global__ void __launch_bounds__(NTHR, M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
+__global__ void __launch_bounds__(NTHR, M == -1 ? (3 * NTHR + 255) / 256  /* phase mode: three workgroups per CU, <= 170 VGPRs */
+                                     : M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
                                                : ((sizeof(XT) == 2 ? 4 : APT_FUSED_MIN_WAVES) * NTHR + 255) / 256)
 k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 {
@@ -252,6 +262,156 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     // small loops that interior tiles run.
     const bool interior = k_lo < 0 && c_hi >= Gm::TILE_K;
     float r[L];
+    if constexpr (Gm::PHASE) {
+        // ---- stages 0 + 1, taps of the thread's polyphase branch in registers (dsp.rs:252-263):
+        // k*m - X0*l = v;  x0 - X0 = c = ceil(v / l);  phase p = c*l - v;  output k = sum_i h[p + i*l] * x[x0 + i]
+        constexpr int NB = 16;     // outputs per thread (>= ceil(TILE_K / S): checked by fused_phase_supported)
+        constexpr int TPPM = 76;   // taps per branch the registers hold (>= tpp)
+        typedef const FusedParams APT_CONST_AS *cprm_tab_ptr;
+        const cprm_tab_ptr tp = (cprm_tab_ptr)(prm);
+        const uint32_t gl = tp->tab.l, gm_ = tp->tab.m, tpp = tp->tab.tpp;
+        const uint32_t S = tp->tab.step_r, dq = tp->tab.step_q;  // thread stride in outputs; S*m / l input samples
+        const uint32_t ZR = tp->tab.off_x;                        // f2 entries per region of the paired tile
+        const uint32_t jl_a = tp->tab.jl_a, jl_b = tp->tab.jl_b;
+        const XT *__restrict__ x = static_cast<const XT *>(call.rec[ri].x);
+        const int64_t n = static_cast<int64_t>(call.rec[ri].n);
+        // The tile starts at work sample k0, which is negative in tile 0: the samples before the recording
+        // read as zero (like those at or past its end), the outputs before it are zeroed afterwards.
+        const int64_t kbm = k0 * static_cast<int64_t>(gm_);           // k0*m = X0*l + rb, 0 <= rb < l
+        int64_t X0 = kbm / static_cast<int64_t>(gl);
+        if (X0 * static_cast<int64_t>(gl) > kbm) --X0;                // floor
+        const uint32_t rb = static_cast<uint32_t>(kbm - X0 * static_cast<int64_t>(gl));
+        const int64_t xfirst = X0 + (rb ? 1 : 0);
+        const int64_t xs0 = xfirst & ~static_cast<int64_t>(3);        // first input sample of the tile
+        const uint32_t xrel0 = static_cast<uint32_t>(X0 - xs0);       // -1 (wrapped) only when rb > 0, and then c >= 1
+        // this thread's branch (the same for all its outputs: S*m is a multiple of l)
+        const bool act = static_cast<uint32_t>(tid) < S;
+        const uint32_t v = rb + static_cast<uint32_t>(tid) * gm_;
+        const uint32_t c = (v + gl - 1) / gl;
+        const uint32_t ph = c * gl - v;
+        // The input tile in LDS, PAIRED: outputs 2jj and 2jj+1 of a thread read windows exactly dq samples
+        // apart, so region jj holds Z[jj][s] = (x[2jj*dq + s], x[(2jj+1)*dq + s]), s < ZR = dq + window + slack:
+        // one 8-byte LDS read then delivers the two samples a packed multiply needs, already in a register
+        // pair (two 4-byte reads would be merged by the compiler with their NEIGHBOURS in the window, and
+        // the pairs rebuilt with a v_mov per sample).  The windows' overlap (~10 %) is stored twice.
+        f2 *Z = reinterpret_cast<f2 *>(lds);
+        {
+            // every load of the tile issued before the first LDS write (regions x rounds unrolled: a loop
+            // that waited for each round's loads cost 26 HBM latencies per tile)
+            constexpr int ZROUNDS = 4;  // ceil(ZR / NTHR) at most (fused_phase_supported)
+            const XT *xt0 = x + xs0;    // only dereferenced inside [x_lo, x_hi)
+            const int x_lo = rel(-xs0), x_hi = rel(n - xs0);
+            XT za[NB / 2][ZROUNDS], zb[NB / 2][ZROUNDS];
+#pragma unroll
+            for (int jj = 0; jj < NB / 2; ++jj) {
+#pragma unroll
+                for (int rr = 0; rr < ZROUNDS; ++rr) {
+                    const uint32_t s_in = static_cast<uint32_t>(tid + rr * kFusedThreads);
+                    const int ia = static_cast<int>(static_cast<uint32_t>(2 * jj) * dq + s_in);
+                    const int ib = ia + static_cast<int>(dq);
+                    za[jj][rr] = (s_in < ZR && ia >= x_lo && ia < x_hi) ? xt0[ia] : XT(0);
+                    zb[jj][rr] = (s_in < ZR && ib >= x_lo && ib < x_hi) ? xt0[ib] : XT(0);
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < NB / 2; ++jj) {
+#pragma unroll
+                for (int rr = 0; rr < ZROUNDS; ++rr) {
+                    const uint32_t s_in = static_cast<uint32_t>(tid + rr * kFusedThreads);
+                    if (s_in < ZR) Z[jj * ZR + s_in] = (f2){static_cast<float>(za[jj][rr]), static_cast<float>(zb[jj][rr])};
+                }
+            }
+        }
+        // its taps -> registers (16-byte loads from the L2-resident table; in flight across the barrier)
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v tq[TPPM / 4];
+        {
+            const f4v *row = reinterpret_cast<const f4v *>(tp->table) + static_cast<size_t>(act ? ph : 0u) * (tpp / 4);
+#pragma unroll
+            for (int e = 0; e < TPPM / 4; ++e)
+                tq[e] = (static_cast<uint32_t>(4 * e) < tpp) ? row[e] : (f4v){0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        if constexpr (APT_FUSED_STOP == 1) return;
+        f2 acc[NB / 2];
+#pragma unroll
+        for (int jj = 0; jj < NB / 2; ++jj) acc[jj] = (f2){0.f, 0.f};
+        if (act) {
+            const f2 *zw[NB / 2];  // window of the output pair (2jj, 2jj+1)
+#pragma unroll
+            for (int jj = 0; jj < NB / 2; ++jj) zw[jj] = Z + jj * ZR + (xrel0 + c);
+            auto tap = [&](auto ii, float t) {
+                constexpr int i = decltype(ii)::value;
+                f2 xp[NB / 2];
+#pragma unroll
+                for (int jj = 0; jj < NB / 2; ++jj) xp[jj] = zw[jj][i];
+                if constexpr (FAST) {
+#pragma unroll
+                    for (int jj = 0; jj < NB / 2; ++jj) acc[jj] = __builtin_elementwise_fma((f2){t, t}, xp[jj], acc[jj]);
+                } else {
+                    f2 pr[NB / 2];
+#pragma unroll
+                    for (int jj = 0; jj < NB / 2; ++jj) pr[jj] = (f2){t, t} * xp[jj];
+#pragma unroll
+                    for (int jj = 0; jj < NB / 2; ++jj) acc[jj] = acc[jj] + pr[jj];
+                }
+            };
+            // taps 0 .. jl_a - 1 for every branch, tap jl_a for the branches p < jl_b (the reference's
+            // `p + i*l < jlim`): the tap count is wave-uniform up to that last, lane-predicated one.  Chunks of
+            // CHK taps under one uniform test, so that the LDS reads of a chunk's later taps are in flight under
+            // the arithmetic of its earlier ones.
+            const bool extra = ph < jl_b;
+            auto tap_of = [&](auto ii) -> float {
+                constexpr int i = decltype(ii)::value;
+                const f4v q4 = tq[i / 4];
+                return (i & 3) == 0 ? q4.x : (i & 3) == 1 ? q4.y : (i & 3) == 2 ? q4.z : q4.w;
+            };
+            constexpr int CHK = 2;
+            bool go = true;  // (wave-uniform)
+            static_for<0, TPPM / CHK>([&](auto ee) {
+                constexpr int i0 = decltype(ee)::value * CHK;
+                go = go && static_cast<uint32_t>(i0 + CHK) <= jl_a;
+                if (go) {
+                    static_for<0, CHK>([&](auto tt) {
+                        using I = std::integral_constant<int, i0 + decltype(tt)::value>;
+                        tap(I{}, tap_of(I{}));
+                    });
+                }
+            });
+            // the last taps (fewer than CHK whole ones, then the predicated one): a run-time loop, its taps
+            // read from the table again
+            {
+                const float *rowf = tp->table + static_cast<size_t>(ph) * tpp;
+#pragma unroll 1
+                for (uint32_t i = jl_a - jl_a % CHK; i <= jl_a; ++i) {
+                    if (i < jl_a || extra) {
+                        const float t = rowf[i];
+                        f2 xp[NB / 2];
+#pragma unroll
+                        for (int jj = 0; jj < NB / 2; ++jj) xp[jj] = zw[jj][i];
+#pragma unroll
+                        for (int jj = 0; jj < NB / 2; ++jj) {
+                            if constexpr (FAST) acc[jj] = __builtin_elementwise_fma((f2){t, t}, xp[jj], acc[jj]);
+                            else acc[jj] = acc[jj] + (f2){t, t} * xp[jj];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();  // everyone is done with the input tile: R may land on it
+        if (act) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int idx = tid + j * static_cast<int>(S);
+                const float val = (j & 1) ? acc[j / 2].y : acc[j / 2].x;
+                // (outputs before the recording or at / past its end: zero)
+                if (idx < Gm::TILE_K) P[idx] = (idx >= k_lo && idx < k_hi) ? val : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < L; ++b) r[b] = P[kq + b];
+    } else
     if constexpr (Gm::TABLE) {
         // ---- stages 0 + 1, table-driven (dsp.rs:252-263): k*m - X0*l = v;  x0 - X0 = c = ceil(v / l);
         // phase p = c*l - v; output k = sum_i table[p][i] * x[x0 + i] over the taps the reference uses

@@ -218,15 +218,21 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         const char *force_any = std::getenv("APTGPU_FUSED_ANY");  // tests: run-time kernel even if specialised
         plan->fused = 0;
         const bool no_spec = force_any && force_any[0] == '1';
+        const char *phase_first = std::getenv("APTGPU_PHASE_FIRST");  // tests: phase-resident stage 1 wherever it exists
         if (eligible && gpu::fused_supported(plan->l, plan->m, t1, t2, plan->pw) && !no_spec)
             plan->fused = 1;
+        else if (eligible && !no_spec && phase_first && phase_first[0] == '1' &&
+                 gpu::fused_phase_supported(plan->l, plan->m, t1, t2, plan->pw, &plan->table_geom))
+            plan->fused = 4;
         else if (eligible && !no_spec && gpu::fused_table_supported(plan->l, plan->m, t1, t2, plan->pw, &plan->table_geom))
             plan->fused = 3;  // table-driven stage 1 + the specialised work-rate stages (11 025 Hz)
+        else if (eligible && !no_spec && gpu::fused_phase_supported(plan->l, plan->m, t1, t2, plan->pw, &plan->table_geom))
+            plan->fused = 4;  // phase-resident taps in stage 1 + the specialised work-rate stages (44 100 Hz)
         else if (eligible && gpu::fused_any_supported(plan->l, plan->m, t1, t2, plan->pw))
             plan->fused = 2;
         plan->fused_fast = plan->mode == APTGPU_MODE_FAST &&
                            ((plan->fused == 1 && gpu::fused_fast_supported(plan->l, plan->m, t1, t2, plan->pw)) ||
-                            plan->fused == 3);
+                            plan->fused == 3 || plan->fused == 4);
         // fp16-tap mode inside the specialised fused kernel where one exists (else the generic kernel)
         if (plan->mode == APTGPU_MODE_FP16_TAPS && plan->l > 1 && plan->work_is_multiple &&
             gpu::fused_f16_supported(plan->l, plan->m, t1, t2, plan->pw)) {
@@ -250,10 +256,12 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         if (plan->fused_fast) plan->inv_sinphi = rc;  // a plain multiplication by the rounded reciprocal
         else if (!(off && off[0] == '1') && gpu::verify_fast_divide(plan->device, plan->sinphi, rc)) plan->inv_sinphi = rc;
     }
-    if (plan->fused == 2 || plan->fused == 3) {
+    if (plan->fused == 2 || plan->fused == 3 || plan->fused == 4) {
         const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
-        Signal tab(static_cast<size_t>(gpu::fused_any_table_floats(plan->l, t1)) + 16, 0.f);
-        gpu::fused_any_table(plan->l, plan->taps_resample.data(), t1, tab.data());
+        Signal tab(static_cast<size_t>(plan->fused == 4 ? gpu::fused_phase_table_floats(plan->l, t1)
+                                                        : gpu::fused_any_table_floats(plan->l, t1)) + 16, 0.f);
+        if (plan->fused == 4) gpu::fused_phase_table(plan->l, plan->taps_resample.data(), t1, tab.data());
+        else gpu::fused_any_table(plan->l, plan->taps_resample.data(), t1, tab.data());
         upload(plan->d_taps_any, tab);
         Signal h2p(2 * (plan->taps_lowpass.size() + 1) + 16, 0.f);
         gpu::fused_lowpass_pairs(plan->taps_lowpass.data(), static_cast<uint32_t>(plan->taps_lowpass.size()),
@@ -338,7 +346,7 @@ void aptgpu_plan::upload_slot_table()
                                   hipMemcpyHostToDevice, stream),
                    "hipMemcpy slot table");
     apt::gpu::FusedParams prm{};
-    if (fused == 1 || fused == 3) {
+    if (fused == 1 || fused == 3 || fused == 4) {
         prm.hs = d_taps_branch.ptr;
         prm.table = d_taps_any.ptr;
         prm.tab = table_geom;
@@ -487,7 +495,7 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
 
     const uint32_t t1 = static_cast<uint32_t>(taps_resample.size());
     const uint32_t t2 = static_cast<uint32_t>(taps_lowpass.size());
-    if (use_fused && (fused == 1 || fused == 3)) {
+    if (use_fused && (fused == 1 || fused == 3 || fused == 4)) {
         // 1-3 fused: resample -> envelope -> low-pass (-> correlation maxima) in one launch per input
         // kind (apt_kernels_fused.hip)
         for (int kind = 0; kind < 2; ++kind) {
@@ -497,7 +505,9 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
             for_chunks(idx, [&](const CallArgs &c, uint64_t max_w, uint32_t) {
                 timed("fused_front_end", [&] {
                     const int kmode = fused_f16 ? 1 : (fused_fast ? 2 : 0);
-                    const bool ok = fused == 3 ? fused_table_front_end(cur, table_geom, kmode, kind == 1, c,
+                    const bool ok = fused == 4 ? fused_phase_front_end(cur, table_geom, kmode, kind == 1, c,
+                                                                       d_fused_params.ptr, max_w)
+                                  : fused == 3 ? fused_table_front_end(cur, table_geom, kmode, kind == 1, c,
                                                                        d_fused_params.ptr, max_w)
                                                : fused_front_end(cur, l, m, t1, t2, pw, kmode, kind == 1, c,
                                                                  d_fused_params.ptr, max_w);

@@ -292,9 +292,9 @@ def test_decode_alternate_paths(oracle, mode, monkeypatch):
 def test_fused_specialisations_are_used(ctx):
     """48 kHz and 96 kHz (standard profile) run the compile-time specialised front end (1); 11 025 Hz
     and the other rates whose tap table and input tile fit run the table-driven stage 1 in front of
-    the specialised work-rate stages (3); the rest the run-time fused kernel (2); l == 1 the unfused
-    kernels (0)."""
-    for rate, profile, want in ((48000, "standard", 1), (96000, "standard", 1), (44100, "standard", 2),
+    the specialised work-rate stages (3); 44 100 Hz the phase-resident stage 1 in front of the same stages
+    (4); the rest the run-time fused kernel (2); l == 1 the unfused kernels (0)."""
+    for rate, profile, want in ((48000, "standard", 1), (96000, "standard", 1), (44100, "standard", 4),
                                 (11025, "standard", 3), (8000, "standard", 3), (22050, "standard", 2),
                                 (48000, "fast", 2), (48000, "slow", 2), (24960, "standard", 0)):
         _, st = apt.decode(ctx, apt.Settings.profile(profile), synth_apt(rate, 11, 3), apt.Rate.hz(rate),
@@ -355,6 +355,67 @@ def test_table_stage1_long_ragged_batched_and_pcm16(oracle):
             res = plan.results(len(recs))
             for i, (want, _) in enumerate(wants):
                 assert_bitexact(d_out[i][:res[i].n_out].cpu().numpy(), want, f"table pcm16 {i}")
+        plan.close()
+
+
+PHASE_CASES = [  # (rate, seconds): rates k_fused's phase-resident stage 1 (fused == 4) can serve
+    (44100, 40), (44100, 11), (32000, 20), (20800, 15), (16000, 20), (24000, 15), (40000, 12), (15600, 20),
+]
+
+
+@pytest.mark.parametrize("rate,seconds", PHASE_CASES)
+@pytest.mark.parametrize("sync", [True, False])
+def test_phase_stage1_bitexact(oracle, monkeypatch, rate, seconds, sync):
+    monkeypatch.setenv("APTGPU_PHASE_FIRST", "1")
+    x = synth_apt(rate, seconds, seed=rate % 89 + seconds)
+    want = oracle.decode(x, rate, sync)
+    got, st = apt.decode(apt.Context(device=0), apt.Settings(), x, apt.Rate.hz(rate), sync, return_stats=True)
+    assert st.fused == 4, (rate, st.l, st.m, st.n_resample_taps)
+    assert_bitexact(got, want, f"phase stage 1 {rate} sync={sync}")
+
+
+def test_phase_stage1_long_ragged_batched_and_pcm16(oracle):
+    """Many tiles, lengths that end mid-tile / mid-group, several recordings per call, PCM16 payloads at
+    odd 2-byte offsets, non-finite samples, and the fast mode's tolerance — all at 44 100 Hz."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    bad = synth_apt(44100, 25, seed=9)
+    bad[70000:70100] = np.nan
+    bad[500000] = np.inf
+    bad[3] = -np.inf
+    recs = [synth_apt(44100, 300, seed=5), synth_apt(44100, 20, seed=6)[:44100 * 20 - 3],
+            synth_apt(44100, 33, seed=7)[:44100 * 33 - 1], synth_apt(44100, 64, seed=8), bad]
+    wants = [oracle.decode(r, 44100, True, want_steps=True) for r in recs]
+    nmax = max(r.size for r in recs)
+    for mode in (apt.MODE_STRICT, apt.MODE_FAST):
+        plan = apt.Plan(apt.Settings(), apt.Rate.hz(44100), True, max_samples=nmax, max_batch=len(recs), mode=mode)
+        assert plan.info.fused == 4
+        d_in = [torch.from_numpy(r).to(dev) for r in recs]
+        cap = int(plan.info.max_rows)
+        d_out = [torch.empty(cap * 2080, dtype=torch.float32, device=dev) for _ in recs]
+        torch.cuda.synchronize()
+        for _ in range(2):
+            plan.decode_device([t.data_ptr() for t in d_in], [r.size for r in recs], [t.data_ptr() for t in d_out],
+                               [cap] * len(recs))
+        res = plan.results(len(recs))
+        for i, (want, st) in enumerate(wants):
+            got = d_out[i][:res[i].n_out].cpu().numpy()
+            if mode == apt.MODE_STRICT:
+                assert_same_values(got, want, f"phase batch {i}")
+                assert plan.sync_positions(i).tolist() == st["sync_pos"].tolist()
+            elif i < 4:
+                from test_gpu_fast import check_tolerance
+                check_tolerance(got, plan.sync_positions(i), want, st["sync_pos"], f"phase fast {i}")
+        if mode == apt.MODE_STRICT:
+            # the same recordings as PCM16 payloads, the second one at an odd 2-byte offset
+            pcm = [torch.from_numpy(np.concatenate([np.zeros(1 if i == 1 else 0, np.int16), r.astype(np.int16)])).to(dev)
+                   for i, r in enumerate(recs[:4])]
+            ptrs = [t.data_ptr() + (2 if i == 1 else 0) for i, t in enumerate(pcm)]
+            specs = [apt.WavSpec(1, 16, 2, 0, 44100, 1, 0, 2 * r.size, r.size, r.size) for r in recs[:4]]
+            plan.decode_device_wav(ptrs, specs, [t.data_ptr() for t in d_out[:4]], [cap] * 4)
+            res = plan.results(4)
+            for i, (want, _) in enumerate(wants[:4]):
+                assert_bitexact(d_out[i][:res[i].n_out].cpu().numpy(), want, f"phase pcm16 {i}")
         plan.close()
 
 
