@@ -244,39 +244,48 @@ bool fused_table_front_end(hipStream_t s, const TableGeom &geom, int mode, bool 
 
 // ---- phase-resident stage 1 (k_fused in PHASE mode)
 namespace {
-constexpr uint32_t kPhaseThreads = 256, kPhaseTile = kPhaseThreads * 13, kPhaseOutputs = 16, kPhaseTapsMax = 76;
+constexpr uint32_t kPhaseOutputs = 16;
 uint32_t phase_tpp(uint32_t l, uint32_t t1)
 {
     const uint32_t jlim = 2 * ((t1 - 1) / 2) + 1;
     return ((jlim + l - 1) / l + 3u) & ~3u;
 }
-}  // namespace
-
-bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom)
+// geometry for workgroups of `threads` (256: three per CU; 512: two per CU); the launcher recovers the thread
+// count from step_r (<= 256 <=> 256 threads: a stride above 256 needs l > 256, which phase_geom(256, ..) refuses)
+bool phase_geom(uint32_t threads, uint32_t l, uint32_t m, uint32_t t1, TableGeom *geom)
 {
-    if (l < 2 || l > kPhaseThreads || m == 0 || t1 == 0 || t2 != 37 || pw != 3) return false;  // (work-rate stages: standard profile)
-    if (static_cast<uint64_t>(kPhaseTile + 4096) * m + l > 0x7fffffffull) return false;  // 32-bit in-tile index math
+    const uint32_t tile = threads * 13;
+    if (l > threads) return false;
+    if (static_cast<uint64_t>(tile + 4096) * m + l > 0x7fffffffull) return false;  // 32-bit in-tile index math
     TableGeom g{};
     g.l = l;
     g.m = m;
     g.jlim = 2 * ((t1 - 1) / 2) + 1;
     const uint32_t per_phase = (g.jlim + l - 1) / l;
-    if (per_phase > kPhaseTapsMax) return false;
+    if (per_phase > (threads == 256 ? 76u : 40u)) return false;  // taps a thread's registers hold (TPPM in k_fused)
     g.tpp = phase_tpp(l, t1);
-    const uint32_t stride = l * (kPhaseThreads / l);  // outputs between a thread's consecutive outputs
-    if ((kPhaseTile + stride - 1) / stride > kPhaseOutputs) return false;
+    const uint32_t stride = l * (threads / l);  // outputs between a thread's consecutive outputs
+    if ((tile + stride - 1) / stride > kPhaseOutputs) return false;
     g.step_r = stride;
     g.step_q = static_cast<uint32_t>(static_cast<uint64_t>(stride) * m / l);  // exact: l divides stride
     // paired input tile: kPhaseOutputs / 2 regions of off_x f2 entries — a thread's window starts at most
     // step_q + 4 entries into its region and is per_phase long
     g.off_x = g.step_q + per_phase + 8;
-    if (g.off_x > 4 * kPhaseThreads) return false;  // (the tile loader covers a region in four rounds)
+    if (g.off_x > 1024) return false;  // (the tile loader covers a region in 1024 / threads rounds)
     g.xt = (kPhaseOutputs / 2) * 2 * g.off_x;
-    if (g.xt > 13600) return false;  // 53 KB: three workgroups per CU
+    // LDS: three 256-thread workgroups (53 KB each) or two 512-thread ones (80 KB) per CU
+    if (g.xt > (threads == 256 ? 13600u : 20480u)) return false;
     g.jl_a = g.jlim / l;
     g.jl_b = g.jlim % l;
     if (geom) *geom = g;
     return true;
+}
+}  // namespace
+
+bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom)
+{
+    if (l < 2 || m == 0 || t1 == 0 || t2 != 37 || pw != 3) return false;  // (work-rate stages: standard profile)
+    return phase_geom(256, l, m, t1, geom) || phase_geom(512, l, m, t1, geom);
 }
 
 uint32_t fused_phase_table_floats(uint32_t l, uint32_t t1) { return l * phase_tpp(l, t1); }
@@ -300,10 +309,14 @@ bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, int mode, bool 
         for (uint32_t i = 0; i < call.count; ++i)
             if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 1u) return false;
     const FusedLaunch a{s, &call, d_prm, max_w, static_cast<size_t>(geom.xt)};
-    if (mode == kModeFast)
-        pcm16 ? fused_launch_phase_std_fast_i16(a) : fused_launch_phase_std_fast_f32(a);
-    else if (mode == kModeStrict)
-        pcm16 ? fused_launch_phase_std_i16(a) : fused_launch_phase_std_f32(a);
+    const bool wide = geom.step_r > 256;  // 512-thread workgroups
+    if (mode == kModeFast) {
+        if (wide) pcm16 ? fused_launch_phase512_std_fast_i16(a) : fused_launch_phase512_std_fast_f32(a);
+        else pcm16 ? fused_launch_phase_std_fast_i16(a) : fused_launch_phase_std_fast_f32(a);
+    } else if (mode == kModeStrict) {
+        if (wide) pcm16 ? fused_launch_phase512_std_i16(a) : fused_launch_phase512_std_f32(a);
+        else pcm16 ? fused_launch_phase_std_i16(a) : fused_launch_phase_std_f32(a);
+    }
     else
         return false;
     return true;

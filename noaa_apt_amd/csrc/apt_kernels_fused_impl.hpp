@@ -162,7 +162,7 @@ __host__ __device__ constexpr bool sync_plus(int j)
 template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
 // (104 VGPRs: three workgroups per CU then leave 200 registers per SIMD lane free, which is what lets
 // the picker's kernels of the previous call — one 1024-thread workgroup among them — run beside this one)
-__global__ void __launch_bounds__(NTHR, M == -1 ? (3 * NTHR + 255) / 256  /* phase mode: three workgroups per CU, <= 170 VGPRs */
+__global__ void __launch_bounds__(NTHR, M == -1 ? ((NTHR > 256 ? 2 : 3) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs) or two 512-thread (<= 128) workgroups per CU */
                                      : M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
                                                : ((sizeof(XT) == 2 ? 4 : APT_FUSED_MIN_WAVES) * NTHR + 255) / 256)
 k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
@@ -266,7 +266,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         // ---- stages 0 + 1, taps of the thread's polyphase branch in registers (dsp.rs:252-263):
         // k*m - X0*l = v;  x0 - X0 = c = ceil(v / l);  phase p = c*l - v;  output k = sum_i h[p + i*l] * x[x0 + i]
         constexpr int NB = 16;     // outputs per thread (>= ceil(TILE_K / S): checked by fused_phase_supported)
-        constexpr int TPPM = 76;   // taps per branch the registers hold (>= tpp)
+        constexpr int TPPM = NTHR > 256 ? 40 : 76;  // taps per branch the registers hold (>= tpp; 128 / 170 VGPRs)
         typedef const FusedParams APT_CONST_AS *cprm_tab_ptr;
         const cprm_tab_ptr tp = (cprm_tab_ptr)(prm);
         const uint32_t gl = tp->tab.l, gm_ = tp->tab.m, tpp = tp->tab.tpp;
@@ -298,7 +298,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         {
             // every load of the tile issued before the first LDS write (regions x rounds unrolled: a loop
             // that waited for each round's loads cost 26 HBM latencies per tile)
-            constexpr int ZROUNDS = 4;  // ceil(ZR / NTHR) at most (fused_phase_supported)
+            constexpr int ZROUNDS = 1024 / kFusedThreads;  // ceil(ZR / NTHR) at most (fused_phase_supported: ZR <= 1024)
             const XT *xt0 = x + xs0;    // only dereferenced inside [x_lo, x_hi)
             const int x_lo = rel(-xs0), x_hi = rel(n - xs0);
             XT za[NB / 2][ZROUNDS], zb[NB / 2][ZROUNDS];

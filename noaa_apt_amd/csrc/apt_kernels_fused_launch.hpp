@@ -41,6 +41,11 @@ void fused_launch_phase_std_f32(const FusedLaunch &a);
 void fused_launch_phase_std_i16(const FusedLaunch &a);
 void fused_launch_phase_std_fast_f32(const FusedLaunch &a);
 void fused_launch_phase_std_fast_i16(const FusedLaunch &a);
+// ... 512-thread workgroups (256 < l <= 512: 22 050 Hz)
+void fused_launch_phase512_std_f32(const FusedLaunch &a);
+void fused_launch_phase512_std_i16(const FusedLaunch &a);
+void fused_launch_phase512_std_fast_f32(const FusedLaunch &a);
+void fused_launch_phase512_std_fast_i16(const FusedLaunch &a);
 #ifdef APT_WITH_PROBES
 // timing probes (make PROBES=1; APTGPU_PROBE_STOP=1..7; sources under tools/probes/): the fast 48 kHz f32
 // kernel cut off after a stage (1..5), or complete with 128 / 192-thread workgroups (6, 7)

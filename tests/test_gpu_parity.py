@@ -295,7 +295,7 @@ def test_fused_specialisations_are_used(ctx):
     the specialised work-rate stages (3); 44 100 Hz the phase-resident stage 1 in front of the same stages
     (4); the rest the run-time fused kernel (2); l == 1 the unfused kernels (0)."""
     for rate, profile, want in ((48000, "standard", 1), (96000, "standard", 1), (44100, "standard", 4),
-                                (11025, "standard", 3), (8000, "standard", 3), (22050, "standard", 2),
+                                (11025, "standard", 3), (8000, "standard", 3), (22050, "standard", 4),
                                 (48000, "fast", 2), (48000, "slow", 2), (24960, "standard", 0)):
         _, st = apt.decode(ctx, apt.Settings.profile(profile), synth_apt(rate, 11, 3), apt.Rate.hz(rate),
                            True, return_stats=True)
@@ -360,6 +360,7 @@ def test_table_stage1_long_ragged_batched_and_pcm16(oracle):
 
 PHASE_CASES = [  # (rate, seconds): rates k_fused's phase-resident stage 1 (fused == 4) can serve
     (44100, 40), (44100, 11), (32000, 20), (20800, 15), (16000, 20), (24000, 15), (40000, 12), (15600, 20),
+    (22050, 40), (22050, 11),  # l = 416: 512-thread workgroups
 ]
 
 
