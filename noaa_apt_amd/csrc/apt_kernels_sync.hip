@@ -84,11 +84,12 @@ k_group_max(const float *__restrict__ corr, uint64_t n_corr, GroupMax *__restric
     gm[g] = has_nan ? GroupMax{-kNegInf, kNegInf} : GroupMax{mx, mx};  // exact values: lo = hi
 }
 
-// ------------------------------------------------------------------ k_sync_nodes
+// ------------------------------------------------------------------ k_sync_words + k_sync_slots
 constexpr int kNodesThreads = 128;
 constexpr int kNodesWaves = kNodesThreads / 64;
 constexpr int kChunkGroups = 128;  // own groups per workgroup
 constexpr int kSlotCap = 64;       // node terminals kept per chunk before "overflow"
+static_assert(kNodesThreads == kChunkGroups, "one thread per own group");
 constexpr uint32_t kNanStartTag = 0x80000000u;  // slot entry = NaN position: only matches a search starting on it
 constexpr uint32_t kPosMask = 0x7FFFFFFFu;      // (positions are < 2^31: longer recordings take the walk)
 
@@ -96,15 +97,13 @@ constexpr uint32_t kPosMask = 0x7FFFFFFFu;      // (positions are < 2^31: longer
 // GS + 38*pw - 1 samples
 __host__ __device__ constexpr uint32_t nodes_window(uint32_t pw) { return (GS + 38u * pw - 1u + 3u) & ~3u; }
 
-// bytes of dynamic LDS of k_sync_nodes for r = md/GS groups of look-ahead: terminal words, hi and lo
-// bounds, window maxima, candidate list | NaN words | one F window per wave
-__host__ __device__ constexpr uint32_t nodes_nanw_ofs(uint32_t r)
+// bytes of dynamic LDS of k_sync_words for r = md/GS groups of look-ahead: terminal and NaN words of the own
+// groups | hi, lo bounds and two buffers of running maxima over own + look-ahead groups | window maxima |
+// candidate list | one F window per wave
+__host__ __device__ constexpr uint32_t words_f32_ofs() { return kChunkGroups * 16u; }
+__host__ __device__ constexpr uint32_t words_win_ofs(uint32_t r)
 {
-    return ((kChunkGroups + r + 1) * (8u + 4u + 2u) + (kChunkGroups + 2 * r + 2) * 8u + 15u) & ~15u;
-}
-__host__ __device__ constexpr uint32_t nodes_win_ofs(uint32_t r)
-{
-    return (nodes_nanw_ofs(r) + (kChunkGroups + r + 1) * 8u + 15u) & ~15u;
+    return (words_f32_ofs() + (kChunkGroups + r + 1) * 16u + kChunkGroups * 4u + kChunkGroups * 2u + 15u) & ~15u;
 }
 
 // correlation of the 52 positions of a group from its F window in `win` (LDS, owned by one wave: its
@@ -152,15 +151,20 @@ __device__ __forceinline__ float nodes_eval_window(float *win, bool on, int lane
     return c;
 }
 
+// k_sync_words: terminal words and NaN words of the picker for the 128 groups of a chunk.
 // NL: 64-lane loads per F window kept in registers while a wave has four candidates in flight
 // (window <= 64*NL samples); 0: any window, one candidate at a time straight into LDS.
 // PWC: the pixel width at compile time (the stock profiles: 3, 4, 5) — the 114..190-term correlation
 // chains then unroll and their LDS reads pipeline (run-time loops wait for every read: 8x slower);
 // 0: run-time pw.
+// (Until round 2 one kernel also built the node-terminal lists, for which a workgroup needs the words of
+// the md/GS + 1 groups BEHIND its own: it evaluated the candidates of that look-behind halo a second
+// time, 76 % more work.  The lists are now a second, trivially cheap launch, k_sync_slots, that reads
+// the words back — a kernel boundary instead of an inter-workgroup hand-over inside one launch.)
 template <int NL, int PWC>
 __global__ void __launch_bounds__(kNodesThreads, 4)  // <= 128 VGPRs: must fit beside the front end's waves
-k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t pw_arg,
-             uint32_t r_groups /* md/GS */, uint32_t grid_groups /* spr/GS */, int fast, int use_corr)
+k_sync_words(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t pw_arg, uint32_t r_groups /* md/GS */,
+             int fast, int use_corr)
 {
     const uint32_t pw = PWC > 0 ? static_cast<uint32_t>(PWC) : pw_arg;
     const RecArgs rec = call.rec[blockIdx.y];
@@ -172,36 +176,31 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
     const GroupMax *__restrict__ gm = sp.gm;
     const float *__restrict__ corr = use_corr ? sp.corr : nullptr;  // nullptr: re-evaluate from F
     const float *__restrict__ fsig = sp.f;
-    uint64_t *__restrict__ words_out = sp.words;
-    uint64_t *__restrict__ nanw_out = sp.nanw;
-    uint32_t *__restrict__ slot_nt = sp.slot_nt;
-    uint32_t *__restrict__ slot_cnt = sp.slot_cnt;
     uint32_t *__restrict__ flags = sp.flags;
 
-    // window of groups [gw0, gw0 + nwin): gw0 = g0 - R - 1, nwin = CG + R + 1.  LDS is sized
-    // at launch for the actual R and pw (8.9 KB at R = 96, pw = 3) so these workgroups fit beside
-    // the front end of the next recording, which leaves only ~9 KB of LDS free per CU.
+    // groups [g0, g0 + CG) are the workgroup's own; bounds are needed up to R groups ahead.  LDS is sized
+    // at launch for the actual R and pw (8 KB at R = 96, pw = 3) so these workgroups fit beside the front
+    // end of the next call, which leaves only ~9 KB of LDS free per CU.
     extern __shared__ uint64_t lds_nodes[];
     const int R = static_cast<int>(r_groups);
-    uint64_t *s_words = lds_nodes;                                           // [CG + R + 1]
-    float *s_hi = reinterpret_cast<float *>(s_words + (kChunkGroups + R + 1));  // [CG + 2R + 2] upper bounds
-    float *s_lo = s_hi + (kChunkGroups + 2 * R + 2);                         // [CG + 2R + 2] lower bounds
-    float *s_wm = s_lo + (kChunkGroups + 2 * R + 2);                         // [CG + R + 1]
-    uint16_t *s_cand = reinterpret_cast<uint16_t *>(s_wm + (kChunkGroups + R + 1));  // [CG + R + 1]
+    const int N = kChunkGroups + R + 1;                                       // bounds held: own + look-ahead
+    uint64_t *s_words = lds_nodes;                                            // [CG]
+    uint64_t *s_nanw = s_words + kChunkGroups;                                // [CG]
+    float *s_hi = reinterpret_cast<float *>(reinterpret_cast<char *>(lds_nodes) + words_f32_ofs());  // [N] upper bounds
+    float *s_lo = s_hi + N;                                                   // [N] lower bounds
+    float *s_ma = s_lo + N;                                                   // [N] running maxima of lo ...
+    float *s_mb = s_ma + N;                                                   // [N] ... double-buffered
+    float *s_wm = s_mb + N;                                                   // [CG]
+    uint16_t *s_cand = reinterpret_cast<uint16_t *>(s_wm + kChunkGroups);     // [CG]
     const uint32_t wlen = nodes_window(pw);
-    // NaN bits of the groups of the window, then one F window per wave (16-byte aligned; plain
-    // pointer arithmetic keeps these LDS accesses)
-    uint64_t *s_nanw = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(lds_nodes) + nodes_nanw_ofs(r_groups));  // [CG + R + 1]
-    float *s_win = reinterpret_cast<float *>(reinterpret_cast<char *>(lds_nodes) + nodes_win_ofs(r_groups));
+    float *s_win = reinterpret_cast<float *>(reinterpret_cast<char *>(lds_nodes) + words_win_ofs(r_groups));
     __shared__ uint32_t s_ncand;
-    __shared__ uint32_t s_scan[kNodesWaves];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int64_t g0 = static_cast<int64_t>(blockIdx.x) * kChunkGroups;
-    const int64_t gw0 = g0 - R - 1;
-    const int nwin = kChunkGroups + R + 1;
+    const int64_t gw0 = g0;  // group of window index 0
     const uint64_t md = static_cast<uint64_t>(R) * GS;
 
     if (tid == 0) s_ncand = 0;
@@ -210,94 +209,37 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
         sp.res->status = -1;
         sp.res->reason = -1;
     }
-    for (int q = tid; q < nwin + R; q += kNodesThreads) {
-        const int64_t g = gw0 + q;
-        const bool in = g >= 0 && g < static_cast<int64_t>(ng);
-        const GroupMax v = in ? gm[g] : GroupMax{kNegInf, kNegInf};
+    for (int q = tid; q < N; q += kNodesThreads) {
+        const int64_t g = g0 + q;
+        const GroupMax v = g < static_cast<int64_t>(ng) ? gm[g] : GroupMax{kNegInf, kNegInf};
         s_hi[q] = v.hi;
         s_lo[q] = v.lo;
+        s_ma[q] = v.lo;
     }
+    s_words[tid] = 0ull;  // (kNodesThreads == kChunkGroups)
+    s_nanw[tid] = 0ull;
     __syncthreads();
 
-    // coarse: WM[g] = max(lo[g+1 .. g+R-1]) — the full groups inside every window of group g — as a
-    // sliding-window maximum by the two-block method: with blocks of W = R-1 groups, a window is the
-    // suffix maximum of its first block from its start plus the prefix maximum of its second block up to
-    // its end.  Each block's two scans are one wave's work (shuffles); the suffix maxima borrow the NaN
-    // words' LDS until the windows are combined.
+    // coarse: WM[q] = max(lo[q+1 .. q+W]), W = R-1 — the full groups inside every window of group q's
+    // positions — from running maxima over power-of-two spans (doubling, log2 W steps of one max per
+    // entry): a window is the union of the two spans of K = 2^floor(log2 W) entries at its two ends.
     {
-        const int W = R - 1;              // window length, >= 1 for every legal md
-        const int N = nwin + R;           // entries of s_lo
-        float *s_suf = reinterpret_cast<float *>(s_nanw);  // [nwin + 1], dead before s_nanw is zeroed
-        const int per = (W + 63) / 64;    // consecutive elements per lane (<= 8: md <= 26 k samples, the plan checks)
-        for (int blk = wave; blk * W < N; blk += kNodesWaves) {
-            const int p0 = blk * W;
-            // forward: pre[p] = max(s_lo[p0 .. p]) -> s_wm[p - W] (the window that ENDS at p starts at p - W + 1)
-            {
-                float loc[8];
-                float run = kNegInf;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int e = lane * per + t;
-                    if (t < per && e < W && p0 + e < N) run = fmaxf(run, s_lo[p0 + e]);
-                    loc[t] = run;
-                }
-                float inc = run;
-                for (int d = 1; d < 64; d <<= 1) {
-                    const float o = __shfl_up(inc, d, 64);
-                    if (lane >= d) inc = fmaxf(inc, o);
-                }
-                float carry = __shfl_up(inc, 1, 64);
-                if (lane == 0) carry = kNegInf;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int e = lane * per + t;
-                    const int pidx = p0 + e;
-                    if (t < per && e < W && pidx < N && pidx - W >= 0 && pidx - W < nwin)
-                        s_wm[pidx - W] = fmaxf(loc[t], carry);
-                }
-            }
-            // backward: suf[p] = max(s_lo[p .. block end]) -> s_suf[p]
-            {
-                float loc[8];
-                float run = kNegInf;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int e = W - 1 - (lane * per + t);  // walk the block from its end
-                    if (t < per && e >= 0 && p0 + e < N) run = fmaxf(run, s_lo[p0 + e]);
-                    loc[t] = run;
-                }
-                float inc = run;
-                for (int d = 1; d < 64; d <<= 1) {
-                    const float o = __shfl_up(inc, d, 64);
-                    if (lane >= d) inc = fmaxf(inc, o);
-                }
-                float carry = __shfl_up(inc, 1, 64);
-                if (lane == 0) carry = kNegInf;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int e = W - 1 - (lane * per + t);
-                    const int pidx = p0 + e;
-                    if (t < per && e >= 0 && pidx < N && pidx <= nwin) s_suf[pidx] = fmaxf(loc[t], carry);
-                }
-            }
+        const int W = R - 1;  // >= 1 for every legal md
+        float *a = s_ma, *bq = s_mb;
+        int K = 1;
+        for (; 2 * K <= W; K *= 2) {
+            for (int q = tid; q < N; q += kNodesThreads) bq[q] = (q + K < N) ? fmaxf(a[q], a[q + K]) : a[q];
+            __syncthreads();
+            float *t = a; a = bq; bq = t;
         }
-        __syncthreads();
-        // window of group q = [q+1, q+W]: suffix of the block holding q+1 from q+1, prefix of the block holding
-        // q+W up to q+W (the same block when q+1 starts one: then the prefix alone is the whole window)
-        for (int q = tid; q < nwin; q += kNodesThreads) {
-            const int64_t g = gw0 + q;
-            const float wm = fmaxf(s_suf[q + 1], s_wm[q]);
-            s_wm[q] = wm;
-            const bool valid = g >= 0 && g < static_cast<int64_t>(ng);
-            // pruned only when a later group certainly holds more than this one possibly does (a group
-            // that holds a NaN has hi = +inf: its NaN positions may be starts, see the top)
-            if (valid && !(wm > s_hi[q])) s_cand[atomicAdd(&s_ncand, 1u)] = static_cast<uint16_t>(q);
-        }
-        __syncthreads();
-        for (int q = tid; q < nwin; q += kNodesThreads) {
-            s_words[q] = 0ull;
-            s_nanw[q] = 0ull;
-        }
+        // a[q] = max(lo[q .. q+K-1]) (clipped at N)
+        const int q = tid;
+        const int64_t g = g0 + q;
+        const float wm = fmaxf(a[q + 1], a[q + 1 + W - K]);  // q + W <= CG - 1 + R - 1 < N
+        s_wm[q] = wm;
+        // pruned only when a later group certainly holds more than this one possibly does (a group
+        // that holds a NaN has hi = +inf: its NaN positions may be starts, see the top)
+        if (g < static_cast<int64_t>(ng) && !(wm > s_hi[q])) s_cand[atomicAdd(&s_ncand, 1u)] = static_cast<uint16_t>(q);
         __syncthreads();
     }
 
@@ -487,25 +429,53 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
     }
     __syncthreads();
 
-    // node terminals of the own groups: heads, terminals whose (t - md - 1) is a terminal,
-    // terminals on the grid
-    const int q = tid + R + 1;  // own group index inside the window
-    const int64_t g = g0 + tid;
+    // own groups' words -> HBM (every group of the chunk: zero where nothing was evaluated)
+    {
+        const int64_t g = g0 + tid;
+        if (g < static_cast<int64_t>(ng)) {
+            sp.words[g] = s_words[tid];
+            sp.nanw[g] = s_nanw[tid];
+        }
+    }
+}
+
+// k_sync_slots: the ordered node-terminal list of every chunk of 128 groups from the terminal / NaN words:
+// heads of runs of terminals, terminals whose (t - md - 1) is a terminal or a NaN position, terminals on the
+// grid, and the NaN positions a phase can start on (tagged with bit 31).  One thread per group.
+__global__ void __launch_bounds__(kNodesThreads)
+k_sync_slots(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t pw, uint32_t r_groups /* md/GS */,
+             uint32_t grid_groups /* spr/GS */)
+{
+    const RecArgs rec = call.rec[blockIdx.y];
+    const uint64_t n_corr = rec.w - 38ull * pw;
+    const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
+    if (blockIdx.x * static_cast<uint32_t>(kChunkGroups) >= ng) return;
+    const SlotPtrs sp = slots[rec.slot];
+    const uint64_t *__restrict__ words = sp.words;
+    const uint64_t *__restrict__ nanw = sp.nanw;
+    uint32_t *__restrict__ slot_nt = sp.slot_nt;
+    __shared__ uint32_t s_scan[kNodesWaves];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t R = r_groups;
+    const int64_t g = static_cast<int64_t>(blockIdx.x) * kChunkGroups + tid;
+    auto word_at = [&](const uint64_t *p, int64_t gi) -> uint64_t {
+        return (gi >= 0 && gi < static_cast<int64_t>(ng)) ? p[gi] : 0ull;
+    };
     uint64_t nw = 0, ns = 0;
     if (g < static_cast<int64_t>(ng)) {
-        const uint64_t wd = s_words[q];
-        const uint64_t nb = s_nanw[q];
-        const uint64_t prev_bit = s_words[q - 1] >> (GS - 1);
+        const uint64_t wd = words[g];
+        const uint64_t nb = nanw[g];
+        const uint64_t prev_bit = word_at(words, g - 1) >> (GS - 1);
         const uint64_t heads = wd & ~(((wd << 1) | prev_bit) & kGroupMask);
         // positions md+1 behind a terminal or behind a NaN position, and the grid: where a phase can start
-        const uint64_t shifted = ((s_words[q - R] << 1) | (s_words[q - R - 1] >> (GS - 1))) & kGroupMask;
-        const uint64_t shifted_nan = ((s_nanw[q - R] << 1) | (s_nanw[q - R - 1] >> (GS - 1))) & kGroupMask;
+        const uint64_t shifted = ((word_at(words, g - R) << 1) | (word_at(words, g - R - 1) >> (GS - 1))) & kGroupMask;
+        const uint64_t shifted_nan = ((word_at(nanw, g - R) << 1) | (word_at(nanw, g - R - 1) >> (GS - 1))) & kGroupMask;
         const uint64_t on_grid = (g % grid_groups == 0) ? 1ull : 0ull;
         const uint64_t starts = shifted | shifted_nan | on_grid;
         nw = wd & (heads | starts);
         ns = nb & starts & ~wd;  // NaN positions a phase can start on (position 0 was clamped: never NaN)
-        words_out[g] = wd;
-        nanw_out[g] = nb;
     }
     // ordered compaction of the node-terminal positions of this chunk (NaN starts tagged with bit 31)
     const uint32_t cnt = static_cast<uint32_t>(__popcll(nw | ns));
@@ -531,8 +501,8 @@ k_sync_nodes(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
         ++ofs;
     }
     if (tid == 0) {
-        slot_cnt[blockIdx.x] = total;
-        if (total > kSlotCap) atomicOr(&flags[0], 1u);
+        sp.slot_cnt[blockIdx.x] = total;
+        if (total > kSlotCap) atomicOr(&sp.flags[0], 1u);
     }
 }
 
@@ -920,19 +890,20 @@ void sync_nodes(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, ui
     const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
     const uint32_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
     const uint32_t r = md / GS;
-    const size_t lds = nodes_win_ofs(r) + static_cast<size_t>(kNodesWaves) * nodes_window(pw) * sizeof(float);
+    const size_t lds = words_win_ofs(r) + static_cast<size_t>(kNodesWaves) * nodes_window(pw) * sizeof(float);
     const dim3 grid(chunks, call.count);
     const uint32_t wneed = GS + 38u * pw - 1u;
-#define APT_NODES_LAUNCH(NL, PWC)                                                                              \
-    hipLaunchKernelGGL((k_sync_nodes<NL, PWC>), grid, dim3(kNodesThreads), lds, s, call, d_slots, pw, r, spr / GS, \
-                       fast ? 1 : 0, use_corr ? 1 : 0)
-    if (pw == 3) APT_NODES_LAUNCH(3, 3);        // standard profile
-    else if (pw == 4) APT_NODES_LAUNCH(4, 4);   // fast profile
-    else if (pw == 5) APT_NODES_LAUNCH(4, 5);   // slow profile
-    else if (wneed <= 192) APT_NODES_LAUNCH(3, 0);
-    else if (wneed <= 256) APT_NODES_LAUNCH(4, 0);
-    else APT_NODES_LAUNCH(0, 0);
-#undef APT_NODES_LAUNCH
+#define APT_WORDS_LAUNCH(NL, PWC)                                                                              \
+    hipLaunchKernelGGL((k_sync_words<NL, PWC>), grid, dim3(kNodesThreads), lds, s, call, d_slots, pw, r, fast ? 1 : 0, \
+                       use_corr ? 1 : 0)
+    if (pw == 3) APT_WORDS_LAUNCH(3, 3);        // standard profile
+    else if (pw == 4) APT_WORDS_LAUNCH(4, 4);   // fast profile
+    else if (pw == 5) APT_WORDS_LAUNCH(4, 5);   // slow profile
+    else if (wneed <= 192) APT_WORDS_LAUNCH(3, 0);
+    else if (wneed <= 256) APT_WORDS_LAUNCH(4, 0);
+    else APT_WORDS_LAUNCH(0, 0);
+#undef APT_WORDS_LAUNCH
+    hipLaunchKernelGGL(k_sync_slots, grid, dim3(kNodesThreads), 0, s, call, d_slots, pw, r, spr / GS);
 }
 
 // node-terminal capacity and uint32 words of scratch k_sync_orbit needs for a work signal of w samples
