@@ -53,6 +53,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace apt::gpu {
@@ -600,7 +601,7 @@ __device__ __forceinline__ void gst(uint32_t *p, uint32_t v)
 // next non-empty one.  Node ids: 0 root, 1..n_grid grid cells 2..kc, base_d + slot entry, END.
 __global__ void __launch_bounds__(kOrbitThreads, 8)
 k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t spr_in, uint32_t md_in,
-                    uint32_t pw, int force_walk)
+                    uint32_t pw, int force_walk, uint32_t lds_entries)
 {
     const RecArgs rec = call.rec[blockIdx.x];
     const SlotPtrs sp = slots[rec.slot];
@@ -715,7 +716,8 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         }
         __syncthreads();
         uint32_t lo = 0, hi = base_d;
-        for (int level = 0; level < kMaxLevels && lo < hi; ++level) {
+        int level = 0;
+        for (; level < kMaxLevels && lo < hi; ++level) {
             for (uint32_t idx = lo + tid; idx < hi; idx += kOrbitThreads) {
                 const uint32_t v = gld(w_list + idx);
                 uint32_t cell, u = 0, nx = END, nxcell = 0;
@@ -747,7 +749,11 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
                 else if (nxcell != cell + 1) s_conflict = 1;
                 if (nx != END && nx >= base_d) {  // grid targets are seeds: already visited
                     const uint32_t bit = 1u << (nx & 31);
-                    if (!(atomicOr(w_mark + (nx >> 5), bit) & bit)) gst(w_list + atomicAdd(&s_count, 1u), nx);
+                    if (!(atomicOr(w_mark + (nx >> 5), bit) & bit)) {
+                        const uint32_t at = atomicAdd(&s_count, 1u);
+                        gst(w_list + at, nx);
+                        gst(w_jb + nx, at);  // its index in the visited list (w_jb is free until the doubling)
+                    }
                 }
             }
             __syncthreads();
@@ -757,6 +763,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         }
         if (lo < hi) walk = true;  // not closed within the level budget: take the general path
         count = hi;
+        if (tid == 0) flags[12] = static_cast<uint32_t>(level);  // breadth-first levels (diagnostics)
     }
     stamp(0);  // reachable set closed
 
@@ -788,7 +795,35 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
     // ---- otherwise: orbit of the root by pointer doubling over the visited nodes:
     // path[m + 2^r] = J_r[path[m]],  J_{r+1} = J_r o J_r (double-buffered)
     uint32_t *ja = w_ja, *jb = w_jb;
-    if (!direct) {
+    // (a) in LDS when the visited nodes fit (they do unless the recording is pathological): jump tables
+    // over the nodes' indices in the visited list, 16 bits each — log2(cells) rounds of LDS reads and
+    // barriers, ~10 us instead of the ~130 us the same rounds cost through L2
+    extern __shared__ uint16_t lds_orbit[];
+    const uint32_t lds_cap = lds_entries;  // uint16 entries of dynamic LDS
+    const bool in_lds = !direct && path_cap + 2 * (count + 1) <= lds_cap && count < 0xFFFFu;
+    if (in_lds) {
+        uint16_t *pth = lds_orbit;              // [path_cap]
+        uint16_t *la = pth + path_cap;          // [count + 1]
+        uint16_t *lb = la + (count + 1);        // [count + 1]
+        const uint16_t ENDC = static_cast<uint16_t>(count);
+        for (uint32_t idx = tid; idx < count; idx += kOrbitThreads) {
+            const uint32_t nx = gld(w_ja + gld(w_list + idx));
+            la[idx] = nx == END ? ENDC : static_cast<uint16_t>(nx < base_d ? nx : gld(w_jb + nx));  // seeds: index == id
+        }
+        if (tid == 0) { la[count] = ENDC; lb[count] = ENDC; pth[0] = 0; }
+        __syncthreads();
+        for (uint32_t span = 1; span < path_cap; span <<= 1) {
+            for (uint32_t mI = tid; mI < span && mI + span < path_cap; mI += kOrbitThreads) pth[mI + span] = la[pth[mI]];
+            for (uint32_t idx = tid; idx < count; idx += kOrbitThreads) lb[idx] = la[la[idx]];
+            __syncthreads();
+            uint16_t *t = la; la = lb; lb = t;
+        }
+        for (uint32_t k = tid; k < path_cap; k += kOrbitThreads)
+            gst(w_path + k, pth[k] == ENDC ? END : gld(w_list + pth[k]));
+        __syncthreads();
+    }
+    // (b) through global memory otherwise
+    if (!direct && !in_lds) {
     constexpr int kKeep = 4;  // visited ids (and their current jump) kept in registers
     uint32_t vk[kKeep], jk[kKeep];
 #pragma unroll
@@ -812,7 +847,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         __syncthreads();
         uint32_t *t = ja; ja = jb; jb = t;
     }
-    }  // !direct
+    }  // !direct && !in_lds
     stamp(1);  // orbit extracted
 
     // ---- peak list: path[k] (k >= 1) starts at s in cell c; pushes fill
@@ -862,7 +897,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         flags[2] = nt_cap;
         flags[3] = n_nodes;
         flags[4] = count;
-        flags[6] = direct ? 1u : 0u;
+        flags[6] = direct ? 1u : (in_lds ? 2u : 0u);  // orbit: 1 read off directly, 2 doubling in LDS, 0 doubling through L2
         flags[11] = flags[7];  // candidates k_sync_nodes settled with exact window maxima; re-armed
         flags[7] = 0u;
     }
@@ -927,8 +962,13 @@ void sync_orbit(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, ui
 {
     if (call.count == 0) return;
     // force: 0 = parallel picker, 1 = sequential walk over the terminal words
-    hipLaunchKernelGGL(k_sync_orbit_global, dim3(call.count), dim3(kOrbitThreads), 0, s, call, d_slots, spr, md, pw,
-                       force == 1 ? 1 : 0);
+    // 24 KB of LDS for the doubling path's jump tables: a recording's visited nodes (about one per image row plus
+    // the seeds) fit unless it is hours long; the kernel falls back to tables in global memory when they do not
+    // (APTGPU_ORBIT_LDS=0, tests: always through global memory)
+    const char *e = std::getenv("APTGPU_ORBIT_LDS");
+    const uint32_t kOrbitLdsEntries = (e && e[0] == '0') ? 0u : 12288u;
+    hipLaunchKernelGGL(k_sync_orbit_global, dim3(call.count), dim3(kOrbitThreads), kOrbitLdsEntries * sizeof(uint16_t), s,
+                       call, d_slots, spr, md, pw, force == 1 ? 1 : 0, kOrbitLdsEntries);
 }
 
 }  // namespace apt::gpu

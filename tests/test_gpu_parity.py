@@ -618,12 +618,19 @@ def test_rows_cap_clamps_the_result_record(oracle):
         apt.Plan(apt.Settings(work_rate=1), apt.Rate.hz(48000), False, max_samples=48000)  # spr == 0
 
 
-def test_picker_paths_direct_and_doubling(oracle):
+@pytest.mark.parametrize("lds", [True, False])
+def test_picker_paths_direct_and_doubling(oracle, monkeypatch, lds):
     """The global-memory picker reads the orbit off directly on a confluent (continuous APT)
-    recording and falls back to pointer doubling otherwise; both bit-exact."""
+    recording and extracts it by pointer doubling otherwise — with its jump tables in LDS, or (forced
+    here; else only for recordings whose visited nodes do not fit) through global memory; all bit-exact."""
     torch = pytest.importorskip("torch")
+    if not lds:
+        monkeypatch.setenv("APTGPU_ORBIT_LDS", "0")
     dev = torch.device("cuda:0")
-    cases = [("apt", synth_apt(48000, 20, 5)), ("noise", synth_noise(48000, 20.0, 5, sigma=4000.0))]
+    cases = [("apt", synth_apt(48000, 20, 5)), ("noise", synth_noise(48000, 20.0, 5, sigma=4000.0)),
+             ("noise-long", synth_noise(48000, 120.0, 6, sigma=3000.0)),
+             ("gaps", np.concatenate([synth_apt(48000, 8, 7), synth_noise(48000, 3.0, 8, sigma=500.0),
+                                      synth_apt(48000, 9, 9), np.zeros(48000, f32), synth_apt(48000, 7, 10)]))]
     seen = {}
     for name, x in cases:
         plan = apt.Plan(apt.Settings(), apt.Rate.hz(48000), True, max_samples=x.size)
@@ -634,12 +641,16 @@ def test_picker_paths_direct_and_doubling(oracle):
         plan.decode_device([d_in.data_ptr()], [x.size], [d_out.data_ptr()], [cap])
         res = plan.results(1)[0]
         flags = plan.read_internal("picker_flags", np.uint32, 32)
-        want = oracle.decode(x, 48000, True)
+        want, st = oracle.decode(x, 48000, True, want_steps=True)
         assert_bitexact(d_out[:res.n_out].cpu().numpy(), want, name)
+        assert plan.sync_positions(0).tolist() == st["sync_pos"].tolist(), name
         seen[name] = (int(flags[1]), int(flags[6]))
         plan.close()
     assert seen["apt"] == (2, 1)       # global kernel, direct orbit
-    assert seen["noise"][0] == 2       # global kernel (orbit direct or doubling, data dependent)
+    assert all(v[0] in (1, 2) for v in seen.values())  # (1: the walk, when a chunk's node list overflowed — the zeros)
+    doubling = [v[1] for v in seen.values() if v[0] == 2 and v[1] != 1]
+    assert doubling, "no case took the doubling path: the test has no teeth"
+    assert all(d == (2 if lds else 0) for d in doubling), seen
 
 
 # ------------------------------------------------------------------ plans / batch

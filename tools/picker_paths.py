@@ -34,7 +34,7 @@ def main():
             plan.decode_device([d.data_ptr()], [x.size], [out.data_ptr()], [cap])
             torch.cuda.synchronize()
         t = plan.collect_timing()
-        print(f"seed {2 + 1000 * j}: rows {res.n_rows} path {int(f[1])} direct {int(f[6])} nodes {int(f[3])} visited {int(f[4])} "
+        print(f"seed {2 + 1000 * j}: rows {res.n_rows} path {int(f[1])} direct {int(f[6])} nodes {int(f[3])} visited {int(f[4])} levels {int(f[12])} "
               f"stamps {[int(v) for v in f[8:11]]} orbit_ms {t.get('sync_orbit', (0, 0))[0]:.4f} nodes_ms {t.get('sync_nodes', (0, 0))[0]:.4f}")
         plan.close()
 
