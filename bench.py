@@ -3,9 +3,9 @@
 
 One "step" = one pass of the decode() hot path (resample -> AM envelope -> low-pass -> sync
 correlation + peak picker -> row gather) over one batch of synthetic input already resident in
-HBM: `--batch` (default 8) independent recordings of BASELINE.json configs[1] — synthetic 48 kHz
+HBM: `--batch` (default 16) independent recordings of BASELINE.json configs[1] — synthetic 48 kHz
 APT, 10 min (28.8 M samples), `standard` profile — decoded by ONE aptgpu_plan_decode_device call,
-i.e. one launch per stage over the eight recordings.  Every GPU works on its own batch (weak
+i.e. one launch per stage over the sixteen recordings (1.8 GB of input per step).  Every GPU works on its own batch (weak
 scaling, no collective on the data path; recordings never talk to each other).  `--batch 1` is
 the recording-by-recording shape of round 1.
 
@@ -48,9 +48,9 @@ def main():
     ap.add_argument("--inputs", type=int, default=4,
                     help="distinct recordings resident in HBM, decoded round-robin (4 x 115 MB exceeds "
                          "the 256 MB Infinity Cache, so every step reads its input from HBM)")
-    ap.add_argument("--batch", type=int, default=8,
-                    help="recordings per decode_device call = per step (default 8: one launch per stage covers the "
-                         "eight recordings; BASELINE config 4's per-GPU share is --seconds 900 --batch 32); `value` "
+    ap.add_argument("--batch", type=int, default=16,
+                    help="recordings per decode_device call = per step (default 16: one launch per stage covers the "
+                         "sixteen recordings; BASELINE config 4's per-GPU share is --seconds 900 --batch 32); `value` "
                          "counts all their samples")
     ap.add_argument("--user-stream", action="store_true",
                     help="experiment: give the plan torch's stream as ctx.stream (every call then waits for "
@@ -325,7 +325,7 @@ def main():
         # (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 2x read correction applied by
         # tools/summarize_pmc.py) for THIS workload and mode; null when no matching profile is committed
         traffic, traffic_src, sq = None, None, None
-        if (args.rate, args.seconds, args.profile, max(1, args.batch)) == (48000, 600.0, "standard", 8) \
+        if (args.rate, args.seconds, args.profile, max(1, args.batch)) == (48000, 600.0, "standard", 16) \
                 and dom[0] == "fused_front_end" and args.mode in ("strict", "fast"):
             try:
                 f = os.path.join(ROOT, "profiles", f"r02_hbm_traffic_{args.mode}.json")
@@ -337,15 +337,17 @@ def main():
                 sq = json.load(open(os.path.join(ROOT, "profiles", f"r02_sq_counters_{args.mode}.json")))
             except Exception:
                 sq = None
-        # arithmetic of the path per work-rate sample: two flops per FIR tap, ~8 for
-        # the envelope, one add per template sample of the strict correlation (22 in fast mode)
+        # arithmetic the front end EXECUTES per work-rate sample: two flops per FIR tap, ~8 for the envelope,
+        # 22 for the sync correlation from pulse sums (every mode: the strict front end only bounds the
+        # reference's 114-term chain, which the picker then evaluates for ~3 % of the positions), +3 for the
+        # strict mode's sum of |F| behind those bounds
         w_len = float(res.work_len)
         taps1 = plan.info.n_resample_taps / plan.info.l
-        corr_ops = 22.0 if args.mode == "fast" else float(plan.info.n_sync_taps)
+        corr_ops = 22.0 if args.mode == "fast" else 25.0
         flops = w_len * (2.0 * taps1 + 8.0 + 2.0 * plan.info.n_lowpass_taps + corr_ops) * max(1, args.batch)
         valu = {
-            "note": "the kernel is bound by VALU issue, not HBM (DESIGN.md §5.1): arithmetic of the path per launch "
-                    "over the isolated kernel time, against the 157.3 TFLOP/s fp32 vector peak",
+            "note": "the kernel is bound by VALU issue, not HBM (DESIGN.md §5.1): arithmetic the front end executes "
+                    "per launch over the isolated kernel time, against the 157.3 TFLOP/s fp32 vector peak",
             "algorithmic_flops_per_launch": flops,
             "achieved_tflops": round(flops / (alone_ms * 1e-3) / 1e12, 3) if alone_ms > 0 else None,
             "pct_of_fp32_vector_peak": round(100.0 * flops / (alone_ms * 1e-3) / 157.3e12, 2) if alone_ms > 0 else None,
@@ -354,7 +356,10 @@ def main():
             valu.update({k: sq[k] for k in ("valu_instructions_per_wave", "waves_per_launch", "issue_floor_us",
                                             "source") if k in sq})
             if alone_ms > 0 and "issue_floor_us" in sq:
-                valu["achieved_frac_of_issue_floor"] = round(sq["issue_floor_us"] / (alone_ms * 1e3), 4)
+                # (the counters were collected on single-recording launches: the floor of a launch over
+                # `batch` recordings is that many times as long)
+                valu["issue_floor_us_per_launch"] = round(sq["issue_floor_us"] * max(1, args.batch), 2)
+                valu["achieved_frac_of_issue_floor"] = round(sq["issue_floor_us"] * max(1, args.batch) / (alone_ms * 1e3), 4)
         line = {
             "metric": "Msamples/sec WAV->APT-line decode",
             "value": round(value, 3),

@@ -36,8 +36,16 @@ def main():
                 d[name + "_fraction_of_wave_time"] = round(per[k] / per["SQ_WAVE_CYCLES"], 4)
     if "SQ_LDS_IDX_ACTIVE" in per and "SQ_LDS_BANK_CONFLICT" in per and per["SQ_LDS_IDX_ACTIVE"]:
         d["lds_bank_conflict_fraction_of_lds_cycles"] = round(per["SQ_LDS_BANK_CONFLICT"] / per["SQ_LDS_IDX_ACTIVE"], 4)
-    print(json.dumps({"note": note, "launches_averaged": max((len(v) for v in agg.values()), default=0),
-                      "per_launch": per, "derived": d}, indent=1))
+    out = {"note": note, "launches_averaged": max((len(v) for v in agg.values()), default=0),
+           "per_launch": per, "derived": d}
+    # what bench.py's roofline.valu quotes: the 100 %-issue floor of one launch — every VALU instruction keeps
+    # its SIMD's pipe busy for SQ_ACTIVE_INST_VALU quad-cycles in all, over 256 CUs x 4 SIMDs at 2.4 GHz
+    if w and "SQ_ACTIVE_INST_VALU" in per:
+        out["valu_instructions_per_wave"] = d.get("valu_instructions_per_wave")
+        out["waves_per_launch"] = w
+        out["issue_floor_us"] = round(per["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / 2.4e3, 2)
+        out["source"] = "SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz, one recording per launch (tools/collect_sq.sh)"
+    print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
