@@ -164,7 +164,7 @@ template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
 // the picker's kernels of the previous call — one 1024-thread workgroup among them — run beside this one)
 __global__ void __launch_bounds__(NTHR, M == -1 ? ((NTHR > 256 ? 2 : 3) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs) or two 512-thread (<= 128) workgroups per CU */
                                      : M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
-                                               : ((sizeof(XT) == 2 ? 4 : APT_FUSED_MIN_WAVES) * NTHR + 255) / 256)
+                                               : (APT_FUSED_MIN_WAVES * NTHR + 255) / 256)
 k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 {
     // The call's arguments are read where they lie, in the kernel-argument segment (constant address

@@ -31,11 +31,21 @@ for MODE in strict fast; do
   done
 done
 else
-for MODE in strict fast; do
+for MODE in ${MODES:-strict fast}; do
   # (1) the bench line itself (default shape: 16 recordings per call), and the driver's shape (20 steps)
   (cd $R && python bench.py --mode $MODE > $O/bench_$MODE.json 2> $O/bench_$MODE.err)
   (cd $R && python bench.py --mode $MODE --steps 20 --warmup 5 --no-extras > $O/bench_${MODE}_steps20.json 2>> $O/bench_$MODE.err)
 done
 # (5) the other configs
+(cd $R && python bench.py --no-extras --seconds 900 --batch 32 --inputs 32 --steps 12 --warmup 2 > $O/bench_config4_share.json 2>> $O/bench_strict.err)
+(cd $R && python bench.py --no-extras --mode fast --seconds 900 --batch 32 --inputs 32 --steps 12 --warmup 2 > $O/bench_config4_share_fast.json 2>> $O/bench_strict.err)
+(cd $R && python bench.py --no-extras --rate 96000 --seconds 3600 --batch 1 --inputs 2 --steps 20 --warmup 3 > $O/bench_config3.json 2>> $O/bench_strict.err)
+(cd $R && python bench.py --no-extras --mode fp16taps > $O/bench_fp16taps.json 2>> $O/bench_strict.err)
+(cd $R && python bench.py --no-extras --batch 1 > $O/bench_strict_batch1.json 2>> $O/bench_strict.err)
+(cd $R && python bench.py --no-extras --batch 8 > $O/bench_strict_batch8.json 2>> $O/bench_strict.err)
+(cd $R && python bench.py --no-extras --rate 44100 > $O/bench_44100.json 2>> $O/bench_strict.err)
+(cd $R && python bench.py --no-extras --rate 11025 > $O/bench_11025.json 2>> $O/bench_strict.err)
+(cd $R && python bench.py --no-extras --rate 22050 > $O/bench_22050.json 2>> $O/bench_strict.err)
+(cd $R && python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras > $O/bench_torchrun_n1.json 2> $O/bench_torchrun.err)
 fi
 ls $O
