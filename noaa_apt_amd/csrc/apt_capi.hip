@@ -76,6 +76,7 @@ void aptgpu_plan_destroy(aptgpu_plan *plan)
     for (hipStream_t st : plan->streams) (void)hipStreamSynchronize(st);
     if (plan->ev_user) (void)hipEventDestroy(plan->ev_user);
     for (hipStream_t st : plan->streams) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : plan->ev_front) (void)hipEventDestroy(ev);
     delete plan;
 }
 

@@ -191,6 +191,16 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     for (auto &st : plan->streams)
         hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
     plan->stream = plan->streams[0];
+    {
+        // (not with a user stream: such plans may be captured into a HIP graph, call by call, and an event
+        // recorded before the capture cannot be waited for inside it)
+        const char *e = std::getenv("APTGPU_FRONT_SERIAL");  // A/B switch
+        plan->front_serial = (e ? e[0] != '0' : max_batch >= 4) && !plan->user_stream && depth > 1;
+        if (plan->front_serial) {
+            plan->ev_front.resize(static_cast<size_t>(depth));
+            for (auto &ev : plan->ev_front) hip_check(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+        }
+    }
 
     plan->max_work_len = plan->work_len_for(max_samples);
     const uint64_t rows = plan->spr ? plan->max_work_len / plan->spr + 2 : 2;
@@ -402,13 +412,14 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
         apt::hip_check(hipEventRecord(ev_user, user_stream), "hipEventRecord");
         apt::hip_check(hipStreamWaitEvent(cur, ev_user, 0), "hipStreamWaitEvent");
     }
-    auto timed = [&](const char *name, auto &&launch) {
+    auto timed_on = [&](hipStream_t st, const char *name, auto &&launch) {
         const bool dominant = !std::strcmp(name, "fused_front_end") || !std::strcmp(name, "resample_generic") ||
                               !std::strcmp(name, "resample_f16taps");
-        timer.begin(cur, name, dominant);
+        timer.begin(st, name, dominant);
         launch();
-        timer.end(cur);
+        timer.end(st);
     };
+    auto timed = [&](const char *name, auto &&launch) { timed_on(cur, name, launch); };
 
     const bool use_fused = fused != 0 && !keep_steps;
     const bool want_sync = sync && work_is_multiple;
@@ -497,24 +508,31 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
     const uint32_t t2 = static_cast<uint32_t>(taps_lowpass.size());
     if (use_fused && (fused == 1 || fused == 3 || fused == 4)) {
         // 1-3 fused: resample -> envelope -> low-pass (-> correlation maxima) in one launch per input
-        // kind (apt_kernels_fused.hip)
+        // kind (apt_kernels_fused.hip), behind the previous call's front end (see front_serial, apt_plan.hpp)
+        hipStream_t fs = cur;
+        if (front_serial && !live.empty() && prev_front >= 0 && prev_front != last_stream)
+            apt::hip_check(hipStreamWaitEvent(cur, ev_front[static_cast<size_t>(prev_front)], 0), "hipStreamWaitEvent");
         for (int kind = 0; kind < 2; ++kind) {
             std::vector<int> idx;
             for (int i : live)
                 if (is_pcm[static_cast<size_t>(i)] == kind) idx.push_back(i);
             for_chunks(idx, [&](const CallArgs &c, uint64_t max_w, uint32_t) {
-                timed("fused_front_end", [&] {
+                timed_on(fs, "fused_front_end", [&] {
                     const int kmode = fused_f16 ? 1 : (fused_fast ? 2 : 0);
-                    const bool ok = fused == 4 ? fused_phase_front_end(cur, table_geom, kmode, kind == 1, c,
+                    const bool ok = fused == 4 ? fused_phase_front_end(fs, table_geom, kmode, kind == 1, c,
                                                                        d_fused_params.ptr, max_w)
-                                  : fused == 3 ? fused_table_front_end(cur, table_geom, kmode, kind == 1, c,
+                                  : fused == 3 ? fused_table_front_end(fs, table_geom, kmode, kind == 1, c,
                                                                        d_fused_params.ptr, max_w)
-                                               : fused_front_end(cur, l, m, t1, t2, pw, kmode, kind == 1, c,
+                                               : fused_front_end(fs, l, m, t1, t2, pw, kmode, kind == 1, c,
                                                                  d_fused_params.ptr, max_w);
                     if (!ok)
                         throw apt::Error{apt::ErrorKind::Internal, "fused front end: no kernel for this geometry"};
                 });
             });
+        }
+        if (front_serial && !live.empty()) {
+            apt::hip_check(hipEventRecord(ev_front[static_cast<size_t>(last_stream)], cur), "hipEventRecord");
+            prev_front = last_stream;
         }
     } else if (use_fused) {
         for (int i : live) {

@@ -92,6 +92,17 @@ struct aptgpu_plan {
     // (in-order => no hazards, no cross-stream events, nothing for the host to wait on).
     std::vector<hipStream_t> streams;
     hipStream_t stream = nullptr;       // = streams[0] (host-API helpers, plan-creation uploads)
+    // Batched plans serialise the fused front ends of consecutive calls: the front end of call j+1 (on its own
+    // stream) waits for an event recorded behind the front end of call j (on another), so front ends run one
+    // after the other, each with the whole GPU, and the picker / gather of call j overlap the front end of
+    // call j+1.  Left alone, the front ends of `depth` consecutive calls start together, share the GPU,
+    // finish together — and their latency-bound chains then run with nothing to overlap (a kernel trace showed
+    // three calls marching in step: 2.4 ms of front ends, then 0.8 ms of chains).  Worth 7 % in a 20-step run
+    // (477 against 445 Gsamples/s), nothing in a long one (the chains cost their own time either way); one
+    // extra low-priority stream for all front ends was tried as well and is no better.
+    bool front_serial = false;
+    std::vector<hipEvent_t> ev_front;   // [depth]: behind the front end of the latest call on that stream
+    int prev_front = -1;                // stream index whose ev_front the next front end waits for
     hipStream_t user_stream = nullptr;  // ctx.stream: inputs are ordered after it (may be null)
     hipEvent_t ev_user = nullptr;
     uint64_t calls = 0;             // calls enqueued so far (stream = calls % depth)
