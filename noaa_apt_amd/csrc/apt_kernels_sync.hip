@@ -100,7 +100,7 @@ __host__ __device__ constexpr uint32_t nodes_window(uint32_t pw) { return (GS + 
 
 // bytes of dynamic LDS of k_sync_words for r = md/GS groups of look-ahead: terminal and NaN words of the own
 // groups | hi, lo bounds and two buffers of running maxima over own + look-ahead groups | window maxima |
-// candidate list | two F windows per wave
+// candidate list | one F window per wave
 __host__ __device__ constexpr uint32_t words_f32_ofs() { return kChunkGroups * 16u; }
 __host__ __device__ constexpr uint32_t words_win_ofs(uint32_t r)
 {
@@ -251,8 +251,7 @@ k_sync_words(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
     constexpr int kBatch = NL > 0 ? 4 : 1;
     constexpr int NLR = NL > 0 ? NL : 1;
     constexpr uint16_t kDeferred = 0x8000u;  // s_cand entry: to be settled in the second pass
-    float *wa = s_win + static_cast<size_t>(wave) * 2 * wlen;  // this wave's F windows: two candidates are
-    float *wb = wa + wlen;                                      // evaluated side by side (packed additions)
+    float *wa = s_win + static_cast<size_t>(wave) * wlen;  // this wave's F window
     const uint32_t wneed = GS + 38u * pw - 1u;  // samples of a window
     // F window of the group at `base` -> wa -> its correlation values
     auto eval_group = [&](uint64_t base, bool on) -> float {
@@ -382,40 +381,21 @@ k_sync_words(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
                 }
             }
         }
-        if constexpr (NL > 0) {
-            // the candidates' correlation values, two groups at a time: both F windows -> LDS, then (strict) ONE
-            // chain of packed additions for the same lane of both groups — half the LDS reads (ds_read2_b32
-            // fetches both windows' sample) and half the additions of two separate chains
-            if (corr == nullptr) {
-#pragma unroll
-                for (int ep = 0; ep < kBatch; ep += 2) {
-                    if (qv[ep] < 0) continue;  // wave-uniform (candidates fill the batch from the front)
-#pragma unroll
-                    for (int t = 0; t < NL; ++t) {
-                        if (lane + 64u * t < wlen) {
-                            wa[lane + 64 * t] = fa[ep][t];
-                            wb[lane + 64 * t] = fa[ep + 1][t];  // (zeros when the batch has no such candidate)
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (fast) {
-                        cv[ep] = nodes_eval_window<NL, PWC>(wa, inv[ep], lane, pw, fast);
-                        cv[ep + 1] = nodes_eval_window<NL, PWC>(wb, inv[ep + 1], lane, pw, fast);
-                    } else {
-                        const int ln = lane < GS ? lane : 0;  // (lanes past the group: any position inside the window)
-                        const sync_f2 c2 = sync_corr_strict2(pw, [&](uint32_t j) { return (sync_f2){wa[ln + j], wb[ln + j]}; });
-                        cv[ep] = inv[ep] ? c2.x : kNegInf;
-                        cv[ep + 1] = inv[ep + 1] ? c2.y : kNegInf;
-                    }
-                    __builtin_amdgcn_wave_barrier();  // the windows are dead from here on: wa is reused
-                }
-            }
-        }
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
             if (qv[e] < 0) continue;  // wave-uniform
-            if constexpr (NL == 0) {
-                if (corr == nullptr) cv[e] = eval_group(static_cast<uint64_t>(gw0 + qv[e]) * GS, inv[e]);
+            if (corr == nullptr) {
+                // F window of the candidate group -> LDS -> its 52 correlation values
+                if constexpr (NL > 0) {
+#pragma unroll
+                    for (int t = 0; t < NL; ++t)
+                        if (lane + 64u * t < wlen) wa[lane + 64 * t] = fa[e][t];
+                    __builtin_amdgcn_wave_barrier();
+                    cv[e] = nodes_eval_window<NL, PWC>(wa, inv[e], lane, pw, fast);
+                    __builtin_amdgcn_wave_barrier();  // the window is dead from here on: wa is reused
+                } else {
+                    cv[e] = eval_group(static_cast<uint64_t>(gw0 + qv[e]) * GS, inv[e]);
+                }
             }
             if (!settle(std::false_type{}, qv[e], cv[e], c2v[e], inv[e])) {
                 if (lane == 0) s_cand[c0 + e] = static_cast<uint16_t>(qv[e]) | kDeferred;
@@ -945,7 +925,7 @@ void sync_nodes(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, ui
     const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
     const uint32_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
     const uint32_t r = md / GS;
-    const size_t lds = words_win_ofs(r) + static_cast<size_t>(kNodesWaves) * 2 * nodes_window(pw) * sizeof(float);
+    const size_t lds = words_win_ofs(r) + static_cast<size_t>(kNodesWaves) * nodes_window(pw) * sizeof(float);
     const dim3 grid(chunks, call.count);
     const uint32_t wneed = GS + 38u * pw - 1u;
 #define APT_WORDS_LAUNCH(NL, PWC)                                                                              \

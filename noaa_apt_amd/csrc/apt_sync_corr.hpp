@@ -51,31 +51,6 @@ __device__ __forceinline__ float sync_corr_strict(uint32_t pw, At &&at)
     return c;
 }
 
-// strict, two positions at once (k_sync_words: the same lane of two candidate groups): at2(j) returns
-// (Fa[i + j], Fb[i' + j]); one packed addition per template sample, each half rounded on its own — the two
-// chains are exactly the ones sync_corr_strict evaluates
-typedef float sync_f2 __attribute__((ext_vector_type(2)));
-template <typename At2>
-__device__ __forceinline__ sync_f2 sync_corr_strict2(uint32_t pw, At2 &&at2)
-{
-#pragma clang fp contract(off)
-    const uint32_t pulse = 2 * pw;
-    sync_f2 c = {0.f, 0.f};
-    uint32_t j = 0;
-#pragma unroll
-    for (uint32_t e = 0; e < pulse; ++e, ++j) c = c - at2(j);
-#pragma unroll
-    for (int rep = 0; rep < 7; ++rep) {
-#pragma unroll
-        for (uint32_t e = 0; e < pulse; ++e, ++j) c = c - at2(j);
-#pragma unroll
-        for (uint32_t e = 0; e < pulse; ++e, ++j) c = c + at2(j);
-    }
-#pragma unroll
-    for (uint32_t e = 0; e < 8 * pw; ++e, ++j) c = c - at2(j);
-    return c;
-}
-
 // fast, step 1: pulse sum B[i]; at(j) returns F[i + j], j < 2*pw
 template <typename At>
 __device__ __forceinline__ float sync_pulse_sum(uint32_t pw, At &&at)
