@@ -38,7 +38,7 @@ struct ImageResult {
 // starts from the peak (0, 0.), decode.rs:208).  lo == hi where the front end evaluated the very
 // arithmetic the picker re-evaluates (fast mode, the unfused kernels, k_fused_any); the strict
 // specialised front ends bound the reference's 114-term chain from pulse sums (apt_kernels_fused_impl.hpp,
-// stage 4).  k_sync_nodes prunes a group only when a later group's lo exceeds its hi, and settles every
+// stage 4).  k_sync_words prunes a group only when a later group's lo exceeds its hi, and settles every
 // comparison the bounds leave open with the exact chain: the intervals only decide how much is
 // re-evaluated, never the result.
 // [-inf, +inf] marks a group that must reach the exact test whatever its neighbours hold: one with a NaN
@@ -51,7 +51,7 @@ struct GroupMax {
 
 // ---- one decode_device call = one launch per stage over all its recordings -----------
 // Per-recording arguments travel BY VALUE in the kernel-argument segment (no H2D copy, no pinned
-// staging, nothing for the host to wait on); blockIdx.y (front end, k_sync_nodes, k_gather_rows) or
+// staging, nothing for the host to wait on); blockIdx.y (front end, k_sync_words, k_sync_slots, k_gather_rows) or
 // blockIdx.x (k_sync_orbit) picks the recording.  The workspace of a recording is a slot of the
 // plan; the slots' pointers sit in a device table written once at plan creation.
 constexpr int kMaxCall = 32;  // recordings per launch; longer calls are split
@@ -194,7 +194,7 @@ bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uin
 // ---- parallel peak picker (apt_kernels_sync.hip) ------------------------------------
 // Each launch covers the recordings of one call (CallArgs by value, slot table in HBM).
 uint32_t sync_group_size();    // correlation positions per group (52)
-uint32_t sync_chunk_groups();  // groups per k_sync_nodes workgroup
+uint32_t sync_chunk_groups();  // groups per k_sync_words / k_sync_slots workgroup
 uint32_t sync_slot_cap();      // node terminals kept per chunk
 // corr -> per-group maxima (unfused path; the fused front ends write them themselves)
 void group_max(hipStream_t s, const float *corr, uint64_t n_corr, GroupMax *gm);

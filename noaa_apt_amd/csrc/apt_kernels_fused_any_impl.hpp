@@ -370,7 +370,7 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
     }
     __syncthreads();
 
-    // ---- stage 5b: group maxima (the correlation itself stays on the CU: k_sync_nodes re-evaluates
+    // ---- stage 5b: group maxima (the correlation itself stays on the CU: k_sync_words evaluates
     // it for the candidate groups).  NaNs are left out of the maximum and reported as [-inf, +inf] bounds.
     for (uint32_t g = tid; g < G.own / kGS; g += NTHR) {
         const uint64_t k = static_cast<uint64_t>(o0) + static_cast<uint64_t>(g) * kGS;

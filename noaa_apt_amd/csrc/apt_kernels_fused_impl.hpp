@@ -946,7 +946,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     }
     if constexpr (APT_FUSED_STOP == 5) return;
     // ---- stage 4: sync cross-correlation (decode.rs:225-233) -> per-group bounds of its maximum.
-    // The correlation itself never leaves the CU: k_sync_nodes re-evaluates it (apt_sync_corr.hpp) for
+    // The correlation itself never leaves the CU: k_sync_words evaluates it (apt_sync_corr.hpp) for
     // the few candidate groups the picker has to look at, so all the front end owes the picker is, per
     // group of GS positions, an interval [lo, hi] that holds the group's maximum.  Every mode gets it from
     // pulse sums (22 operations per position instead of the 114 of the reference's chain):
@@ -957,7 +957,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     //           (an F passes through at most 3 + 18 rounded additions), so |a - c| <= slack * A with
     //           slack = 138 u at PW = 3 (fused_gm_slack: 134 u plus 3 % for the bound's own roundings) and
     //           A = sum of |F| over the group's whole window.  No underflow term: floating-point
-    //           additions of subnormals are exact.  lo = max - slack*A, hi = max + slack*A; k_sync_nodes
+    //           additions of subnormals are exact.  lo = max - slack*A, hi = max + slack*A; k_sync_words
     //           prunes with lo against hi and settles what the bounds cannot with the exact chain.
     //   a group whose window holds a non-finite F (NaN, +-Inf, or an overflowing sum) — where the two
     //   evaluations may disagree about WHERE the NaNs are — gets [-inf, +inf]: always evaluated, never

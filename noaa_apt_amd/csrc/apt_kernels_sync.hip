@@ -30,20 +30,22 @@
 //
 // Kernels (GS = 52 correlation positions per group; md = 32*pw groups, spr = 40*pw groups):
 //   k_group_max   corr -> GM (unfused path only; the fused front end emits GM itself)
-//   k_sync_nodes  coarse: GM[g] = [lo, hi] bounds the maximum of group g (lo = hi where the front
+//   k_sync_words  coarse: GM[g] = [lo, hi] bounds the maximum of group g (lo = hi where the front
 //                 end evaluated the exact arithmetic; [-inf, +inf] = holds a NaN / not finite).  A
 //                 group can hold a terminal only if its hi is not exceeded by the lo of one of the
 //                 next md/GS-1 groups; fine: exact test on the few candidates, whose correlation
-//                 values are RE-EVALUATED from F (apt_sync_corr.hpp: the reference's chain, or the
+//                 values are EVALUATED from F (apt_sync_corr.hpp: the reference's chain, or the
 //                 fast mode's pulse sums) — the fused front ends never write the correlation to
 //                 HBM.  Where the bounds of the groups in between leave a candidate position's
 //                 comparison open (lo <= corr < hi: bounds from the strict front ends' pulse sums,
-//                 a few 1e-6 wide, or NaN groups), those groups are evaluated exactly too: the
-//                 result never depends on the bounds.  Emits terminal words (fallback input) and
-//                 ordered node-terminal lists
+//                 ~1e-3 of a typical correlation value wide, or NaN groups), those groups are
+//                 evaluated exactly too: the result never depends on the bounds.  Emits the
+//                 terminal words and NaN words of its 128 groups
+//   k_sync_slots  terminal / NaN words -> ordered node-terminal list per chunk of 128 groups
 //   k_sync_orbit  one workgroup per recording: builds the functional graph over start nodes,
 //                 extracts the orbit of the root (directly when the recording is confluent,
-//                 else by pointer doubling), writes the peak list and the result record;
+//                 else by pointer doubling, in LDS when the visited nodes fit), writes the peak list
+//                 and the result record;
 //                 falls back to a sequential walk over the terminal words when a per-chunk
 //                 list overflowed (pathological inputs).
 // All three take the recordings of one decode_device call in one launch (CallArgs by value,
@@ -596,7 +598,7 @@ __device__ __forceinline__ void gst(uint32_t *p, uint32_t v)
 }
 // One workgroup per recording (blockIdx.x); every table in the global scratch `ws` (sized by
 // sync_orbit_ws_words()), so the kernel needs almost no LDS and can run beside the next call's
-// front end.  Node terminals are looked up straight in the per-chunk slots k_sync_nodes wrote
+// front end.  Node terminals are looked up straight in the per-chunk slots k_sync_slots wrote
 // (no gather pass): chunk = position / (128*52), then the first entry >= s of that slot or of the
 // next non-empty one.  Node ids: 0 root, 1..n_grid grid cells 2..kc, base_d + slot entry, END.
 __global__ void __launch_bounds__(kOrbitThreads, 8)
@@ -773,7 +775,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
             flags[1] = 1u;  // report which path ran
             flags[0] = 0u;  // re-arm the overflow flag for the next decode
             flags[5] = 0u;
-            flags[11] = flags[7];  // candidates k_sync_nodes settled with exact window maxima; re-armed
+            flags[11] = flags[7];  // candidates k_sync_words settled with exact window maxima; re-armed
             flags[7] = 0u;
         }
         return;
@@ -898,7 +900,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         flags[3] = n_nodes;
         flags[4] = count;
         flags[6] = direct ? 1u : (in_lds ? 2u : 0u);  // orbit: 1 read off directly, 2 doubling in LDS, 0 doubling through L2
-        flags[11] = flags[7];  // candidates k_sync_nodes settled with exact window maxima; re-armed
+        flags[11] = flags[7];  // candidates k_sync_words settled with exact window maxima; re-armed
         flags[7] = 0u;
     }
     stamp(2);  // peaks written

@@ -84,7 +84,7 @@ struct aptgpu_plan {
     int device = 0;
     int mode = APTGPU_MODE_STRICT;
     // Pipeline over consecutive calls: the recordings of ONE decode_device call go through ONE launch
-    // per stage (front end -> k_sync_nodes -> k_sync_orbit -> k_gather_rows; blockIdx.y / .x picks
+    // per stage (front end -> k_sync_words -> k_sync_slots -> k_sync_orbit -> k_gather_rows; blockIdx.y / .x picks
     // the recording, per-recording arguments travel by value in the kernel arguments), in order on
     // one of `depth` streams; consecutive calls go round-robin over the streams, so the front end
     // of call j+1 overlaps the latency-bound picker of call j.  Stream k owns the workspace slots

@@ -1,6 +1,6 @@
 // apt_sync_corr.hpp — the two ways the sync cross-correlation of find_sync() (src/decode.rs:225-233)
 // is evaluated on the device, shared by the fused front ends (which only emit per-group maxima of
-// it) and by k_sync_nodes (which re-evaluates it for the few candidate groups the picker looks at).
+// it) and by k_sync_words (which evaluates it for the few candidate groups the picker looks at).
 // Both sides must produce the SAME bits for the same position, so the arithmetic lives here once.
 //
 //   strict : corr = 0; for j in 0..38*pw: corr +-= F[i+j]   — the reference's sequential chain,
