@@ -30,6 +30,9 @@ CASES = [
     ("apt48k_fast", "apt", dict(rate_hz=48000, seconds=12, seed=5), 48000, "FAST", True),
     ("apt48k_slow", "apt", dict(rate_hz=48000, seconds=12, seed=6), 48000, "SLOW", True),
     ("noise11025_std", "noise", dict(rate_hz=11025, seconds=30.0, seed=77), 11025, "STANDARD", True),
+    # the rates served by k_fused's phase-resident stage 1 (256- and 512-thread workgroups)
+    ("apt44100_std", "apt", dict(rate_hz=44100, seconds=13, seed=8), 44100, "STANDARD", True),
+    ("apt22050_std", "apt", dict(rate_hz=22050, seconds=14, seed=9), 22050, "STANDARD", True),
 ]
 
 
