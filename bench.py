@@ -416,6 +416,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                # what the HBM system actually moved during the launch (the PMC bytes over the same per-launch time)
+                "traffic_GBps": round(traffic / (alone_ms * 1e-3) / 1e9, 2) if (traffic and alone_ms > 0) else None,
+                "traffic_frac_of_peak": round(traffic / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if (traffic and alone_ms > 0) else None,
                 "algorithmic_bytes_per_launch": b_alg,
                 # in the timed region several calls are in flight and their front-end launches share the
                 # GPU: a launch then lasts `avg_concurrent_launches` x the time the GPU spends on it
