@@ -42,37 +42,48 @@ bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t 
 
 uint32_t fused_group_size(uint32_t l) { return 4 * l; }
 
-// floats in the stage-1 tap tables: [WIN][NP] pairs, then [WIN] taps of the odd branch L-1
+// floats in the stage-1 tap table: chunk-major, one run of chw = 4*(l/2) + 2 dwords
+// per chunk of two window samples, plus one chunk of zeros
 uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1)
 {
     const uint32_t tp = (t1 + l - 1) / l;
     const uint32_t clast = ((l - 1) * m + l - 1) / l;
     const uint32_t win = clast + tp;
-    return win * (l / 2) * 2 + win + 2;
+    const uint32_t chw = 4 * (l / 2) + 2;
+    return ((win + 1) / 2 + 1) * chw;
 }
 
-// host: hs[q][pp] = (tap of branch 2pp at window sample q, tap of branch 2pp+1), 0 where a branch
-// does not use q; after the pairs, hl[q] = tap of the odd branch L-1 at q
+// host: chunk c holds, for its window samples q = 2c + e (e = 0, 1), the pairs (tap of branch 2pp at q, tap of
+// branch 2pp+1 at q) at dwords e*2*np + 2*pp, then (tap of the odd branch l-1 at 2c, at 2c+1) at dwords 4*np;
+// 0 where a branch does not use q or q lies past the window
 void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, float *hs)
 {
     const uint32_t tp = (t1 + l - 1) / l;
     const uint32_t clast = ((l - 1) * m + l - 1) / l;
     const uint32_t win = clast + tp;
     const uint32_t np = l / 2;
+    const uint32_t chw = 4 * np + 2;
     auto tap = [&](uint32_t b, uint32_t q) -> float {
         const uint32_t cb = (b * m + l - 1) / l;
         const uint32_t pb = cb * l - b * m;
-        if (q < cb) return 0.f;
+        if (q < cb || q >= win) return 0.f;
         const uint64_t j = pb + static_cast<uint64_t>(q - cb) * l;
         return j < t1 ? coeff[j] : 0.f;
     };
-    float *hl = hs + static_cast<size_t>(win) * np * 2;
-    for (uint32_t q = 0; q < win; ++q) {
-        for (uint32_t pp = 0; pp < np; ++pp) {
-            hs[(q * np + pp) * 2] = tap(2 * pp, q);
-            hs[(q * np + pp) * 2 + 1] = tap(2 * pp + 1, q);
+    const uint32_t nch = (win + 1) / 2;
+    for (uint32_t c = 0; c <= nch; ++c) {
+        float *row = hs + static_cast<size_t>(c) * chw;
+        for (uint32_t i = 0; i < chw; ++i) row[i] = 0.f;
+        if (c == nch) break;
+        for (uint32_t e = 0; e < 2; ++e)
+            for (uint32_t pp = 0; pp < np; ++pp) {
+                row[e * 2 * np + 2 * pp] = tap(2 * pp, 2 * c + e);
+                row[e * 2 * np + 2 * pp + 1] = tap(2 * pp + 1, 2 * c + e);
+            }
+        if (l & 1) {
+            row[4 * np] = tap(l - 1, 2 * c);
+            row[4 * np + 1] = tap(l - 1, 2 * c + 1);
         }
-        hl[q] = (l & 1) ? tap(l - 1, q) : 0.f;
     }
 }
 
@@ -167,10 +178,10 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
                 const char *e = std::getenv("APTGPU_PROBE_STOP");
                 return e ? std::atoi(e) : 0;
             }();
-            if (!pcm16 && probe >= 1 && probe <= 9) {
-                void (*const fn[9])(const FusedLaunch &) = {fused_launch_probe1, fused_launch_probe2, fused_launch_probe3,
+            if (!pcm16 && probe >= 1 && probe <= 7) {
+                void (*const fn[7])(const FusedLaunch &) = {fused_launch_probe1, fused_launch_probe2, fused_launch_probe3,
                                                             fused_launch_probe4, fused_launch_probe5, fused_launch_probe6,
-                                                            fused_launch_probe7, fused_launch_probe8, fused_launch_probe9};
+                                                            fused_launch_probe7};
                 fn[probe - 1](a);
             } else
 #endif

@@ -83,8 +83,9 @@ struct FusedGeom {
     static constexpr int LDS_FLOATS = XT_LDS > W_LDS_FLOATS ? XT_LDS : W_LDS_FLOATS;
     static constexpr int GS = 4 * L;                                  // correlation group size
     static constexpr int NP = L / 2;                                  // accumulator pairs (+1 single if L odd)
-    static constexpr int PS = NP;                                     // f2 tap entries per window sample
-    static constexpr int HL_OFF = 2 * ((CLAST + (T1 + L - 1) / L) * NP);  // float offset of the odd branch's taps
+    // stage-1 tap table, chunk-major (fused_branch_taps): per chunk of two window samples, 2 x NP branch pairs,
+    // then (tap of the odd branch L-1 at sample 0, at sample 1)
+    static constexpr int CHW = 2 * 2 * NP + 2;
     static constexpr int DW = L + T2 - 1;                             // envelope window per thread
     static_assert(PRE_K >= T2 + 1, "pre-halo too small for the low-pass");
     static_assert((kFusedThreads - kPreThreads - kOwnThreads) * L >= G - 1, "post-halo too small");
@@ -601,17 +602,19 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         for (int b = 0; b < L; ++b) r[b] = (kq + b < k_lo || kq + b >= k_hi) ? 0.f : acc[b] * f16_unscale;
     } else
     {
-        // Software pipeline over chunks of CH window samples: SMEM returns out of order, so the
-        // only usable wait is lgkmcnt(0).  Each chunk therefore (1) consumes its first tap —
-        // which makes the compiler wait for exactly the loads issued one chunk ago — (2) issues
-        // the loads of the NEXT chunk, (3) computes the rest under their latency.
+        // Software pipeline over chunks of CH = 2 window samples.  The taps of a chunk are ONE contiguous run of
+        // the chunk-major table (fused_branch_taps: 2 x NP branch pairs, then the pair of the odd branch's taps
+        // of the two samples) fetched by three scalar loads written out as inline assembly — as C++ loads the
+        // compiler merged them across chunks, waited for them on the spot and spilled what it had fetched early
+        // (454 SGPR spills in one layout, 41 in another).  SMEM returns out of order, so the only usable wait is
+        // lgkmcnt(0): chunk c waits for the loads issued one chunk ago (the wait names the tap registers as
+        // in/out operands, which is what orders their uses behind it — the compiler's own counter does not
+        // see assembly loads), issues the loads of chunk c + 1, and computes under their latency.
         // kModeFast runs the same pipeline with one v_pk_fma_f32 per tap pair instead of a
         // v_pk_mul_f32 + v_pk_add_f32 (half the VALU instructions under the same tap loads).
-#ifndef APT_FUSED_CH_FAST
-#define APT_FUSED_CH_FAST 2
-#endif
-        constexpr int CH = FAST ? APT_FUSED_CH_FAST : 2;
+        constexpr int CH = 2;
         constexpr int NCH = (Gm::WIN + CH - 1) / CH;
+        static_assert(Gm::CHW == 26, "three scalar loads per chunk: 16 + 8 + 2 dwords");
         auto xsrc = [&](int q) -> float {
             if constexpr (sizeof(XT) == 2) return static_cast<float>(reinterpret_cast<const int16_t *>(lds)[tid * M + q]);
             else return P[tid * M + q];
@@ -620,46 +623,115 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         float accl = 0.f;
 #pragma unroll
         for (int pp = 0; pp < Gm::NP; ++pp) acc[pp] = (f2){0.f, 0.f};
-        f2 tb[2][CH * Gm::PS];   // tap pairs of the chunk in use / in flight (SGPRs)
-        float tl[2][CH];         // taps of the odd branch L-1 (contiguous per sample: aligned pairs)
-        float xb[2][CH];         // window samples of the chunk in use / in flight
-        const cfloat_ptr hl = (cfloat_ptr)(hs) + Gm::HL_OFF;
+        typedef uint32_t u16s __attribute__((ext_vector_type(16)));
+        typedef uint32_t u8s __attribute__((ext_vector_type(8)));
+        typedef uint32_t u2s __attribute__((ext_vector_type(2)));
+        u16s ta[2];  // dwords 0..15 of the chunk in use / in flight (SGPRs)
+        u8s tb[2];   // 16..23
+        u2s tc[2];   // 24, 25: (odd branch's tap at sample 0, at sample 1)
+        // Window samples, RW per LDS read.  Lane t reads word t*M + q: as 4-byte reads a stride of 50 words
+        // reaches 16 of the 32 banks (2-way conflict, 4.1 LDS cycles per instruction measured; 100 words: 8 banks,
+        // 8.5 cycles), and the compiler's ds_read2_b32 is two such reads.  An 8-byte read is banked over 64 words:
+        // M = 50 is conflict-free as ds_read_b64 (2.3 cycles per TWO samples), M = 100 as ds_read_b128 (4.9 cycles
+        // per FOUR) — tools/ubench/rates.hip.  (PCM16 tiles: stride M/2 words, element-wise reads.)
+        constexpr int RW = (sizeof(XT) == 4) ? ((M % 4 == 0) ? 4 : ((M % 2 == 0) ? 2 : 1)) : 1;
+        constexpr int XG = RW > CH ? RW : CH;
+        typedef float f4w __attribute__((ext_vector_type(4)));
+        using XV = std::conditional_t<RW == 4, f4w, f2>;
+        XV xw[2];                // window samples of the read group in use / in flight (one register tuple)
         auto issue = [&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int buf = c & 1;
+            // (asm operands do not capture: name the registers through references first.  The tap registers are
+            // pinned — s[36:87], the two buffers side by side: left to itself the allocator put both buffers of
+            // the last piece into one register pair and spilled it to VGPR lanes in every chunk)
+            u16s &ra = ta[buf];
+            u8s &rb = tb[buf];
+            u2s &rc = tc[buf];
+            const cf2_ptr hsp = hs;
+#define APT_TAP_LOADS "s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx8 %1, %3, %5\n\ts_load_dwordx2 %2, %3, %6"
+            if constexpr (buf == 0)
+                asm volatile(APT_TAP_LOADS
+                             : "={s[36:51]}"(ra), "={s[68:75]}"(rb), "={s[84:85]}"(rc)
+                             : "s"(hsp), "n"(c * Gm::CHW * 4), "n"(c * Gm::CHW * 4 + 64), "n"(c * Gm::CHW * 4 + 96));
+            else
+                asm volatile(APT_TAP_LOADS
+                             : "={s[52:67]}"(ra), "={s[76:83]}"(rb), "={s[86:87]}"(rc)
+                             : "s"(hsp), "n"(c * Gm::CHW * 4), "n"(c * Gm::CHW * 4 + 64), "n"(c * Gm::CHW * 4 + 96));
+#undef APT_TAP_LOADS
+            if constexpr (RW >= CH) {
+                if constexpr ((c * CH) % RW == 0) {  // (the last group may reach past the window: inside the tile's pad)
+                    constexpr int g = (c * CH) / RW;
+                    const float *src = P + tid * M + c * CH;
+                    xw[g & 1] = *reinterpret_cast<const XV *>(src);
+                }
+            } else {
 #pragma unroll
-            for (int e = 0; e < CH; ++e) {
-                const int q = c * CH + e;
-                xb[buf][e] = (q < Gm::WIN) ? xsrc(q) : 0.f;
-                if constexpr (L & 1) tl[buf][e] = (q < Gm::WIN) ? hl[q] : 0.f;
-#pragma unroll
-                for (int k = 0; k < Gm::PS; ++k)
-                    tb[buf][e * Gm::PS + k] = (q < Gm::WIN) ? hs[q * Gm::PS + k] : (f2){0.f, 0.f};
+                for (int e = 0; e < CH; ++e) xw[buf][e] = (c * CH + e < Gm::WIN) ? xsrc(c * CH + e) : 0.f;
+                static_assert(CH == 2, "element-wise window reads fill an f2");
             }
+        };
+        // (the window samples read with the taps are operands too: the compiler then places ITS wait for that LDS
+        // read here, in front of the next chunk's loads — behind them its count-based wait, which does not know
+        // of the assembly loads, would wait for those as well)
+        auto wait_taps = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int buf = c & 1;
+            u16s &ra = ta[buf];
+            u8s &rb = tb[buf];
+            u2s &rc = tc[buf];
+#define APT_TAP_REGS0 "+{s[36:51]}"(ra), "+{s[68:75]}"(rb), "+{s[84:85]}"(rc)
+#define APT_TAP_REGS1 "+{s[52:67]}"(ra), "+{s[76:83]}"(rb), "+{s[86:87]}"(rc)
+            if constexpr (RW >= CH && (c * CH) % RW != 0) {
+                if constexpr (buf == 0) asm volatile("s_waitcnt lgkmcnt(0)" : APT_TAP_REGS0);
+                else asm volatile("s_waitcnt lgkmcnt(0)" : APT_TAP_REGS1);
+            } else {
+                constexpr int g = RW >= CH ? ((c * CH) / RW) & 1 : buf;
+                XV &xv = xw[g];
+                if constexpr (buf == 0) asm volatile("s_waitcnt lgkmcnt(0)" : APT_TAP_REGS0, "+v"(xv));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : APT_TAP_REGS1, "+v"(xv));
+            }
+#undef APT_TAP_REGS0
+#undef APT_TAP_REGS1
+        };
+        auto xat = [&](auto cc, auto ee) -> float {
+            constexpr int c = decltype(cc)::value, e = decltype(ee)::value;
+            if constexpr (RW >= CH) return xw[((c * CH) / RW) & 1][(c * CH) % RW + e];
+            else return xw[c & 1][e];
+        };
+        // dword i of the chunk's taps
+        auto tapd = [&](auto cc, auto ii) -> float {
+            constexpr int buf = decltype(cc)::value & 1, i = decltype(ii)::value;
+            if constexpr (i < 16) return __uint_as_float(ta[buf][i]);
+            else if constexpr (i < 24) return __uint_as_float(tb[buf][i - 16]);
+            else return __uint_as_float(tc[buf][i - 24]);
+        };
+        auto tap_pair = [&](auto cc, auto ee, auto kk) -> f2 {  // (taps of branches 2k, 2k+1 at sample e)
+            constexpr int i = decltype(ee)::value * 2 * Gm::NP + 2 * decltype(kk)::value;
+            return (f2){tapd(cc, std::integral_constant<int, i>{}), tapd(cc, std::integral_constant<int, i + 1>{})};
+        };
+        auto tap_odd = [&](auto cc) -> f2 {  // (taps of the odd branch L-1 at the chunk's two samples)
+            constexpr int i = CH * 2 * Gm::NP;
+            return (f2){tapd(cc, std::integral_constant<int, i>{}), tapd(cc, std::integral_constant<int, i + 1>{})};
         };
         // product of window sample (c, e) with tap pair k — kept apart from the accumulation so
         // that a sample's products are all issued before the first dependent add (a v_pk_add
         // right behind the v_pk_mul it reads costs a wait state)
         auto prod = [&](auto cc, auto ee, auto kk) -> f2 {
             constexpr int c = decltype(cc)::value, e = decltype(ee)::value, k = decltype(kk)::value;
-            constexpr int buf = c & 1;
             constexpr int q = c * CH + e;
             f2 p = (f2){0.f, 0.f};
             if constexpr (q < Gm::WIN) {
-                const float xq = xb[buf][e];
-                if constexpr (k < Gm::NP) {
-                    const f2 t = tb[buf][e * Gm::PS + k];
-                    constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
-                    constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
-                    if constexpr (va && vb) {
-                        p = t * (f2){xq, xq};
-                    } else if constexpr (va) {
-                        p.x = t.x * xq;
-                    } else if constexpr (vb) {
-                        p.y = t.y * xq;
-                    }
-                } else if constexpr (branch_uses<L, M, T1>(L - 1, q)) {
-                    p.x = tl[buf][e] * xq;
+                const float xq = xat(cc, ee);
+                const f2 t = tap_pair(cc, ee, kk);
+                constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
+                constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
+                if constexpr (va && vb) {
+                    p = t * (f2){xq, xq};
+                } else if constexpr (va) {
+                    p.x = t.x * xq;
+                } else if constexpr (vb) {
+                    p.y = t.y * xq;
                 }
             }
             return p;
@@ -667,23 +739,18 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         // kModeFast: acc += tap * x in one fused operation
         auto mac = [&](auto cc, auto ee, auto kk) {
             constexpr int c = decltype(cc)::value, e = decltype(ee)::value, k = decltype(kk)::value;
-            constexpr int buf = c & 1;
             constexpr int q = c * CH + e;
             if constexpr (q < Gm::WIN) {
-                const float xq = xb[buf][e];
-                if constexpr (k < Gm::NP) {
-                    const f2 t = tb[buf][e * Gm::PS + k];
-                    constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
-                    constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
-                    if constexpr (va && vb) {
-                        acc[k] = __builtin_elementwise_fma(t, (f2){xq, xq}, acc[k]);
-                    } else if constexpr (va) {
-                        acc[k].x = __builtin_fmaf(t.x, xq, acc[k].x);
-                    } else if constexpr (vb) {
-                        acc[k].y = __builtin_fmaf(t.y, xq, acc[k].y);
-                    }
-                } else if constexpr (branch_uses<L, M, T1>(L - 1, q)) {
-                    accl = __builtin_fmaf(tl[buf][e], xq, accl);
+                const float xq = xat(cc, ee);
+                const f2 t = tap_pair(cc, ee, kk);
+                constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
+                constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
+                if constexpr (va && vb) {
+                    acc[k] = __builtin_elementwise_fma(t, (f2){xq, xq}, acc[k]);
+                } else if constexpr (va) {
+                    acc[k].x = __builtin_fmaf(t.x, xq, acc[k].x);
+                } else if constexpr (vb) {
+                    acc[k].y = __builtin_fmaf(t.y, xq, acc[k].y);
                 }
             }
         };
@@ -691,62 +758,73 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             constexpr int c = decltype(cc)::value, e = decltype(ee)::value, k = decltype(kk)::value;
             constexpr int q = c * CH + e;
             if constexpr (q < Gm::WIN) {
-                if constexpr (k < Gm::NP) {
-                    constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
-                    constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
-                    if constexpr (va && vb) {
-                        acc[k] = acc[k] + p;
-                    } else if constexpr (va) {
-                        acc[k].x = acc[k].x + p.x;
-                    } else if constexpr (vb) {
-                        acc[k].y = acc[k].y + p.y;
+                constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
+                constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
+                if constexpr (va && vb) {
+                    acc[k] = acc[k] + p;
+                } else if constexpr (va) {
+                    acc[k].x = acc[k].x + p.x;
+                } else if constexpr (vb) {
+                    acc[k].y = acc[k].y + p.y;
+                }
+            }
+        };
+        // the odd branch L-1: the products of its two taps of the chunk in ONE packed multiply (taps and samples
+        // both lie in aligned pairs), its additions one after the other in tap order
+        auto odd_branch = [&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            if constexpr (L & 1) {
+                constexpr int q0 = c * CH;
+                constexpr bool u0 = q0 < Gm::WIN && branch_uses<L, M, T1>(L - 1, q0);
+                constexpr bool u1 = q0 + 1 < Gm::WIN && branch_uses<L, M, T1>(L - 1, q0 + 1);
+                using I0 = std::integral_constant<int, 0>;
+                using I1 = std::integral_constant<int, 1>;
+                if constexpr (u0 || u1) {
+                    const f2 t = tap_odd(cc);
+                    const float x0 = xat(cc, I0{}), x1 = xat(cc, I1{});
+                    if constexpr (FAST) {
+                        if constexpr (u0) accl = __builtin_fmaf(t.x, x0, accl);
+                        if constexpr (u1) accl = __builtin_fmaf(t.y, x1, accl);
+                    } else if constexpr (u0 && u1) {
+                        const f2 po = t * (f2){x0, x1};
+                        accl = accl + po.x;
+                        accl = accl + po.y;
+                    } else if constexpr (u0) {
+                        accl = accl + t.x * x0;
+                    } else {
+                        accl = accl + t.y * x1;
                     }
-                } else if constexpr (branch_uses<L, M, T1>(L - 1, q)) {
-                    accl = accl + p.x;
                 }
             }
         };
         issue(std::integral_constant<int, 0>{});
         static_for<0, NCH>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
-            constexpr int NK = Gm::PS + (L & 1);
-            using I0 = std::integral_constant<int, 0>;
-            using I1 = std::integral_constant<int, 1>;
-            if constexpr (FAST) {
-                // the first two multiply-adds force the wait for the loads issued one chunk ago
-                mac(cc, I0{}, I0{});
-                mac(cc, I0{}, I1{});
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (c + 1 < NCH) issue(std::integral_constant<int, c + 1>{});
-                __builtin_amdgcn_sched_barrier(0);
-                static_for<0, CH>([&](auto ee) {
-                    constexpr int e = decltype(ee)::value;
-                    static_for<0, NK>([&](auto kk) {
-                        constexpr int k = decltype(kk)::value;
-                        if constexpr (!(e == 0 && k < 2)) mac(cc, ee, kk);
-                    });
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-            // the first two products force the wait for the loads issued one chunk ago
-            const f2 p00 = prod(cc, I0{}, I0{});
-            const f2 p01 = prod(cc, I0{}, I1{});
+            wait_taps(cc);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (c + 1 < NCH) issue(std::integral_constant<int, c + 1>{});
             __builtin_amdgcn_sched_barrier(0);
-            static_for<0, CH>([&](auto ee) {
-                constexpr int e = decltype(ee)::value;
-                f2 pr[NK];
-                static_for<0, NK>([&](auto kk) {
-                    constexpr int k = decltype(kk)::value;
-                    if constexpr (e == 0 && k == 0) pr[k] = p00;
-                    else if constexpr (e == 0 && k == 1) pr[k] = p01;
-                    else pr[k] = prod(cc, ee, kk);
+            if constexpr (FAST) {
+                static_for<0, CH>([&](auto ee) {
+                    static_for<0, Gm::NP>([&](auto kk) { mac(cc, ee, kk); });
                 });
-                static_for<0, NK>([&](auto kk) { accum(cc, ee, kk, pr[decltype(kk)::value]); });
-            });
-            __builtin_amdgcn_sched_barrier(0);
+                odd_branch(cc);
+            } else {
+                static_for<0, CH>([&](auto ee) {
+                    f2 pr[Gm::NP > 0 ? Gm::NP : 1];
+                    static_for<0, Gm::NP>([&](auto kk) { pr[decltype(kk)::value] = prod(cc, ee, kk); });
+                    static_for<0, Gm::NP>([&](auto kk) { accum(cc, ee, kk, pr[decltype(kk)::value]); });
+                });
+                odd_branch(cc);
             }
+            // (pins the accumulators here: their only consumer is a block further down, and the compiler would sink
+            // the ends of the chains — and keep those chunks' taps alive in spilled registers — to it)
+            static_for<0, Gm::NP>([&](auto kk) {
+                f2 &a = acc[decltype(kk)::value];
+                asm volatile("" : "+v"(a));
+            });
+            asm volatile("" : "+v"(accl));
+            __builtin_amdgcn_sched_barrier(0);
         });
 #pragma unroll
         for (int pp = 0; pp < Gm::NP; ++pp) {
@@ -797,16 +875,36 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             prev_sq = curr_sq;
         }
     } else {
+        // (the constants in vector registers: an instruction with a scalar operand issues at half the rate of one
+        // without, tools/ubench/rates3.hip)
+        float cosv = cosphi2, sinv = sinphi, invv = inv_sinphi;
+        asm volatile("" : "+v"(cosv), "+v"(sinv), "+v"(invv));
         float prev = (tid > 0) ? P[tid * L - 1] : 0.f;
         float xr[L];
-        bool in_range = inv_sinphi != 0.f;  // 0: the fast divide did not verify for this sin(phi)
+        bool in_range = inv_sinphi != 0.f;  // 0: the fast root / divide did not verify on this device / for this sin(phi)
+        if constexpr (INT) {
+            // every value of the thread inside [2^-96, 2^100]: as bit patterns, minimum and maximum (a NaN or a
+            // negative radicand has a pattern above the range's end)
+            uint32_t umin = 0xFFFFFFFFu, umax = 0u;
 #pragma unroll
-        for (int b = 0; b < L; ++b) {
-            const float curr = r[b];
-            xr[b] = envelope_radicand(prev, curr, cosphi2);
-            // (outputs outside the recording are zeroed below whatever their radicand is)
-            in_range = in_range && (envelope_in_range(xr[b]) || (!INT && (kq + b <= k_lo || kq + b >= k_hi)));
-            prev = curr;
+            for (int b = 0; b < L; ++b) {
+                const float curr = r[b];
+                xr[b] = envelope_radicand(prev, curr, cosv);
+                const uint32_t u = __float_as_uint(xr[b]);
+                umin = u < umin ? u : umin;
+                umax = u > umax ? u : umax;
+                prev = curr;
+            }
+            in_range = in_range && umin >= 0x0F800000u && umax <= 0x71800000u;
+        } else {
+#pragma unroll
+            for (int b = 0; b < L; ++b) {
+                const float curr = r[b];
+                xr[b] = envelope_radicand(prev, curr, cosv);
+                // (outputs outside the recording are zeroed below whatever their radicand is)
+                in_range = in_range && (envelope_in_range(xr[b]) || kq + b <= k_lo || kq + b >= k_hi);
+                prev = curr;
+            }
         }
         // wave-uniform choice: the exactly rounded fast path (apt_envelope.hpp) when every value
         // of the wave is in its range, the compiler's general sequences otherwise
@@ -814,7 +912,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 #pragma unroll
             for (int b = 0; b < L; ++b) {
                 // (positions at or past the end of the recording hold garbage: never read)
-                Q[tid * L + b] = (INT || kq + b > k_lo) ? envelope_fast(xr[b], sinphi, inv_sinphi) : 0.f;
+                Q[tid * L + b] = (INT || kq + b > k_lo) ? envelope_fast(xr[b], sinv, invv) : 0.f;
             }
         } else {
 #pragma unroll
@@ -964,8 +1062,8 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     //   pruning anything.
     if (want_gm) {
         GroupMax *__restrict__ gm_out = slots[slot_late].gm;
-        float c[L];
         constexpr int PUL = 2 * PW;
+        static_assert(L == 13 && PUL == 6 && Gm::GS == 52, "the position remapping below is written for 13-sample threads and 6-sample pulses");
         float *AB = lds + Gm::D_OFF + Gm::TILE_K + 36 * PW;  // [NTHR] per-thread sums of |F|
         {
             // pulse sums of the thread's own L positions -> Q (D is dead)
@@ -996,58 +1094,87 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 AB[tid] = a;
             }
         }
-        __syncthreads();
-        {
-            // 19 signed pulse sums per position
-            constexpr int BW = L + 18 * PUL;  // pulse-sum window per thread
-            constexpr int CH4 = 11;
-            const float *src = Q + tid * L;
-            static_for<0, (BW + CH4 - 1) / CH4>([&](auto cc) {
-                constexpr int q0 = decltype(cc)::value * CH4;
-                float bv[CH4];
+        __syncthreads();  // pulse sums complete; F (region P) is dead from here on
+        // ---- the correlation of the owned positions, REMAPPED: thread t = 6 blk + r takes the 13 positions
+        // p_j = PRE_K + 78 blk + r + 6 j (one pulse apart), whose 19 pulse sums each are V[j + k] with
+        // V[n] = B[p_0 + 6 n], n < 31: 31 LDS reads per thread where 13 CONSECUTIVE positions need a window of 121
+        // (each pulse sum now serves up to 13 positions of the thread instead of 2), all of them 4-byte reads at
+        // compile-time offsets (a thread's window of consecutive positions starts at 13 t words: unaligned for
+        // wider reads, and the ds_read2_b32 pairs the compiler then picks cost one v_add_u32 each for an address
+        // beyond their 8-bit offsets).  And with a thread's values one pulse apart, the template's alternating
+        // part telescopes inside the thread (apt_sync_corr.hpp: E = differences of neighbouring pulse sums,
+        // S2 / S4 = sums of 2 / 4 of them, T2 / T4 the template's tail): 139 additions per thread, not 247.
+        // A block of 78 positions is 1.5 groups of 52: the thread reduces its values to two partial maxima,
+        // for the group its first positions lie in and for the next one, and the block pair's six partial
+        // lists go through LDS (region P) to the thread that writes a group's record.
+        constexpr int NB6 = ((Gm::OWN_K + 6 * L - 1) / (6 * L)) * 6;  // threads with a block (the last may be partial)
+        static_assert(NB6 <= NTHR, "one thread per block column");
+        float *PMX = P;  // [groups][12]: partial maxima by group (6 from each of the two blocks that reach it, or -inf)
+        if (tid < NB6) {
+            const uint32_t blk = static_cast<uint32_t>(tid) / 6u;
+            const int rr = tid - static_cast<int>(blk) * 6;
+            const int p0 = Gm::PRE_K + static_cast<int>(blk) * (6 * L) + rr;  // tile-relative position of j = 0
+            const float *vsrc = Q + p0;
+            float c[L];
+            {
+                float V[L + 18];
 #pragma unroll
-                for (int e = 0; e < CH4; ++e) bv[e] = (q0 + e < BW) ? src[q0 + e] : 0.f;
-                static_for<0, CH4>([&](auto ee) {
-                    constexpr int q = q0 + decltype(ee)::value;
-                    if constexpr (q < BW) {
-                        const float v = bv[decltype(ee)::value];
-                        static_for<0, L>([&](auto bb) {
-                            constexpr int b = decltype(bb)::value;
-                            if constexpr (q >= b && (q - b) % PUL == 0 && (q - b) / PUL < 19) {
-                                constexpr int k = (q - b) / PUL;
-                                if constexpr (k == 0) c[b] = -v;
-                                else c[b] = sync_pulse_plus(k) ? c[b] + v : c[b] - v;
-                            }
-                        });
-                    }
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
+                for (int n = 0; n < L + 18; ++n) V[n] = vsrc[PUL * n];
+                sync_corr_pulse_stride<L>(V, c);
+            }
+            const bool odd = (blk & 1u) != 0u;
+            if (!interior) {
+#pragma unroll
+                for (int j = 0; j < L; ++j) {
+                    const int pq = p0 + PUL * j;
+                    if (pq == k_lo && !(c[j] > 0.f)) c[j] = 0.f;     // the picker starts from the peak (0, 0.)
+                    if (pq < k_lo || pq >= c_hi) c[j] = kNegInfF;    // not a correlation position
+                }
+            }
+            // a NaN position is a terminal of the picker whatever the finite maximum of its group is
+            // (decode.rs:250): fast mode reports it through the bounds here — any NaN among the thread's values
+            // (their sum is one) opens both of its groups; the strict modes see it in the sum of |F| below
+            bool any_nan = false;
+            if constexpr (FAST) {
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < L; ++j) sum = sum + ((c[j] == kNegInfF) ? 0.f : c[j]);
+                any_nan = sum != sum;
+            }
+            // positions of the first group: r + 6 j < 52 in an even block (j <= 7, and j = 8 for r < 4), < 26 in an
+            // odd one (j <= 3, and j = 4 for r < 2)
+            const float m03 = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
+            const float m57 = fmaxf(fmaxf(c[5], c[6]), c[7]);
+            const float m912 = fmaxf(fmaxf(c[9], c[10]), fmaxf(c[11], c[12]));
+            const bool a4 = !odd || rr < 2, a8 = !odd && rr < 4;
+            float mA = fmaxf(fmaxf(m03, a4 ? c[4] : kNegInfF), fmaxf(odd ? kNegInfF : m57, a8 ? c[8] : kNegInfF));
+            float mB = fmaxf(fmaxf(m912, a4 ? kNegInfF : c[4]), fmaxf(odd ? m57 : kNegInfF, a8 ? kNegInfF : c[8]));
+            if (any_nan) {
+                mA = __builtin_huge_valf();
+                mB = __builtin_huge_valf();
+            }
+            // group of the first part: 3 (blk / 2) + (odd ? 1 : 0); slots 0..5 of a group belong to the even
+            // block that reaches it — except that group 3u+1 is reached by the even block's SECOND part (slots
+            // 0..5) and the odd block's FIRST (slots 6..11); what no block fills is -inf
+            const uint32_t u = blk >> 1;
+            float *g0 = PMX + (3u * u + (odd ? 1u : 0u)) * 12u + (odd ? 6u : 0u) + rr;
+            g0[0] = mA;
+            g0[odd ? 6 : 12] = mB;                    // even: group 3u+1, slot r;  odd: group 3u+2, slot r
+            g0[odd ? 12 : 6] = kNegInfF;              // even: group 3u, slot 6+r;  odd: group 3u+2, slot 6+r
         }
-        // the maximum over the group's positions — NaNs left out and reported through the bounds (a NaN
-        // position is a terminal of the picker, decode.rs:250, whatever the finite maximum of its group
-        // is) — and the group's record
+        __syncthreads();
+        // the group's record
         auto group_bounds = [&](auto interior_tag) {
         constexpr bool INT = decltype(interior_tag)::value;  // interior tile: no edge tests
-        float mx = kNegInfF;
-        bool has_nan = false;
-#pragma unroll
-        for (int b = 0; b < L; ++b) {
-            const int pq = kq + b;
-            float v = c[b];
-            if (!INT && pq == k_lo && !(v > 0.f)) v = 0.f;  // the picker starts from the peak (0, 0.)
-            if (INT || (pq >= k_lo && pq < c_hi)) {
-                mx = fmaxf(mx, v);
-                has_nan = has_nan || (v != v);
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-        int hn = has_nan ? 1 : 0;
-        hn |= __shfl_xor(hn, 1, 64);
-        hn |= __shfl_xor(hn, 2, 64);
         if ((tid & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads && (INT || kq < c_hi)) {
+            const int gl = (tid - kPreThreads) / 4;
+            typedef float f4g __attribute__((ext_vector_type(4)));
+            const f4g *pm = reinterpret_cast<const f4g *>(PMX + gl * 12);
+            const f4g q0 = pm[0], q1 = pm[1], q2 = pm[2];
+            const float mx = fmaxf(fmaxf(fmaxf(fmaxf(q0.x, q0.y), fmaxf(q0.z, q0.w)), fmaxf(fmaxf(q1.x, q1.y), fmaxf(q1.z, q1.w))),
+                                   fmaxf(fmaxf(q2.x, q2.y), fmaxf(q2.z, q2.w)));
             float hi = mx, lo = mx;
+            bool open = mx == __builtin_huge_valf();  // fast mode's NaN mark (or a maximum that IS +inf: same record)
             if constexpr (!FAST) {
                 // |F| over the group's window: the threads that hold positions kq .. kq + GS + G - 2
                 constexpr int NT = (Gm::GS + Gm::G - 1 + L - 1) / L;
@@ -1059,15 +1186,15 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 #pragma unroll
                 for (int e = 1; e < NT; ++e) A = A + av[e];
                 const float err = A * late->gm_slack;
-                if (!(err < __builtin_huge_valf())) hn = 1;  // NaN or Inf somewhere in the window
+                if (!(err < __builtin_huge_valf())) open = true;  // NaN or Inf somewhere in the window
                 hi = mx + err;
                 lo = mx - err;
             }
-            if (hn) {
+            if (open) {
                 hi = __builtin_huge_valf();
                 lo = kNegInfF;
             }
-            gm_out[o0 / Gm::GS + (tid - kPreThreads) / 4] = GroupMax{hi, lo};
+            gm_out[o0 / Gm::GS + gl] = GroupMax{hi, lo};
         }
         };
         if (interior) group_bounds(std::true_type{});

@@ -56,8 +56,6 @@ void fused_launch_probe4(const FusedLaunch &a);
 void fused_launch_probe5(const FusedLaunch &a);
 void fused_launch_probe6(const FusedLaunch &a);
 void fused_launch_probe7(const FusedLaunch &a);
-void fused_launch_probe8(const FusedLaunch &a);  // stage-1 chunks of 3 samples
-void fused_launch_probe9(const FusedLaunch &a);  // stage-1 chunks of 4 samples
 #endif
 
 }  // namespace apt::gpu

@@ -521,6 +521,41 @@ __global__ void __launch_bounds__(256) k_verify_fast_divide(float c, float rc, u
     if (__float_as_uint(want) != __float_as_uint(got)) atomicAdd(bad, 1u);
 }
 
+// every float of [2^-96, 2^100], 64 per thread
+__global__ void __launch_bounds__(256) k_verify_fast_sqrt(uint32_t lo, uint32_t count, uint32_t *bad)
+{
+    const uint64_t base = (static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x) * 64u;
+    uint32_t b = 0;
+    for (uint32_t i = 0; i < 64u; ++i) {
+        const uint64_t idx = base + i;
+        if (idx >= count) break;
+        const float x = __uint_as_float(lo + static_cast<uint32_t>(idx));
+        b += __float_as_uint(exact_sqrt_inrange(x)) != __float_as_uint(__builtin_sqrtf(x));
+    }
+    if (b) atomicAdd(bad, b);
+}
+
+// the square-root half of the check: a property of the device, not of the plan
+static bool verify_fast_sqrt(int device, hipStream_t s, uint32_t *d_bad)
+{
+    static std::mutex mu;
+    static std::map<int, bool> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    if (auto it = cache.find(device); it != cache.end()) return it->second;
+    constexpr uint32_t lo = 0x0F800000u, hi = 0x71800000u;  // envelope_in_range()
+    constexpr uint32_t count = hi - lo + 1u, threads = (count + 63u) / 64u;
+    uint32_t bad = 1;
+    bool ok = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), s) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_verify_fast_sqrt, dim3((threads + 255u) / 256u), dim3(256), 0, s, lo, count, d_bad);
+        ok = hipGetLastError() == hipSuccess &&
+             hipMemcpyAsync(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, s) == hipSuccess &&
+             hipStreamSynchronize(s) == hipSuccess;
+    }
+    if (ok) cache[device] = bad == 0;  // a failed check (HIP error) is not cached
+    return ok && bad == 0;
+}
+
 bool verify_fast_divide(int device, float c, float rc)
 {
     if (!(c == c) || !(rc == rc) || c == 0.f || rc == 0.f) return false;
@@ -546,7 +581,7 @@ bool verify_fast_divide(int device, float c, float rc)
         return false;
     }
     uint32_t bad = 1;
-    bool ok = hipMemsetAsync(d_bad, 0, sizeof(uint32_t), s) == hipSuccess;
+    bool ok = verify_fast_sqrt(device, s, d_bad) && hipMemsetAsync(d_bad, 0, sizeof(uint32_t), s) == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(k_verify_fast_divide, dim3((1u << 24) / 256u), dim3(256), 0, s, c, rc, d_bad);
         ok = hipGetLastError() == hipSuccess &&

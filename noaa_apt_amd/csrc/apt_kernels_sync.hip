@@ -684,7 +684,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
                     const uint32_t k0 = 4 * (j + e);
                     const uint32_t vals[4] = {v[e].x, v[e].y, v[e].z, v[e].w};
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
+                    for (int t = 0; t < 4; ++t) {  // 4 entries per uint4
                         const uint32_t pos = vals[t] & kPosMask;  // a tagged entry only matches its own position
                         if (k0 + t < lim && pos >= sv && (!(vals[t] & kNanStartTag) || pos == sv)) {
                             *uval = pos;

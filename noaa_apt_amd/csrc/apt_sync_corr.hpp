@@ -9,9 +9,10 @@
 //            signs - | -+ x7 | ----), so with pulse sums
 //                B2[i] = F[i] + F[i+1]
 //                B[i]  = ((B2[i] + B2[i+2]) + B2[i+4]) + ...      (pw terms)
-//            corr[i] = -B[i] - B[i+P] + B[i+2P] - ... (19 terms, left to right).
-//            22 operations per position instead of 114 at pw = 3; differs from `strict` by
-//            reassociation only (a few ulp of the largest partial sum).  APTGPU_MODE_FAST.
+//            corr[i] = -B[i] - B[i+P] + B[i+2P] - ... (19 terms, in the fixed association of
+//            sync_corr_from_pulses below).  22 operations per position instead of 114 at pw = 3 — 14 where a
+//            thread evaluates positions one pulse apart and shares the partial sums (sync_corr_pulse_stride);
+//            differs from `strict` by reassociation only (a few ulp of the largest partial sum).  APTGPU_MODE_FAST.
 #pragma once
 
 #include "apt_kernels.hpp"
@@ -62,15 +63,49 @@ __device__ __forceinline__ float sync_pulse_sum(uint32_t pw, At &&at)
     return b;
 }
 
-// fast, step 2: corr[i] from the pulse sums; bat(k) returns B[i + k*2*pw], k < 19
+// fast, step 2: corr[i] from the pulse sums; bat(k) returns B[i + k*2*pw], k < 19.
+// The signs are - | (-+) x7 | ----: with E_k = B_{k+1} - B_k the alternating part is E_1 + E_3 + ... + E_13, summed as
+//   ((E_1 + E_3) + (E_5 + E_7)) + (E_9 + E_11)) + E_13,
+// the tail as (B_15 + B_16) + (B_17 + B_18), and corr = (alternating - B_0) - tail.  A fixed association, so a front end
+// that evaluates many positions one pulse apart and shares the partial sums between them (sync_corr_pulse_stride)
+// produces the same bits as this per-position form.
 template <typename Bat>
 __device__ __forceinline__ float sync_corr_from_pulses(Bat &&bat)
 {
 #pragma clang fp contract(off)
-    float c = -bat(0);
+    float e[7];
 #pragma unroll
-    for (int k = 1; k < 19; ++k) c = sync_pulse_plus(k) ? c + bat(k) : c - bat(k);
-    return c;
+    for (int m = 0; m < 7; ++m) e[m] = bat(2 * m + 2) - bat(2 * m + 1);
+    const float s4 = (e[0] + e[1]) + (e[2] + e[3]);
+    const float alt = (s4 + (e[4] + e[5])) + e[6];
+    const float tail = (bat(15) + bat(16)) + (bat(17) + bat(18));
+    return (alt - bat(0)) - tail;
+}
+
+// The same values for N positions ONE PULSE APART: V[n] = B[i + n*2*pw], n < N + 18; c[j] = corr[i + j*2*pw].
+// E[n] = V[n+1] - V[n], S2[n] = E[n] + E[n+2], S4[n] = S2[n] + S2[n+4]:
+//   c[j] = (((S4[j+1] + S2[j+9]) + E[j+13]) - V[j]) - ((V[j+15] + V[j+16]) + (V[j+17] + V[j+18])).
+// 10.7 additions per position at N = 13 instead of 18.
+template <int N>
+__device__ __forceinline__ void sync_corr_pulse_stride(const float (&V)[N + 18], float (&c)[N])
+{
+#pragma clang fp contract(off)
+    float E[N + 13];   // E[1 .. N+12] used
+#pragma unroll
+    for (int n = 1; n < N + 13; ++n) E[n] = V[n + 1] - V[n];
+    float S2[N + 9];   // S2[1 .. N+8] used
+#pragma unroll
+    for (int n = 1; n < N + 9; ++n) S2[n] = E[n] + E[n + 2];
+    float T2[N + 17];  // T2[15 .. N+16] used
+#pragma unroll
+    for (int n = 15; n < N + 17; ++n) T2[n] = V[n] + V[n + 1];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const float s4 = S2[j + 1] + S2[j + 5];
+        const float alt = (s4 + S2[j + 9]) + E[j + 13];
+        const float tail = T2[j + 15] + T2[j + 17];
+        c[j] = (alt - V[j]) - tail;
+    }
 }
 
 }  // namespace apt::gpu

@@ -5,7 +5,7 @@ mkdir -p /tmp/isa
 cd /root/repo/noaa_apt_amd/csrc || exit 1
 for k in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
-    -fhip-fp32-correctly-rounded-divide-sqrt --cuda-device-only -S -o /tmp/isa/$k.s apt_kernels_$k.hip 2>&1 | grep -E "error" -A5 &
+    -fhip-fp32-correctly-rounded-divide-sqrt -fno-slp-vectorize --cuda-device-only -S -o /tmp/isa/$k.s apt_kernels_$k.hip 2>&1 | grep -E "error" -A5 &
 done
 wait
 for k in "$@"; do
