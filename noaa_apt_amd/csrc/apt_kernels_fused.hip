@@ -178,10 +178,10 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
                 const char *e = std::getenv("APTGPU_PROBE_STOP");
                 return e ? std::atoi(e) : 0;
             }();
-            if (!pcm16 && probe >= 1 && probe <= 7) {
-                void (*const fn[7])(const FusedLaunch &) = {fused_launch_probe1, fused_launch_probe2, fused_launch_probe3,
+            if (!pcm16 && probe >= 1 && probe <= 8) {
+                void (*const fn[8])(const FusedLaunch &) = {fused_launch_probe1, fused_launch_probe2, fused_launch_probe3,
                                                             fused_launch_probe4, fused_launch_probe5, fused_launch_probe6,
-                                                            fused_launch_probe7};
+                                                            fused_launch_probe7, fused_launch_probe8};
                 fn[probe - 1](a);
             } else
 #endif
@@ -189,8 +189,22 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
                 pcm16 ? fused_launch_48k_fast_i16(a) : fused_launch_48k_fast_f32(a);
             }
         }
-        else
-            pcm16 ? fused_launch_48k_i16(a) : fused_launch_48k_f32(a);
+        else {
+#ifdef APT_WITH_PROBES
+            static const int sprobe = [] {
+                const char *e = std::getenv("APTGPU_PROBE_STOP");
+                return e ? std::atoi(e) : 0;
+            }();
+            if (!pcm16 && sprobe >= 11 && sprobe <= 16) {
+                void (*const fn[6])(const FusedLaunch &) = {fused_launch_probe11, fused_launch_probe12, fused_launch_probe13,
+                                                            fused_launch_probe14, fused_launch_probe15, fused_launch_probe16};
+                fn[sprobe - 11](a);
+            } else
+#endif
+            {
+                pcm16 ? fused_launch_48k_i16(a) : fused_launch_48k_f32(a);
+            }
+        }
         return true;
     }
     if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3 && mode != kModeF16Taps) {

@@ -208,7 +208,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             for (int e = 0; e < NXR; ++e) {
                 const int q = (tid + e * kFusedThreads) * 4;
                 if constexpr (sizeof(XT) == 4) {
+#ifdef APT_FUSED_NOLOAD  // timing probe: the kernel without its HBM reads (synthetic tile contents)
+                    xr[e] = make_float4(1000.f + q, 900.f - q, 800.f + (q & 255), 700.f - (q & 127));
+#else
                     xr[e] = (q < Gm::XT_PAD) ? *reinterpret_cast<const float4 *>(xt + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
                 } else {
                     // PCM16: x is 4-byte aligned and xs0, q are even, so sample pairs move as dwords
                     xr[e] = (q < Gm::XT_PAD) ? *reinterpret_cast<const uint2 *>(xt + q) : make_uint2(0u, 0u);
@@ -864,15 +868,29 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         // native v_sqrt_f32 (1 ulp) and a multiplication by RN(1/sin(phi)): ~2 ulp from the
         // correctly rounded value, no range checks (the radicand is >= (1-|cos phi|)(p^2+c^2) >= 0)
         float prev = (tid > 0) ? P[tid * L - 1] : 0.f;
+        if constexpr (INT) {
+            // two values per instruction, as in the strict path below
+            const f2 cos2 = (f2){cosphi2, cosphi2}, inv2 = (f2){inv_sinphi, inv_sinphi};
+#pragma unroll
+            for (int p2 = 0; p2 < (L + 1) / 2; ++p2) {
+                const f2 A = (f2){r[2 * p2], (2 * p2 + 1 < L) ? r[2 * p2 + 1] : r[2 * p2]};
+                const f2 S = (f2){p2 == 0 ? prev : r[2 * p2 - 1], r[2 * p2]};
+                const f2 rad = __builtin_elementwise_fma(-(S * A), cos2, (S * S) + (A * A));
+                const f2 q = (f2){__builtin_amdgcn_sqrtf(rad.x), __builtin_amdgcn_sqrtf(rad.y)} * inv2;
+                Q[tid * L + 2 * p2] = q.x;
+                if (2 * p2 + 1 < L) Q[tid * L + 2 * p2 + 1] = q.y;
+            }
+        } else {
         float prev_sq = prev * prev;
 #pragma unroll
         for (int b = 0; b < L; ++b) {
             const float curr = r[b];
             const float curr_sq = curr * curr;
             const float rad = __builtin_fmaf(-(prev * curr), cosphi2, prev_sq + curr_sq);
-            Q[tid * L + b] = (INT || kq + b > k_lo) ? __builtin_amdgcn_sqrtf(rad) * inv_sinphi : 0.f;
+            Q[tid * L + b] = (kq + b > k_lo) ? __builtin_amdgcn_sqrtf(rad) * inv_sinphi : 0.f;
             prev = curr;
             prev_sq = curr_sq;
+        }
         }
     } else {
         // (the constants in vector registers: an instruction with a scalar operand issues at half the rate of one
@@ -883,19 +901,55 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         float xr[L];
         bool in_range = inv_sinphi != 0.f;  // 0: the fast root / divide did not verify on this device / for this sin(phi)
         if constexpr (INT) {
-            // every value of the thread inside [2^-96, 2^100]: as bit patterns, minimum and maximum (a NaN or a
-            // negative radicand has a pattern above the range's end)
+            // Interior tile, two values per instruction: A[p] = (r[2p], r[2p+1]) are the stage-1 accumulator pairs,
+            // S[p] = (r[2p-1], r[2p]) their predecessors; radicand = (prev^2 + curr^2) - (prev*curr)*cos2 in the
+            // reference's order (envelope_radicand), element by element.
+            constexpr int NPE = (L + 1) / 2;
+            f2 rad[NPE];
             uint32_t umin = 0xFFFFFFFFu, umax = 0u;
+            const f2 cos2 = (f2){cosv, cosv};
 #pragma unroll
-            for (int b = 0; b < L; ++b) {
-                const float curr = r[b];
-                xr[b] = envelope_radicand(prev, curr, cosv);
-                const uint32_t u = __float_as_uint(xr[b]);
-                umin = u < umin ? u : umin;
-                umax = u > umax ? u : umax;
-                prev = curr;
+            for (int p2 = 0; p2 < NPE; ++p2) {
+                const f2 A = (f2){r[2 * p2], (2 * p2 + 1 < L) ? r[2 * p2 + 1] : r[2 * p2]};
+                const f2 S = (f2){p2 == 0 ? prev : r[2 * p2 - 1], r[2 * p2]};
+                const f2 ss = (S * S) + (A * A);
+                const f2 cc = (S * A) * cos2;
+                rad[p2] = ss - cc;
+                // every value of the thread inside [2^-96, 2^100]: as bit patterns, minimum and maximum (a NaN or a
+                // negative radicand has a pattern above the range's end)
+                const uint32_t u0 = __float_as_uint(rad[p2].x), u1 = __float_as_uint(rad[p2].y);
+                umin = u0 < umin ? u0 : umin;
+                umin = u1 < umin ? u1 : umin;
+                umax = u0 > umax ? u0 : umax;
+                umax = u1 > umax ? u1 : umax;
             }
             in_range = in_range && umin >= 0x0F800000u && umax <= 0x71800000u;
+            // wave-uniform choice: the exactly rounded fast path (apt_envelope.hpp) when every value
+            // of the wave is in its range, the compiler's general sequences otherwise
+            if (__all(in_range)) {
+                const f2 sin2 = (f2){sinv, sinv}, inv2 = (f2){invv, invv}, half2 = (f2){0.5f, 0.5f};
+#pragma unroll
+                for (int p2 = 0; p2 < NPE; ++p2) {
+                    // exact_sqrt_inrange + fast_divide (apt_envelope.hpp), both lanes of a pair at once
+                    const f2 x = rad[p2];
+                    const f2 y = (f2){__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)};
+                    const f2 g = x * y;
+                    const f2 h = half2 * y;
+                    const f2 d = __builtin_elementwise_fma(-g, g, x);
+                    const f2 root = __builtin_elementwise_fma(d, h, g);
+                    const f2 q0 = root * inv2;
+                    const f2 rem = __builtin_elementwise_fma(-sin2, q0, root);
+                    const f2 q = __builtin_elementwise_fma(rem, inv2, q0);
+                    Q[tid * L + 2 * p2] = q.x;
+                    if (2 * p2 + 1 < L) Q[tid * L + 2 * p2 + 1] = q.y;
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < L; ++b) {
+                    const float x = (b & 1) ? rad[b / 2].y : rad[b / 2].x;
+                    Q[tid * L + b] = (kq + b > k_lo) ? envelope_general(x, sinphi) : 0.f;
+                }
+            }
         } else {
 #pragma unroll
             for (int b = 0; b < L; ++b) {
@@ -905,18 +959,16 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 in_range = in_range && (envelope_in_range(xr[b]) || kq + b <= k_lo || kq + b >= k_hi);
                 prev = curr;
             }
-        }
-        // wave-uniform choice: the exactly rounded fast path (apt_envelope.hpp) when every value
-        // of the wave is in its range, the compiler's general sequences otherwise
-        if (__all(in_range)) {
+            if (__all(in_range)) {
 #pragma unroll
-            for (int b = 0; b < L; ++b) {
-                // (positions at or past the end of the recording hold garbage: never read)
-                Q[tid * L + b] = (INT || kq + b > k_lo) ? envelope_fast(xr[b], sinv, invv) : 0.f;
+                for (int b = 0; b < L; ++b) {
+                    // (positions at or past the end of the recording hold garbage: never read)
+                    Q[tid * L + b] = (kq + b > k_lo) ? envelope_fast(xr[b], sinv, invv) : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < L; ++b) Q[tid * L + b] = (kq + b > k_lo) ? envelope_general(xr[b], sinphi) : 0.f;
             }
-        } else {
-#pragma unroll
-            for (int b = 0; b < L; ++b) Q[tid * L + b] = (kq + b > k_lo) ? envelope_general(xr[b], sinphi) : 0.f;
         }
     }
     };
@@ -1071,15 +1123,18 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             float fw[L + PUL - 1];
 #pragma unroll
             for (int e = 0; e < L + PUL - 1; ++e) fw[e] = src[e];  // (past the tile: unused garbage)
-            float b2[L + PUL - 2];
+            float b2[L + PUL - 1];
 #pragma unroll
             for (int e = 0; e < L + PUL - 2; ++e) b2[e] = fw[e] + fw[e + 1];
+            b2[L + PUL - 2] = 0.f;
+            // (the sums of PW pairs two positions at a time: packed)
 #pragma unroll
-            for (int b = 0; b < L; ++b) {
-                float bs = b2[b] + b2[b + 2];
+            for (int b = 0; b < L; b += 2) {
+                f2 bs = (f2){b2[b], b2[b + 1]} + (f2){b2[b + 2], b2[b + 3]};
 #pragma unroll
-                for (int t = 2; t < PW; ++t) bs = bs + b2[b + 2 * t];
-                Q[tid * L + b] = bs;
+                for (int t = 2; t < PW; ++t) bs = bs + (f2){b2[b + 2 * t], b2[b + 2 * t + 1]};
+                Q[tid * L + b] = bs.x;
+                if (b + 1 < L) Q[tid * L + b + 1] = bs.y;
             }
             if constexpr (!FAST) {
                 float a = 0.f;
@@ -1117,10 +1172,22 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             const float *vsrc = Q + p0;
             float c[L];
             {
-                float V[L + 18];
+                // V[n] = vsrc[6 n] twice: even-aligned pairs (V[2p], V[2p+1]) and odd-aligned pairs (V[2p+1], V[2p+2]),
+                // one two-address LDS read each (apt_sync_corr.hpp: every addition of the evaluation is then packed)
+                constexpr int NP2 = (L + 1) / 2;
+                f2 VA[NP2 + 9], VS[NP2 + 8], cp[NP2];
 #pragma unroll
-                for (int n = 0; n < L + 18; ++n) V[n] = vsrc[PUL * n];
-                sync_corr_pulse_stride<L>(V, c);
+                for (int p2 = 0; p2 < NP2 + 9; ++p2) VA[p2] = (f2){vsrc[PUL * (2 * p2)], vsrc[PUL * (2 * p2 + 1)]};
+                // (through a pointer the compiler cannot identify with vsrc: it would reuse the values already loaded
+                // and build these pairs with 28 v_mov — a second LDS read costs no VALU issue slot)
+                int odd_ofs = PUL;
+                asm volatile("" : "+v"(odd_ofs));  // (the offset, not the pointer: that would lose its address space)
+                const float *vsrc_odd = vsrc + odd_ofs;
+#pragma unroll
+                for (int p2 = 0; p2 < NP2 + 8; ++p2) VS[p2] = (f2){vsrc_odd[PUL * (2 * p2)], vsrc_odd[PUL * (2 * p2 + 1)]};
+                sync_corr_pulse_stride<NP2>(VA, VS, cp);
+#pragma unroll
+                for (int j = 0; j < L; ++j) c[j] = (j & 1) ? cp[j / 2].y : cp[j / 2].x;
             }
             const bool odd = (blk & 1u) != 0u;
             if (!interior) {

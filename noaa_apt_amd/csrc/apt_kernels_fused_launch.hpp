@@ -56,6 +56,14 @@ void fused_launch_probe4(const FusedLaunch &a);
 void fused_launch_probe5(const FusedLaunch &a);
 void fused_launch_probe6(const FusedLaunch &a);
 void fused_launch_probe7(const FusedLaunch &a);
+// ... and the strict kernel cut off after a stage (11..15)
+void fused_launch_probe11(const FusedLaunch &a);
+void fused_launch_probe12(const FusedLaunch &a);
+void fused_launch_probe13(const FusedLaunch &a);
+void fused_launch_probe14(const FusedLaunch &a);
+void fused_launch_probe15(const FusedLaunch &a);
+void fused_launch_probe16(const FusedLaunch &a);  // strict, complete, no HBM reads
+void fused_launch_probe8(const FusedLaunch &a);   // fast, complete, no HBM reads
 #endif
 
 }  // namespace apt::gpu

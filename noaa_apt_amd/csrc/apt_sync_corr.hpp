@@ -82,29 +82,36 @@ __device__ __forceinline__ float sync_corr_from_pulses(Bat &&bat)
     return (alt - bat(0)) - tail;
 }
 
-// The same values for N positions ONE PULSE APART: V[n] = B[i + n*2*pw], n < N + 18; c[j] = corr[i + j*2*pw].
+// The same values for N positions ONE PULSE APART: V[n] = B[i + n*2*pw]; c[j] = corr[i + j*2*pw].
 // E[n] = V[n+1] - V[n], S2[n] = E[n] + E[n+2], S4[n] = S2[n] + S2[n+4]:
 //   c[j] = (((S4[j+1] + S2[j+9]) + E[j+13]) - V[j]) - ((V[j+15] + V[j+16]) + (V[j+17] + V[j+18])).
-// 10.7 additions per position at N = 13 instead of 18.
-template <int N>
-__device__ __forceinline__ void sync_corr_pulse_stride(const float (&V)[N + 18], float (&c)[N])
+// 10.7 additions per position at N = 13 instead of 18 — and every one of them in packed form (a packed f32
+// instruction takes the issue slot of a plain one): the caller hands V over twice, as even-aligned pairs
+// A[p] = (V[2p], V[2p+1]) and odd-aligned pairs S[p] = (V[2p+1], V[2p+2]), and gets cp[q] = (c[2q], c[2q+1]).
+// Then Eo[p] = A[p+1] - S[p] = (E[2p+1], E[2p+2]), S2o[p] = Eo[p] + Eo[p+1] = (S2[2p+1], S2[2p+2]),
+// T2o[p] = S[p] + A[p+1] = (T2[2p+1], T2[2p+2]), and for the output pair q (j = 2q):
+//   cp[q] = ((((S2o[q] + S2o[q+2]) + S2o[q+4]) + Eo[q+6]) - A[q]) - (T2o[q+7] + T2o[q+8]).
+// NP2 = ceil(N / 2) output pairs; needs A[0 .. NP2+8], S[0 .. NP2+7].
+typedef float sync_f2 __attribute__((ext_vector_type(2)));
+template <int NP2>
+__device__ __forceinline__ void sync_corr_pulse_stride(const sync_f2 (&A)[NP2 + 9], const sync_f2 (&S)[NP2 + 8], sync_f2 (&cp)[NP2])
 {
 #pragma clang fp contract(off)
-    float E[N + 13];   // E[1 .. N+12] used
+    sync_f2 Eo[NP2 + 6];
 #pragma unroll
-    for (int n = 1; n < N + 13; ++n) E[n] = V[n + 1] - V[n];
-    float S2[N + 9];   // S2[1 .. N+8] used
+    for (int p = 0; p < NP2 + 6; ++p) Eo[p] = A[p + 1] - S[p];
+    sync_f2 S2o[NP2 + 4];
 #pragma unroll
-    for (int n = 1; n < N + 9; ++n) S2[n] = E[n] + E[n + 2];
-    float T2[N + 17];  // T2[15 .. N+16] used
+    for (int p = 0; p < NP2 + 4; ++p) S2o[p] = Eo[p] + Eo[p + 1];
+    sync_f2 T2o[NP2 + 8];  // T2o[7 .. NP2+7] used
 #pragma unroll
-    for (int n = 15; n < N + 17; ++n) T2[n] = V[n] + V[n + 1];
+    for (int p = 7; p < NP2 + 8; ++p) T2o[p] = S[p] + A[p + 1];
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const float s4 = S2[j + 1] + S2[j + 5];
-        const float alt = (s4 + S2[j + 9]) + E[j + 13];
-        const float tail = T2[j + 15] + T2[j + 17];
-        c[j] = (alt - V[j]) - tail;
+    for (int q = 0; q < NP2; ++q) {
+        const sync_f2 s4 = S2o[q] + S2o[q + 2];
+        const sync_f2 alt = (s4 + S2o[q + 4]) + Eo[q + 6];
+        const sync_f2 tail = T2o[q + 7] + T2o[q + 8];
+        cp[q] = (alt - A[q]) - tail;
     }
 }
 
