@@ -34,6 +34,150 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 
 
+def config4_recordings(count, rate=48000, seconds=900.0, distinct=4):
+    """The recording list of BASELINE config 4: `count` independent 15-minute recordings, seeds
+    1000..., per-recording sample-rate error uniform in +-50 ppm and a random start phase so that lengths and sync
+    positions differ.  Synthesising 256 x 43.2 M samples would take a quarter of an hour of numpy: `distinct` base
+    recordings (each with its own seed and rate error) are generated, and recording i is base i % distinct started
+    at a random sample (a rotation: another start phase, another row alignment) and cut to its own length.
+    Returns (lengths, make(i) -> f32 array)."""
+    from noaa_apt_amd.testing.synth import synth_apt
+    rng = np.random.default_rng(4)
+    ppm = rng.uniform(-50.0, 50.0, size=count)
+    n_nom = int(round(rate * seconds))
+    lengths = [int(round(n_nom * (1.0 + p * 1e-6))) for p in ppm]
+    shift = rng.integers(0, n_nom, size=count)
+    slack = int(n_nom * 60e-6) + 8
+    bases = {}
+
+    def make(i):
+        j = i % distinct
+        if j not in bases:
+            bases[j] = synth_apt(rate, seconds + slack / rate, seed=1000 + j, ppm=float(ppm[j]))
+        b = bases[j]
+        return np.ascontiguousarray(np.roll(b, -int(shift[i]))[:lengths[i]])
+
+    return lengths, make
+
+
+def run_config4(args):
+    """bench.py --config4: see the argument's help.  One JSON line on rank 0."""
+    import torch
+    import noaa_apt_amd as apt
+    from noaa_apt_amd import shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    visible = torch.cuda.device_count()
+    dist = None
+    if world > 1 or "RANK" in os.environ:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    G = max(1, args.node_gpus)
+    rate_hz, seconds = 48000, 900.0
+    lengths, make = config4_recordings(args.recordings, rate_hz, seconds)
+    shares = shard.assign(lengths, G)  # the node's sharding, whatever is visible here
+    # which of the G shares this process measures: one per rank under torchrun, one per visible device otherwise
+    if dist is not None:
+        mine = [(rank, local_rank)] if rank < G else []
+    else:
+        mine = [(g, g) for g in range(min(G, visible))]
+    settings = apt.Settings.profile(args.profile)
+    rate = apt.Rate.hz(rate_hz)
+    mode = {"strict": apt.MODE_STRICT, "generic": apt.MODE_GENERIC, "fp16taps": apt.MODE_FP16_TAPS, "fast": apt.MODE_FAST}[args.mode]
+    B = max(1, args.batch)
+    per_device = []
+    for share_idx, dev_idx in mine:
+        idx = shares[share_idx]
+        recs = [make(i) for i in idx]
+        samples = float(sum(r.size for r in recs))
+        torch.cuda.set_device(dev_idx)
+        dev = torch.device("cuda", dev_idx)
+        # (i) device-resident: the share's inputs in HBM, decoded in calls of B recordings
+        d_x = [torch.from_numpy(r).to(dev) for r in recs]
+        n_max = max(r.size for r in recs)
+        plan = apt.Plan(settings, rate, True, max_samples=n_max, max_batch=B, device=dev_idx, mode=mode)
+        cap = int(plan.info.max_rows)
+        depth = 3
+        outs = [[torch.empty(cap * 2080, dtype=torch.float32, device=dev) for _ in range(B)] for _ in range(depth)]
+        torch.cuda.synchronize()
+
+        def run_share():
+            k = 0
+            for a in range(0, len(recs), B):
+                b = min(len(recs), a + B)
+                plan.decode_device([t.data_ptr() for t in d_x[a:b]], [t.numel() for t in d_x[a:b]],
+                                   [t.data_ptr() for t in outs[k % depth][:b - a]], [cap] * (b - a))
+                k += 1
+
+        for _ in range(2):
+            run_share()
+        torch.cuda.synchronize()
+        reps = max(1, args.steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run_share()
+        torch.cuda.synchronize()
+        t_dev = (time.perf_counter() - t0) / reps
+        res0 = plan.results(1)[0]
+        plan.close()
+        del d_x, outs
+        torch.cuda.empty_cache()
+        # (ii) host-fed: the same recordings from pageable host memory through aptgpu_decode_batch
+        ctx = apt.Context(device=dev_idx, mode=mode)
+        apt.decode_batch(ctx, settings, recs[:min(len(recs), 2 * B)], rate, True, devices=(dev_idx,), recordings_per_call=B)
+        got, hres, hst = apt.decode_batch(ctx, settings, recs, rate, True, devices=(dev_idx,), recordings_per_call=B,
+                                          return_stats=True)
+        ok = all(not isinstance(g, Exception) for g in got)
+        moved = hst.h2d_bytes + hst.d2h_bytes
+        per_device.append({
+            "share_of_gpu": share_idx, "device": dev_idx, "recordings": len(idx), "samples": samples,
+            "device_resident": {"seconds": round(t_dev, 5), "value": round(samples / t_dev / 1e6, 1), "unit": "Msamples/s"},
+            "host_fed": {"seconds": round(hst.seconds, 5), "value": round(hst.samples / hst.seconds / 1e6, 1),
+                         "unit": "Msamples/s", "pcie_GBps": round(moved / hst.seconds / 1e9, 2),
+                         "frac_of_pcie_peak": round(moved / hst.seconds / 63e9, 4), "all_decoded": ok},
+            "rows_of_first_recording": int(res0.n_rows),
+        })
+        apt.cache_clear()
+    # whole-job figures: every share runs concurrently on its own GPU, so the job takes as long as its slowest share
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_device)
+        per_device = [d for lst in gathered for d in lst]
+    if rank == 0:
+        measured = sorted(d["share_of_gpu"] for d in per_device)
+        t_res = max(d["device_resident"]["seconds"] for d in per_device)
+        t_host = max(d["host_fed"]["seconds"] for d in per_device)
+        s_meas = sum(d["samples"] for d in per_device)
+        line = {
+            "metric": "Msamples/sec WAV->APT-line decode", "unit": "Msamples/s", "higher_is_better": True,
+            "scaling": "strong", "dtype": "f32", "data": "synthetic", "vs_baseline": None,
+            "config": {"workload": f"BASELINE config 4: {args.recordings} independent 15-minute 48 kHz recordings "
+                                   f"(+-50 ppm, random start phase), sharded longest-first over {G} GPUs "
+                                   f"(noaa_apt_amd.shard.assign), {B} recordings per call, mode={args.mode}",
+                       "shares_measured": measured,
+                       "shares_not_measured": [g for g in range(G) if g not in measured],
+                       "visible_gpus": visible if dist is None else world},
+            # the measured shares run side by side: aggregate = their samples over the slowest of them
+            "value": round(s_meas / t_res / 1e6, 1), "n_gpus": len(measured),
+            "value_host_fed": round(s_meas / t_host / 1e6, 1),
+            "note": "value = device-resident aggregate over the measured shares; value_host_fed = the same from pageable "
+                    "host memory (PCIe-inclusive, one worker per GPU).  Shares of GPUs that are not visible are not "
+                    "extrapolated.",
+            "per_device": per_device,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,8 +190,9 @@ def main():
                     help="strict (default): bit-exact; fast: APTGPU_MODE_FAST, tolerance of SURVEY.md §8(d), "
                          "checked against the oracle after the timed region")
     ap.add_argument("--inputs", type=int, default=4,
-                    help="distinct recordings resident in HBM, decoded round-robin (4 x 115 MB exceeds "
-                         "the 256 MB Infinity Cache, so every step reads its input from HBM)")
+                    help="distinct recordings resident in HBM, decoded round-robin; at least --batch of them are "
+                         "generated (16 x 115 MB per step: far beyond the 256 MB Infinity Cache, so every step "
+                         "reads its input from HBM)")
     ap.add_argument("--batch", type=int, default=16,
                     help="recordings per decode_device call = per step (default 16: one launch per stage covers the "
                          "sixteen recordings; BASELINE config 4's per-GPU share is --seconds 900 --batch 32); `value` "
@@ -65,7 +210,15 @@ def main():
                          "launch of the process then has the bench's launch shape)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="experiment: leave the per-kernel HIP events out of the timed region")
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE config 4 as written: --recordings (default 256) independent 15-minute 48 kHz recordings "
+                         "sharded over 8 GPUs with shard.assign(); every visible GPU / rank decodes the share of one of the "
+                         "eight, device-resident and host-fed; shares of GPUs that are not there are marked 'not measured'")
+    ap.add_argument("--recordings", type=int, default=256)
+    ap.add_argument("--node-gpus", type=int, default=8, help="GPUs config 4 shards over (BASELINE.json: 8)")
     args = ap.parse_args()
+    if args.config4:
+        return run_config4(args)
 
     import torch
     import noaa_apt_amd as apt
@@ -248,35 +401,56 @@ def main():
             }
             step(0)
             plan.results(1)
-            # (3) host-fed: recordings in ordinary (pageable) host memory -> aptgpu_decode_batch, which uploads
-            # call k+1 while call k decodes and copies the rows back; once as f32 Signals, once as PCM16 WAV
-            # file images (half the PCIe bytes).  End-to-end, PCIe-inclusive: never part of `value`.
+            # (3) host-fed: BASELINE config 4's per-GPU share (32 recordings of 15 minutes, ragged, +-50 ppm) in ordinary
+            # (pageable) host memory -> aptgpu_decode_batch, which keeps uploads, kernels and downloads of consecutive
+            # calls in flight together; once as f32 Signals, once as PCM16 WAV file images (half the PCIe bytes).
+            # End-to-end, PCIe-inclusive: never part of `value`.
             from noaa_apt_amd.testing.wavfile import make_wav
+            from noaa_apt_amd import shard as _shard
             PCIE_GBS = 63.0  # PCIe Gen5 x16 (MI355X_MICROARCH.md)
-            host_recs = [xs[j % n_inputs] for j in range(8)]
-            host_wavs = [make_wav(v.astype(np.int16), args.rate) for v in xs]
-            host_wavs = [host_wavs[j % n_inputs] for j in range(8)]
+            if (args.rate, args.profile) == (48000, "standard"):
+                c4_len, c4_make = config4_recordings(256)
+                c4_idx = _shard.assign(c4_len, 8)[0]
+                host_recs = [c4_make(i) for i in c4_idx]
+                what = (f"BASELINE config 4's share of one GPU ({len(host_recs)} x 15 min at 48 kHz, +-50 ppm, of 256 "
+                        f"sharded over 8) from pageable host memory")
+            else:
+                host_recs = [xs[j % n_inputs] for j in range(16)]
+                what = f"{len(host_recs)} recordings of this run from pageable host memory"
+            host_wavs = [make_wav(v.astype(np.int16), args.rate) for v in host_recs]
+            ref_host = apt.decode(apt.Context(device=local_rank, mode=mode), settings, host_recs[0], rate, True)
             for key, inputs, workers in (("host_fed_f32", host_recs, 1), ("host_fed_f32_two_workers", host_recs, 2),
                                          ("host_fed_pcm16_wav", host_wavs, 1), ("host_fed_pcm16_wav_two_workers", host_wavs, 2)):
-                apt.decode_batch(apt.Context(device=local_rank, mode=mode), settings, inputs[:2], rate, True,
-                                 devices=(local_rank,))  # warm-up (first-touch of the host pages, HIP pools)
+                apt.decode_batch(apt.Context(device=local_rank, mode=mode), settings, inputs[:2 * B], rate, True,
+                                 devices=(local_rank,) * workers, recordings_per_call=B)  # warm-up (host pages, session cache)
                 got, hres, hst = apt.decode_batch(apt.Context(device=local_rank, mode=mode), settings, inputs, rate, True,
-                                                  devices=(local_rank,) * workers, recordings_per_call=4,
+                                                  devices=(local_rank,) * workers, recordings_per_call=B,
                                                   return_stats=True)
-                ok = all(not isinstance(g, Exception) and g.size == ref_rows.numel() for g in got)
-                same0 = bool(ok and np.array_equal(got[0].view(np.uint32), ref_rows.cpu().numpy().view(np.uint32)))
+                ok = all(not isinstance(g, Exception) for g in got)
+                same0 = bool(ok and np.array_equal(got[0].view(np.uint32), ref_host.view(np.uint32)))
                 moved = hst.h2d_bytes + hst.d2h_bytes
                 extras[key] = {
-                    "what": f"{len(inputs)} recordings from pageable host memory, {workers} worker(s) on this GPU, "
-                            f"4 recordings per call; rows copied back to the host",
+                    "what": f"{what}, {workers} worker(s) on this GPU, {B} recordings per call; rows DMA'd into the "
+                            f"caller's buffers",
                     "seconds": round(hst.seconds, 5),
                     "value": round(hst.samples / hst.seconds / 1e6, 3), "unit": "Msamples/s",
                     "pcie_bytes": int(moved),
                     "pcie_GBps": round(moved / hst.seconds / 1e9, 2),
                     "frac_of_pcie_peak": round(moved / hst.seconds / 1e9 / PCIE_GBS, 4),
-                    "h2d_GBps_inside_copies": round(hst.h2d_bytes / max(hst.h2d_seconds, 1e-9) / 1e9 * workers, 2),
-                    "rows_identical_to_device_resident": same0,
+                    "rows_identical_to_one_shot_decode": same0,
                 }
+            # (4) the one-shot aptgpu_decode() of recording 0 (plan, buffers and staging from the session cache)
+            for _ in range(3):
+                apt.decode(apt.Context(device=local_rank, mode=mode), settings, x, rate, True)
+            o0 = time.perf_counter()
+            for _ in range(10):
+                apt.decode(apt.Context(device=local_rank, mode=mode), settings, x, rate, True)
+            extras["one_shot_decode"] = {
+                "what": f"aptgpu_decode() of one {args.seconds:g} s recording in pageable host memory, rows back on the host "
+                        f"(PCIe floor of its {4 * n / 1e6:.0f} MB: {4 * n / 57e6:.2f} ms)",
+                "ms": round(1e2 * (time.perf_counter() - o0), 3)}
+            del host_recs, host_wavs
+            apt.cache_clear()
         pflags = plan.read_internal("picker_flags", np.uint32, 32)
 
         # ---- the same K steps in APTGPU_MODE_FAST (reported NEXT TO the strict headline, never as `value`):
@@ -341,14 +515,29 @@ def main():
         traffic, traffic_src, sq = None, None, None
         if (args.rate, args.seconds, args.profile, max(1, args.batch)) == (48000, 600.0, "standard", 16) \
                 and dom[0] == "fused_front_end" and args.mode in ("strict", "fast"):
+            # committed counter summaries are only quoted when they were collected on THESE kernel sources
+            # (tools/collect_profiles.sh stamps them with tools/csrc_hash.py's hash of noaa_apt_amd/csrc)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
             try:
-                f = os.path.join(ROOT, "profiles", f"r02_hbm_traffic_{args.mode}.json")
-                traffic = json.load(open(f))["per_launch"]["k_fused"]["hbm_total_MB"] * 1e6
-                traffic_src = f"profiles/r02_hbm_traffic_{args.mode}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                from csrc_hash import csrc_sha16
+                here = csrc_sha16(ROOT)
+            except Exception:
+                here = None
+            try:
+                f = os.path.join(ROOT, "profiles", f"r03_hbm_traffic_{args.mode}.json")
+                d_t = json.load(open(f))
+                if here and d_t.get("csrc_sha16") == here:
+                    traffic = d_t["per_launch"]["k_fused"]["hbm_total_MB"] * 1e6
+                    traffic_src = (f"profiles/r03_hbm_traffic_{args.mode}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                   f"collected on these kernel sources: csrc {here})")
+                else:
+                    traffic_src = (f"profiles/r03_hbm_traffic_{args.mode}.json is stamped {d_t.get('csrc_sha16')}, the kernel "
+                                   f"sources here hash to {here}: not quoted")
             except Exception:
                 traffic = None
             try:
-                sq = json.load(open(os.path.join(ROOT, "profiles", f"r02_sq_counters_{args.mode}.json")))
+                d_s = json.load(open(os.path.join(ROOT, "profiles", f"r03_sq_counters_{args.mode}.json")))
+                sq = d_s if (here and d_s.get("csrc_sha16") == here) else None
             except Exception:
                 sq = None
         # arithmetic the front end EXECUTES per work-rate sample: two flops per FIR tap, ~8 for the envelope,
@@ -393,7 +582,7 @@ def main():
                             f"{plan.info.m} ({plan.info.n_resample_taps} taps) -> AM envelope -> "
                             f"{plan.info.n_lowpass_taps}-tap low-pass -> sync correlation + peak "
                             f"picker -> {res.n_rows} rows x 2080 px",
-                "parallelism": f"{world} independent recordings, one per GPU, no collectives",
+                "parallelism": f"{world} GPU(s), {max(1, args.batch)} independent recordings per GPU and step, no collectives",
                 "recordings_per_call": max(1, args.batch),
                 "mode": args.mode,
                 "rows": int(res.n_rows),

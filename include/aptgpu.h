@@ -137,6 +137,17 @@ int aptgpu_decode(const aptgpu_context *ctx, const aptgpu_settings *settings,
 /* Releases any buffer this library returned (Vec<f32> drop). */
 void aptgpu_free(void *p);
 
+/* The host-array entry points (aptgpu_decode, aptgpu_decode_wav, aptgpu_decode_batch[_wav]) keep what a call
+ * needs on the device between calls — the plan (designed taps, HBM workspace, streams), input / output buffers,
+ * pinned staging — in a process-wide, mutex-guarded, least-recently-used cache keyed by (device, the five
+ * settings decode() reads, input rate, sync, mode, recordings per call): SURVEY.md section 8(b), threading
+ * row.  A cached session serves one call at a time (concurrent callers with the same key each get their own);
+ * at most 8 idle sessions / APTGPU_SESSION_CACHE_MB (default 65536; 0 = no caching) of device memory are
+ * kept.  Calls that export steps or run on a caller's stream do not use it.
+ * aptgpu_cache_clear() releases every idle session; aptgpu_cache_info() reports what is idle. */
+void aptgpu_cache_clear(void);
+void aptgpu_cache_info(int32_t *entries /* nullable */, uint64_t *device_bytes /* nullable */);
+
 /* ====================================================================== */
 /* 2. plans: device-resident and batched decode                            */
 /* ====================================================================== */
@@ -242,8 +253,11 @@ int aptgpu_plan_read_internal(aptgpu_plan *plan, int i, const char *name, void *
  * (the reference's CLI does it for one, src/main.rs:102-104) binds instead of the loop.  Recordings are
  * independent, so they are sharded over `devices` (ordinals, repeats allowed: {0, 0} = two workers on
  * GPU 0; n_devices == 0 = ctx->device) longest-first onto the least loaded entry, with NO collective of
- * any kind; every entry gets a host thread and a plan, uploads call k+1's inputs while call k decodes
- * (recordings_per_call recordings per call, <= 0 = 8), and copies the rows back.  All recordings of
+ * any kind; every entry gets a host thread and a cached session (plan, device buffers, copy streams) and keeps
+ * the uploads of calls k+1 / k+2, the kernels of call k and the download of call k-1 in flight together
+ * (recordings_per_call recordings per call, <= 0 = 16); rows are DMA'd straight into the returned buffers.
+ * Measured on BASELINE config 4's per-GPU share (32 x 15 min at 48 kHz, pageable inputs, one worker, 16 per
+ * call): 52 GB/s over PCIe as f32 Signals (12 Gsamples/s), 50 GB/s as PCM16 WAV images (21.5).  All recordings of
  * a batch share (settings, input_rate_hz, sync); ctx supplies mode (and the device when n_devices == 0),
  * callbacks are not used.
  *   rows_out[i] / n_out[i]: malloc'd rows of recording i (aptgpu_free), NULL / 0 when status[i] != 0;

@@ -181,6 +181,10 @@ def lib():
     L.aptgpu_device_count.restype = i32
     L.aptgpu_free.argtypes = [vp]
     L.aptgpu_free.restype = None
+    L.aptgpu_cache_clear.argtypes = []
+    L.aptgpu_cache_clear.restype = None
+    L.aptgpu_cache_info.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+    L.aptgpu_cache_info.restype = None
     L.aptgpu_decode.argtypes = [C.POINTER(_CContext), C.POINTER(_CSettings), _f32p, sz, u32, i32,
                                 C.POINTER(_f32p), C.POINTER(sz), C.POINTER(Stats), C.c_char_p, sz]
     L.aptgpu_plan_create.argtypes = [C.POINTER(_CContext), C.POINTER(_CSettings), u32, i32, sz,
@@ -257,6 +261,18 @@ def version():
 
 def device_count():
     return int(lib().aptgpu_device_count())
+
+
+def cache_clear():
+    """Releases every idle session (plan + device buffers) of the host-array entry points' cache."""
+    lib().aptgpu_cache_clear()
+
+
+def cache_info():
+    """(idle sessions, device bytes they hold)."""
+    e, b = C.c_int32(0), C.c_uint64(0)
+    lib().aptgpu_cache_info(C.byref(e), C.byref(b))
+    return int(e.value), int(b.value)
 
 
 def _take(ptr, n, dtype=np.float32):
@@ -716,17 +732,35 @@ def decode_batch(context: Optional[Context], settings: Settings, inputs, input_r
     stats = BatchStats()
     err = C.create_string_buffer(_ERRCAP)
     fn = lib().aptgpu_decode_batch_wav if wav else lib().aptgpu_decode_batch
-    _check(fn(C.byref(cctx), C.byref(cs), input_rate.get_hz(), int(sync), k, ptrs, sizes, devs, len(devices),
-              int(recordings_per_call), rows, n_out, status, results, C.byref(stats), err, _ERRCAP), err)
+    rc = fn(C.byref(cctx), C.byref(cs), input_rate.get_hz(), int(sync), k, ptrs, sizes, devs, len(devices),
+            int(recordings_per_call), rows, n_out, status, results, C.byref(stats), err, _ERRCAP)
+    if rc != 0:
+        # a worker-level failure (HIP error, bad argument): nothing of what finished before it is leaked
+        for i in range(k):
+            if rows[i]:
+                lib().aptgpu_free(C.cast(rows[i], C.c_void_p))
+        _check(rc, err)
     out = []
     for i in range(k):
         if status[i] == 0:
             out.append(_take(rows[i], n_out[i]))
-        else:
-            reason = {1: "Got less than 10 rows of samples, audio file is too short",
-                      2: "Found less than 5 sync frames, audio file is too short or too noisy",
-                      3: "work_rate is not multiple of FINAL_RATE"}.get(results[i].reason, "")
-            out.append(_ERRORS.get(status[i], AptError)(reason or f"recording {i}: status {status[i]}"))
+            continue
+        reason = {1: "Got less than 10 rows of samples, audio file is too short",
+                  2: "Found less than 5 sync frames, audio file is too short or too noisy",
+                  3: "work_rate is not multiple of FINAL_RATE"}.get(results[i].reason, "")
+        if not reason and wav:
+            # rejected before it reached a worker: the reference's message for this file (wav.rs / err.rs:72-83),
+            # or the one thing a batch adds — every recording of a batch has the batch's input rate
+            try:
+                spec = wav_parse(keep[i])
+                if spec.sample_rate != input_rate.get_hz():
+                    reason = (f"recording {i}: WAV sample rate {spec.sample_rate} Hz differs from the batch's "
+                              f"input rate {input_rate.get_hz()} Hz")
+            except AptError as e:
+                reason = str(e)
+        elif not reason and sizes[i] and not ptrs[i]:
+            reason = f"recording {i}: null input"
+        out.append(_ERRORS.get(status[i], AptError)(reason or f"recording {i}: status {status[i]}"))
     return (out, list(results)[:k], stats) if return_stats else out
 
 

@@ -7,15 +7,13 @@
 #include <string>
 
 #include "apt_capi_util.hpp"
+#include "apt_session.hpp"
 
 namespace {
 
 using namespace apt::capi;
 
-struct PlanDeleter {
-    void operator()(aptgpu_plan *p) const { aptgpu_plan_destroy(p); }
-};
-using PlanPtr = std::unique_ptr<aptgpu_plan, PlanDeleter>;
+using PlanPtr = std::unique_ptr<aptgpu_plan, apt::capi::PlanDeleter>;
 
 
 apt::Signal download(const float *d, size_t n, hipStream_t s)
@@ -53,6 +51,17 @@ int aptgpu_device_count(void)
 }
 
 void aptgpu_free(void *p) { std::free(p); }
+
+void aptgpu_cache_clear(void) { apt::capi::session_cache_clear(); }
+
+void aptgpu_cache_info(int32_t *entries, uint64_t *device_bytes)
+{
+    int e = 0;
+    uint64_t b = 0;
+    apt::capi::session_cache_info(&e, &b);
+    if (entries) *entries = e;
+    if (device_bytes) *device_bytes = b;
+}
 
 // ------------------------------------------------------------------ plans
 int aptgpu_plan_create(const aptgpu_context *ctx, const aptgpu_settings *settings,
@@ -274,32 +283,73 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
         // decode.rs:63
         if (!wav || !steps) status(&ctx, 0.1f, "Resampling to " + std::to_string(work));
 
-        PlanPtr plan(apt::plan_create(&ctx, *settings, input_rate_hz, sync != 0, n, 1, /*depth*/ 1));
+        // The plan (designed taps, HBM workspace, streams) and the device input / output buffers come from the
+        // process-wide session cache (apt_session.hpp; SURVEY.md §8(b), threading row) unless the caller wants the
+        // step export (unfused kernels, every intermediate kept) or runs on a stream of their own: building and
+        // tearing them down cost 2 ms per call, as much as the PCIe time of a ten-minute recording.
+        const bool cached = !steps && ctx.stream == nullptr;
+        SessionLease lease;
+        struct PoisonOnThrow {  // a session that an exception left half-way through a call is not reused
+            SessionLease &l;
+            bool ok = false;
+            ~PoisonOnThrow() { if (!ok && l) l.poison(); }
+        } guard{lease};
+        PlanPtr own_plan;
+        aptgpu_plan *plan = nullptr;
+        if (cached) {
+            SessionKey key;
+            key.device = ctx.device;
+            key.mode = ctx.mode;
+            key.rate = input_rate_hz;
+            key.sync = sync != 0;
+            key.per_call = 1;
+            key.settings = *settings;
+            key.settings.export_wav = 0;
+            key.settings.export_resample_filtered = 0;
+            lease = session_acquire(key, n);
+            plan = lease->plan.get();
+        } else {
+            own_plan.reset(apt::plan_create(&ctx, *settings, input_rate_hz, sync != 0, n, 1, /*depth*/ 1));
+            plan = own_plan.get();
+        }
         if (plan->spr == 0) throw Error{ErrorKind::Invalid, "work_rate too small"};
-        hipStream_t s = plan->stream;  // a fresh plan's first recording runs on streams[0] == stream
+        hipStream_t s = plan->stream;  // a single-stream plan: every call runs on streams[0] == stream
         const uint64_t w = plan->work_len_for(n);
+        const uint64_t out_cap =
+            sync ? (plan->spr ? w / plan->spr + 2 : 2) * 2080u : plan->out_len_nosync(w) + 16;
 
-        apt::DeviceBuffer<float> d_in, d_rows;
-        apt::DeviceBuffer<uint8_t> d_wav;
+        apt::DeviceBuffer<float> own_in, own_rows;
+        apt::DeviceBuffer<uint8_t> own_wav;
+        const size_t in_bytes = wav ? wav->data_len : n * sizeof(float);
+        void *d_in_ptr = nullptr;
+        float *d_rows_ptr = nullptr;
+        if (cached) {
+            lease->ensure_set(0, in_bytes + 64, out_cap);
+            d_in_ptr = lease->sets[0].in[0].ptr;
+            d_rows_ptr = lease->sets[0].out[0].ptr;
+        } else if (wav) {
+            own_wav.alloc(in_bytes + 16);
+            d_in_ptr = own_wav.ptr;
+        } else {
+            own_in.alloc(n + 16);
+            d_in_ptr = own_in.ptr;
+        }
+        if (!cached) {
+            own_rows.alloc(out_cap);
+            d_rows_ptr = own_rows.ptr;
+        }
+        struct { float *ptr; } d_rows{d_rows_ptr};
         aptgpu_plan::Input in;
         in.n = n;
+        in.ptr = d_in_ptr;
+        if (in_bytes)
+            apt::hip_check(hipMemcpyAsync(d_in_ptr, wav ? static_cast<const void *>(wav_data) : static_cast<const void *>(signal),
+                                          in_bytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync H2D");
         if (wav) {
-            d_wav.alloc(wav->data_len + 16);
-            apt::hip_check(hipMemcpyAsync(d_wav.ptr, wav_data, wav->data_len, hipMemcpyHostToDevice, s),
-                           "hipMemcpyAsync H2D");
-            in.ptr = d_wav.ptr;
             in.channels = wav->channels;
             in.bytes_per_sample = wav->bytes_per_sample;
             in.codec = static_cast<int>(wav->codec);
-        } else {
-            d_in.alloc(n + 16);
-            apt::hip_check(hipMemcpyAsync(d_in.ptr, signal, n * sizeof(float), hipMemcpyHostToDevice, s),
-                           "hipMemcpyAsync H2D");
-            in.ptr = d_in.ptr;
         }
-        const uint64_t out_cap =
-            sync ? static_cast<uint64_t>(plan->max_rows) * 2080u : plan->out_len_nosync(w) + 16;
-        d_rows.alloc(out_cap);
 
         float *rows_ptr = d_rows.ptr;
         const uint64_t cap64 = out_cap;
@@ -347,7 +397,7 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
                 apt::Signal c = download(sl.correlation.ptr, w - plan->n_sync_taps, s);
                 step(&ctx, steps, "sync_correlation", 0, c.data(), c.size(), 0);
             }
-            if (aptgpu_plan_results(plan.get(), 1, &res) != APTGPU_OK)
+            if (aptgpu_plan_results(plan, 1, &res) != APTGPU_OK)
                 throw Error{ErrorKind::Hip, "could not read the result record"};
             if (res.n_sync < 5) throw Error{ErrorKind::Internal, kFewSync};  // decode.rs:112-118
             if (steps) {
@@ -374,7 +424,7 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
         } else {
             status(&ctx, 0.5f, "Skipping Syncing");  // decode.rs:136
             step(&ctx, steps, "sync_correlation", 0, nullptr, 0, work);  // decode.rs:139
-            if (aptgpu_plan_results(plan.get(), 1, &res) != APTGPU_OK)
+            if (aptgpu_plan_results(plan, 1, &res) != APTGPU_OK)
                 throw Error{ErrorKind::Hip, "could not read the result record"};
             if (steps) {
                 const uint64_t aligned = w / plan->spr * plan->spr;
@@ -417,6 +467,7 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
         if (steps) step(&ctx, steps, "resample_decimated", 0, rows, res.n_out, apt::FINAL_RATE);
         *rows_out = rows;
         *n_out = res.n_out;
+        guard.ok = true;
         if (stats) {
             stats->work_len = w;
             stats->n_sync = res.n_sync;

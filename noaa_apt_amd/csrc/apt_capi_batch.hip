@@ -7,14 +7,23 @@
 // the recordings (longest first onto the least loaded entry — the same rule as
 // noaa_apt_amd/shard.py), and works through it in calls of `recordings_per_call`.
 //
-// Per worker, chunk k+1's inputs go up (copy stream, its own device buffers) while chunk k decodes
-// (the plan's streams): a worker owns TWO sets of input / output device buffers and alternates.  WAV
-// file images are uploaded as their data-chunk payload (2 bytes per sample for PCM16) and converted
-// on the device.  Host buffers that are pinned (aptgpu_host_alloc, or hipHostMalloc/hipHostRegister by
-// the caller) are DMA'd directly; pageable ones go through the runtime's staging path.
+// Per worker (one host thread per device entry): a Session leased from the process-wide cache (apt_session.hpp:
+// plan, three sets of device input / output buffers, pinned staging for rows and result records, an upload and
+// a download stream), and a three-stage software pipeline over calls of `recordings_per_call` recordings in
+// which the HOST never waits for anything but finished rows:
+//   upload(c+2)   H2D of the inputs, `up` stream, behind the decode that last read that set's buffers
+//   decode(c)     the plan's five launches, behind upload(c) and the download that last read that set's rows
+//   download(c)   the call's result records (ONE copy) and the rows, `down` stream, into pinned staging
+//   collect(c-1)  host: wait for download(c-1), hand malloc'd rows to the caller
+// so H2D of call k+1 / k+2, the kernels of call k and D2H of call k-1 are in flight together and the link is
+// used in both directions at once.  WAV file images are uploaded as their data-chunk payload (2 bytes per sample
+// for PCM16) and converted on the device.  Pageable host buffers are handed to hipMemcpyAsync as they are: the
+// runtime's pinned staging moves them at 56 GB/s here, as fast as a caller-pinned buffer (57 GB/s;
+// tools/ubench/hostpath.cpp — pinning 173 MB on the fly costs 4.7 ms, more than its transfer).
 #include <algorithm>
 #include <chrono>
 #include <cstring>
+#include <list>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -22,6 +31,195 @@
 #include <vector>
 
 #include "apt_capi_util.hpp"
+#include "apt_session.hpp"
+
+namespace apt::capi {
+
+// ------------------------------------------------------------------ session cache
+bool SessionKey::operator==(const SessionKey &o) const
+{
+    return device == o.device && mode == o.mode && rate == o.rate && sync == o.sync && per_call == o.per_call &&
+           settings.work_rate == o.settings.work_rate &&
+           std::memcmp(&settings.resample_atten, &o.settings.resample_atten, sizeof(float)) == 0 &&
+           std::memcmp(&settings.resample_delta_freq, &o.settings.resample_delta_freq, sizeof(float)) == 0 &&
+           std::memcmp(&settings.resample_cutout, &o.settings.resample_cutout, sizeof(float)) == 0 &&
+           std::memcmp(&settings.demodulation_atten, &o.settings.demodulation_atten, sizeof(float)) == 0;
+}
+
+void PlanDeleter::operator()(aptgpu_plan *p) const { aptgpu_plan_destroy(p); }
+
+Session::~Session()
+{
+    (void)hipSetDevice(key.device);
+    // nothing of this session may still be in flight when its buffers go
+    if (up) (void)hipStreamSynchronize(up);
+    if (down) (void)hipStreamSynchronize(down);
+    if (plan) {
+        try {
+            plan->sync_all();
+        } catch (...) {
+        }
+    }
+    for (IoSet &s : sets) {
+        if (s.h_rows) (void)hipHostFree(s.h_rows);
+        if (s.h_res) (void)hipHostFree(s.h_res);
+        if (s.uploaded) (void)hipEventDestroy(s.uploaded);
+        if (s.decoded) (void)hipEventDestroy(s.decoded);
+        if (s.downloaded) (void)hipEventDestroy(s.downloaded);
+    }
+    if (up) (void)hipStreamDestroy(up);
+    if (down) (void)hipStreamDestroy(down);
+}
+
+void Session::ensure_set(int k, uint64_t in_bytes, uint64_t out_cap)
+{
+    IoSet &s = sets[k];
+    const size_t B = static_cast<size_t>(key.per_call);
+    if (!s.uploaded) {
+        apt::hip_check(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming), "hipEventCreate");
+        apt::hip_check(hipEventCreateWithFlags(&s.decoded, hipEventDisableTiming), "hipEventCreate");
+        apt::hip_check(hipEventCreateWithFlags(&s.downloaded, hipEventDisableTiming), "hipEventCreate");
+        s.in.resize(B);
+        s.out.resize(B);
+    }
+    if (!s.h_res) apt::hip_check(hipHostMalloc(reinterpret_cast<void **>(&s.h_res), B * sizeof(apt::gpu::Result), hipHostMallocDefault), "hipHostMalloc");
+    if (in_bytes > s.in_bytes) {
+        for (auto &b : s.in) {
+            device_bytes -= b.count;
+            b.alloc(in_bytes);
+            device_bytes += in_bytes;
+        }
+        s.in_bytes = in_bytes;
+    }
+    if (out_cap > s.out_cap) {
+        for (auto &b : s.out) {
+            device_bytes -= b.count * sizeof(float);
+            b.alloc(out_cap);
+            device_bytes += out_cap * sizeof(float);
+        }
+        if (s.h_rows) (void)hipHostFree(s.h_rows);  // (re-created at the new size if it is ever needed)
+        s.h_rows = nullptr;
+        s.out_cap = out_cap;
+    }
+}
+
+// the pinned staging for rows whose destination could not be page-locked: allocated on first use
+float *staging_rows(IoSet &s, size_t per_call)
+{
+    if (!s.h_rows)
+        apt::hip_check(hipHostMalloc(reinterpret_cast<void **>(&s.h_rows), per_call * s.out_cap * sizeof(float), hipHostMallocDefault),
+                       "hipHostMalloc");
+    return s.h_rows;
+}
+
+namespace {
+
+struct Cache {
+    std::mutex mu;
+    std::list<std::unique_ptr<Session>> idle;  // most recently used first
+    uint64_t clock = 0;
+    static constexpr size_t kMaxIdle = 8;
+    static uint64_t budget_bytes()
+    {
+        static const uint64_t v = [] {
+            const char *e = std::getenv("APTGPU_SESSION_CACHE_MB");
+            return (e ? static_cast<uint64_t>(std::strtoull(e, nullptr, 10)) : 65536ull) << 20;
+        }();
+        return v;
+    }
+};
+Cache &cache()
+{
+    static Cache *c = new Cache;  // (never destroyed: sessions may not outlive the HIP runtime's own teardown)
+    return *c;
+}
+
+uint64_t plan_device_bytes(const aptgpu_plan &p)
+{
+    // the workspace is dominated by four work-rate arrays per slot
+    return static_cast<uint64_t>(p.slots.size()) * p.max_work_len * 4u * sizeof(float);
+}
+
+}  // namespace
+
+SessionLease session_acquire(const SessionKey &key, uint64_t max_n)
+{
+    Cache &c = cache();
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        for (auto it = c.idle.begin(); it != c.idle.end(); ++it) {
+            if ((*it)->key == key && (*it)->max_n >= max_n) {
+                std::unique_ptr<Session> s = std::move(*it);
+                c.idle.erase(it);
+                return SessionLease(std::move(s));
+            }
+        }
+    }
+    // a new one, with headroom so that the next, slightly longer recording still fits
+    auto s = std::make_unique<Session>();
+    s->key = key;
+    s->max_n = max_n + max_n / 8 + 4096;
+    apt::hip_check(hipSetDevice(key.device), "hipSetDevice");
+    aptgpu_context ctx{};
+    ctx.device = key.device;
+    ctx.mode = key.mode;
+    s->plan.reset(apt::plan_create(&ctx, key.settings, key.rate, key.sync, s->max_n, key.per_call,
+                                   key.per_call > 1 ? Session::kSets : 1));
+    apt::hip_check(hipStreamCreateWithFlags(&s->up, hipStreamNonBlocking), "hipStreamCreate");
+    apt::hip_check(hipStreamCreateWithFlags(&s->down, hipStreamNonBlocking), "hipStreamCreate");
+    s->device_bytes = plan_device_bytes(*s->plan);
+    return SessionLease(std::move(s));
+}
+
+SessionLease::~SessionLease()
+{
+    if (!s_) return;
+    if (poisoned_ || Cache::budget_bytes() == 0) {
+        s_.reset();
+        return;
+    }
+    Cache &c = cache();
+    std::list<std::unique_ptr<Session>> evicted;  // destroyed outside the lock (their destructors synchronise)
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        s_->last_used = ++c.clock;
+        c.idle.push_front(std::move(s_));
+        uint64_t bytes = 0;
+        size_t n = 0;
+        for (auto it = c.idle.begin(); it != c.idle.end();) {
+            bytes += (*it)->device_bytes;
+            ++n;
+            if (n > Cache::kMaxIdle || (bytes > Cache::budget_bytes() && n > 1)) {
+                evicted.push_back(std::move(*it));
+                it = c.idle.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+}
+
+void session_cache_clear()
+{
+    Cache &c = cache();
+    std::list<std::unique_ptr<Session>> all;
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        all.swap(c.idle);
+    }
+}
+
+void session_cache_info(int *entries, uint64_t *device_bytes)
+{
+    Cache &c = cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    uint64_t b = 0;
+    for (const auto &s : c.idle) b += s->device_bytes;
+    if (entries) *entries = static_cast<int>(c.idle.size());
+    if (device_bytes) *device_bytes = b;
+}
+
+}  // namespace apt::capi
 
 namespace {
 
@@ -49,17 +247,20 @@ struct Shared {
     std::mutex mu;
     std::string first_error;
     int first_error_code = APTGPU_OK;
-    double h2d_seconds = 0, d2h_seconds = 0;  // summed over workers (host wall time inside the copies)
+    double h2d_seconds = 0, d2h_seconds = 0;  // summed over workers (host wall time inside the copy calls / collects)
     uint64_t h2d_bytes = 0, d2h_bytes = 0;
 };
 
-struct PlanDeleter {
-    void operator()(aptgpu_plan *p) const { aptgpu_plan_destroy(p); }
-};
+std::mutex &upload_gate(int device)
+{
+    static std::mutex gates[64];
+    return gates[(device >= 0 && device < 64) ? device : 0];
+}
 
 void fail_item(Shared &sh, const Item &it, int code)
 {
     sh.status[it.index] = code;
+    if (sh.rows_out[it.index]) std::free(sh.rows_out[it.index]);
     sh.rows_out[it.index] = nullptr;
     sh.n_out[it.index] = 0;
 }
@@ -69,6 +270,7 @@ void worker(Shared &sh, int device, std::vector<Item> items)
 {
     using clock = std::chrono::steady_clock;
     auto seconds = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    SessionLease lease;
     try {
         apt::hip_check(hipSetDevice(device), "hipSetDevice");
         uint64_t max_n = 0, max_bytes = 0;
@@ -77,65 +279,66 @@ void worker(Shared &sh, int device, std::vector<Item> items)
             max_bytes = std::max(max_bytes, it.bytes);
         }
         const int B = std::max(1, std::min<int>(sh.per_call, static_cast<int>(items.size())));
-        aptgpu_context ctx{};
-        ctx.device = device;
-        ctx.mode = sh.mode;
-        // two calls in flight: the plan's stream of call k+1 picks up where the copy stream left its inputs
-        std::unique_ptr<aptgpu_plan, PlanDeleter> plan(
-            apt::plan_create(&ctx, *sh.settings, sh.rate, sh.sync, max_n, B, /*depth*/ 2));
-        const uint64_t out_cap = sh.sync ? static_cast<uint64_t>(plan->max_rows) * 2080u
-                                         : plan->out_len_nosync(plan->work_len_for(max_n)) + 16;
-        hipStream_t copy = nullptr;
-        apt::hip_check(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking), "hipStreamCreate");
-        struct Set {
-            std::vector<apt::DeviceBuffer<uint8_t>> in;
-            std::vector<apt::DeviceBuffer<float>> out;
-            hipEvent_t uploaded = nullptr, decoded = nullptr;
-        } sets[2];
-        for (Set &s : sets) {
-            s.in.resize(static_cast<size_t>(B));
-            s.out.resize(static_cast<size_t>(B));
-            for (int b = 0; b < B; ++b) {
-                s.in[static_cast<size_t>(b)].alloc(max_bytes + 64);
-                s.out[static_cast<size_t>(b)].alloc(out_cap);
-            }
-            apt::hip_check(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming), "hipEventCreate");
-            apt::hip_check(hipEventCreateWithFlags(&s.decoded, hipEventDisableTiming), "hipEventCreate");
-        }
+        SessionKey key;
+        key.device = device;
+        key.mode = sh.mode;
+        key.rate = sh.rate;
+        key.sync = sh.sync;
+        key.per_call = B;
+        key.settings = *sh.settings;
+        key.settings.export_wav = 0;
+        key.settings.export_resample_filtered = 0;
+        lease = session_acquire(key, max_n);
+        Session &S = *lease;
+        aptgpu_plan *plan = S.plan.get();
+        auto rows_bound = [&](uint64_t n) -> uint64_t {  // floats the rows of an n-sample recording can take
+            const uint64_t w = plan->work_len_for(n);
+            return sh.sync ? (plan->spr ? w / plan->spr + 2 : 2) * 2080u : plan->out_len_nosync(w) + 16;
+        };
+        const uint64_t out_cap = rows_bound(max_n);
+        const size_t n_chunks = (items.size() + static_cast<size_t>(B) - 1) / static_cast<size_t>(B);
+        const int n_sets = static_cast<int>(std::min<size_t>(Session::kSets, n_chunks));
+        for (int k = 0; k < n_sets; ++k) S.ensure_set(k, max_bytes + 64, out_cap);
         double t_h2d = 0, t_d2h = 0;
         uint64_t b_h2d = 0, b_d2h = 0;
 
-        const size_t n_chunks = (items.size() + static_cast<size_t>(B) - 1) / static_cast<size_t>(B);
         auto chunk_of = [&](size_t c, size_t *from, size_t *to) {
             *from = c * static_cast<size_t>(B);
             *to = std::min(items.size(), *from + static_cast<size_t>(B));
         };
-        // upload chunk c into set c % 2 (its previous user, chunk c - 2, was collected before)
+        std::vector<uint8_t> used(Session::kSets, 0);  // the set's events have been recorded in THIS call
+        // H2D of chunk c into set c % 3, behind the decode that last read that set's input buffers
         auto upload = [&](size_t c) {
-            Set &s = sets[c % 2];
+            IoSet &s = S.sets[c % Session::kSets];
             size_t from, to;
             chunk_of(c, &from, &to);
             const auto a = clock::now();
+            if (used[c % Session::kSets]) apt::hip_check(hipStreamWaitEvent(S.up, s.decoded, 0), "hipStreamWaitEvent");
+            // hipMemcpyAsync from PAGEABLE memory returns when the runtime has staged the data: the calling thread is
+            // busy for the duration of the copy.  Two workers of one device doing that at once contend for the link
+            // and for the runtime's staging path (measured: 34 GB/s together against 52 GB/s one after the other),
+            // so uploads to one device take turns; the worker that waits has its decode / download in flight meanwhile.
+            std::lock_guard<std::mutex> gate(upload_gate(device));
             for (size_t k = from; k < to; ++k) {
                 const Item &it = items[k];
                 if (it.bytes)
-                    apt::hip_check(hipMemcpyAsync(s.in[k - from].ptr, it.data, it.bytes, hipMemcpyHostToDevice, copy),
+                    apt::hip_check(hipMemcpyAsync(s.in[k - from].ptr, it.data, it.bytes, hipMemcpyHostToDevice, S.up),
                                    "hipMemcpyAsync H2D");
                 b_h2d += it.bytes;
             }
-            apt::hip_check(hipEventRecord(s.uploaded, copy), "hipEventRecord");
+            apt::hip_check(hipEventRecord(s.uploaded, S.up), "hipEventRecord");
             t_h2d += seconds(a, clock::now());
         };
-        // enqueue the decode of chunk c behind its upload
+        // the decode of chunk c, behind its upload and behind the download that last read that set's rows
         std::vector<std::vector<int>> chunk_slots(n_chunks);
         auto decode = [&](size_t c) {
-            Set &s = sets[c % 2];
+            IoSet &s = S.sets[c % Session::kSets];
             size_t from, to;
             chunk_of(c, &from, &to);
             const int cnt = static_cast<int>(to - from);
             std::vector<aptgpu_plan::Input> ins(static_cast<size_t>(cnt));
             std::vector<float *> rows(static_cast<size_t>(cnt));
-            std::vector<uint64_t> caps(static_cast<size_t>(cnt), out_cap);
+            std::vector<uint64_t> caps(static_cast<size_t>(cnt), s.out_cap);
             for (int b = 0; b < cnt; ++b) {
                 const Item &it = items[from + static_cast<size_t>(b)];
                 aptgpu_plan::Input &in = ins[static_cast<size_t>(b)];
@@ -148,67 +351,136 @@ void worker(Shared &sh, int device, std::vector<Item> items)
                 }
                 rows[static_cast<size_t>(b)] = s.out[static_cast<size_t>(b)].ptr;
             }
-            // the call's stream (plan->streams[calls % 2]) must not start before the inputs have landed
             hipStream_t next = plan->streams[static_cast<size_t>(plan->calls % plan->streams.size())];
             apt::hip_check(hipStreamWaitEvent(next, s.uploaded, 0), "hipStreamWaitEvent");
+            if (used[c % Session::kSets]) apt::hip_check(hipStreamWaitEvent(next, s.downloaded, 0), "hipStreamWaitEvent");
             plan->run_call(cnt, ins.data(), rows.data(), caps.data(), false);
             apt::hip_check(hipEventRecord(s.decoded, next), "hipEventRecord");
             chunk_slots[c] = plan->last_slots;
         };
-        // wait for chunk c, read its records, copy the rows out
-        auto collect = [&](size_t c) {
-            Set &s = sets[c % 2];
+        // D2H of chunk c: the call's result records in ONE copy (its slots are consecutive) into pinned memory, and the
+        // rows STRAIGHT into the buffers the caller will own: malloc'd for as many floats as a recording of that
+        // length can produce (the record says how many of them count), page-locked for the duration of the copy.
+        // (Through pinned staging and a host memcpy the rows cost the worker thread 3 ms per recording — first-touch
+        // page faults included — and that copy, not the link, set the pace of PCM16 batches.)
+        struct Dest {
+            float *rows = nullptr;
+            bool locked = false;
+        };
+        std::vector<std::vector<Dest>> dests(n_chunks);
+        auto release_dests = [&](size_t c, bool free_rows) {
+            for (Dest &d : dests[c]) {
+                if (d.locked) (void)hipHostUnregister(d.rows);
+                d.locked = false;
+                if (free_rows && d.rows) std::free(d.rows);
+                if (free_rows) d.rows = nullptr;
+            }
+        };
+        auto download = [&](size_t c) {
+            IoSet &s = S.sets[c % Session::kSets];
             size_t from, to;
             chunk_of(c, &from, &to);
-            apt::hip_check(hipEventSynchronize(s.decoded), "hipEventSynchronize");
+            const int cnt = static_cast<int>(to - from);
+            const std::vector<int> &sl = chunk_slots[c];
+            const auto a = clock::now();
+            dests[c].resize(static_cast<size_t>(cnt));
+            for (int b = 0; b < cnt; ++b) {
+                const uint64_t fl = std::min<uint64_t>(rows_bound(items[from + static_cast<size_t>(b)].n), s.out_cap);
+                Dest &d = dests[c][static_cast<size_t>(b)];
+                d.rows = static_cast<float *>(std::malloc((fl ? fl : 1) * sizeof(float)));
+                if (!d.rows) throw std::bad_alloc();
+                d.locked = fl && hipHostRegister(d.rows, fl * sizeof(float), hipHostRegisterDefault) == hipSuccess;
+                if (!d.locked) (void)hipGetLastError();  // (falls back to the staged copy below)
+            }
+            apt::hip_check(hipStreamWaitEvent(S.down, s.decoded, 0), "hipStreamWaitEvent");
+            bool consecutive = true;
+            for (int b = 1; b < cnt; ++b) consecutive = consecutive && sl[static_cast<size_t>(b)] == sl[0] + b;
+            if (consecutive) {
+                apt::hip_check(hipMemcpyAsync(s.h_res, plan->d_results.ptr + sl[0], static_cast<size_t>(cnt) * sizeof(apt::gpu::Result),
+                                              hipMemcpyDeviceToHost, S.down), "hipMemcpyAsync results");
+            } else {
+                for (int b = 0; b < cnt; ++b)
+                    apt::hip_check(hipMemcpyAsync(s.h_res + b, plan->d_results.ptr + sl[static_cast<size_t>(b)], sizeof(apt::gpu::Result),
+                                                  hipMemcpyDeviceToHost, S.down), "hipMemcpyAsync results");
+            }
+            for (int b = 0; b < cnt; ++b) {
+                const uint64_t fl = std::min<uint64_t>(rows_bound(items[from + static_cast<size_t>(b)].n), s.out_cap);
+                Dest &d = dests[c][static_cast<size_t>(b)];
+                float *dst = d.locked ? d.rows : staging_rows(s, static_cast<size_t>(S.key.per_call)) + static_cast<size_t>(b) * s.out_cap;
+                apt::hip_check(hipMemcpyAsync(dst, s.out[static_cast<size_t>(b)].ptr, fl * sizeof(float), hipMemcpyDeviceToHost, S.down),
+                               "hipMemcpyAsync D2H rows");
+            }
+            apt::hip_check(hipEventRecord(s.downloaded, S.down), "hipEventRecord");
+            used[c % Session::kSets] = 1;
+            t_d2h += seconds(a, clock::now());
+        };
+        // host: wait for chunk c's download, hand the rows over
+        auto collect = [&](size_t c) {
+            IoSet &s = S.sets[c % Session::kSets];
+            size_t from, to;
+            chunk_of(c, &from, &to);
+            const auto a = clock::now();
+            apt::hip_check(hipEventSynchronize(s.downloaded), "hipEventSynchronize");
             for (size_t k = from; k < to; ++k) {
                 const Item &it = items[k];
+                Dest &d = dests[c][k - from];
                 aptgpu_result r{};
-                apt::hip_check(hipMemcpy(&r, plan->d_results.ptr + chunk_slots[c][k - from], sizeof r, hipMemcpyDeviceToHost),
-                               "hipMemcpy result");
+                static_assert(sizeof(aptgpu_result) == sizeof(apt::gpu::Result), "the device record IS the ABI record");
+                std::memcpy(&r, s.h_res + (k - from), sizeof r);
                 if (sh.results) sh.results[it.index] = r;
+                const bool was_locked = d.locked;
+                if (d.locked) (void)hipHostUnregister(d.rows);
+                d.locked = false;
                 if (r.status != APTGPU_OK) {
+                    std::free(d.rows);
+                    d.rows = nullptr;
                     fail_item(sh, it, r.status);
                     continue;
                 }
-                float *rows = static_cast<float *>(std::malloc((r.n_out ? r.n_out : 1) * sizeof(float)));
-                if (!rows) throw std::bad_alloc();
-                const auto a = clock::now();
-                if (r.n_out)
-                    apt::hip_check(hipMemcpy(rows, s.out[k - from].ptr, r.n_out * sizeof(float), hipMemcpyDeviceToHost),
-                                   "hipMemcpy D2H rows");
-                t_d2h += seconds(a, clock::now());
+                if (!was_locked && r.n_out) std::memcpy(d.rows, s.h_rows + (k - from) * s.out_cap, r.n_out * sizeof(float));
                 b_d2h += r.n_out * sizeof(float);
-                sh.rows_out[it.index] = rows;
+                sh.rows_out[it.index] = d.rows;
+                d.rows = nullptr;
                 sh.n_out[it.index] = r.n_out;
                 sh.status[it.index] = APTGPU_OK;
             }
+            t_d2h += seconds(a, clock::now());
         };
+        struct DestGuard {  // an exception half-way: nothing stays page-locked, nothing leaks
+            std::vector<std::vector<Dest>> &d;
+            hipStream_t down;
+            ~DestGuard()
+            {
+                bool any = false;
+                for (auto &v : d)
+                    for (Dest &x : v) any = any || x.rows;
+                if (!any) return;
+                (void)hipStreamSynchronize(down);
+                for (auto &v : d)
+                    for (Dest &x : v) {
+                        if (x.locked) (void)hipHostUnregister(x.rows);
+                        if (x.rows) std::free(x.rows);
+                        x.rows = nullptr;
+                    }
+            }
+        } dest_guard{dests, S.down};
+        (void)release_dests;
 
-        // software pipeline: upload(c+1) is issued before chunk c is collected, so the copy engine works
-        // on the next inputs while the kernels of chunk c run
-        if (n_chunks > 0) upload(0);
+        for (size_t c = 0; c < std::min<size_t>(2, n_chunks); ++c) upload(c);
         for (size_t c = 0; c < n_chunks; ++c) {
             decode(c);
-            if (c + 1 < n_chunks) {
-                if (c >= 1) collect(c - 1);  // frees set (c + 1) % 2
-                upload(c + 1);
-            }
+            download(c);
+            if (c + 2 < n_chunks) upload(c + 2);
+            if (c >= 1) collect(c - 1);
         }
-        if (n_chunks >= 2) collect(n_chunks - 2);
         if (n_chunks >= 1) collect(n_chunks - 1);
-        plan->sync_all();
-        for (Set &s : sets) {
-            (void)hipEventDestroy(s.uploaded);
-            (void)hipEventDestroy(s.decoded);
-        }
-        (void)hipStreamDestroy(copy);
         std::lock_guard<std::mutex> lock(sh.mu);
         sh.h2d_seconds += t_h2d;
         sh.d2h_seconds += t_d2h;
         sh.h2d_bytes += b_h2d;
         sh.d2h_bytes += b_d2h;
     } catch (const Error &e) {
+        lease.poison();  // (its destructor synchronises the streams before anything is freed)
         std::lock_guard<std::mutex> lock(sh.mu);
         if (sh.first_error_code == APTGPU_OK) {
             sh.first_error_code = static_cast<int>(e.kind);
@@ -217,6 +489,7 @@ void worker(Shared &sh, int device, std::vector<Item> items)
         for (const Item &it : items)
             if (sh.status[it.index] == -1) fail_item(sh, it, static_cast<int>(e.kind));
     } catch (const std::exception &e) {
+        lease.poison();
         std::lock_guard<std::mutex> lock(sh.mu);
         if (sh.first_error_code == APTGPU_OK) {
             sh.first_error_code = APTGPU_ERR_INTERNAL;
@@ -251,7 +524,7 @@ int decode_batch_impl(const aptgpu_context *ctx, const aptgpu_settings *settings
         sh.rate = input_rate_hz;
         sh.sync = sync != 0;
         sh.mode = ctx ? ctx->mode : APTGPU_MODE_STRICT;
-        sh.per_call = std::max(1, std::min(recordings_per_call <= 0 ? 8 : recordings_per_call, apt::gpu::kMaxCall));
+        sh.per_call = std::max(1, std::min(recordings_per_call <= 0 ? 16 : recordings_per_call, apt::gpu::kMaxCall));
         sh.rows_out = rows_out;
         sh.n_out = n_out;
         sh.status = status;

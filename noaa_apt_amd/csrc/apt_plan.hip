@@ -2,6 +2,7 @@
 // kernel pipeline of decode() (reference: src/decode.rs:43-162).
 #include "apt_plan.hpp"
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -240,6 +241,20 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
             plan->fused = 4;  // phase-resident taps in stage 1 + the specialised work-rate stages (44 100 Hz)
         else if (eligible && gpu::fused_any_supported(plan->l, plan->m, t1, t2, plan->pw))
             plan->fused = 2;
+        // A plan whose resampling factors have a specialised kernel but whose tap COUNT differs (a tuned
+        // resample_atten / resample_delta_freq) lands on a slower kernel — the count fixes which window samples each
+        // polyphase branch uses, a compile-time pattern.  Same results; say so once instead of leaving it to
+        // stats.fused (APTGPU_QUIET=1 silences it).
+        if (eligible && !no_spec && plan->fused != 1 && plan->l == 13 && (plan->m == 50 || plan->m == 100) && plan->pw == 3) {
+            static std::atomic<bool> told{false};
+            const char *q = std::getenv("APTGPU_QUIET");
+            if (!(q && q[0] == '1') && !told.exchange(true))
+                std::fprintf(stderr,
+                             "aptgpu: %u -> %u Hz with %u resample / %u low-pass taps has no compile-time specialised front end "
+                             "(those exist for 959 / 1915 resample taps and 37 low-pass taps at 48 / 96 kHz); using kernel path %d "
+                             "(same results, lower throughput)\n",
+                             plan->input_rate, plan->settings.work_rate, t1, t2, plan->fused);
+        }
         plan->fused_fast = plan->mode == APTGPU_MODE_FAST &&
                            ((plan->fused == 1 && gpu::fused_fast_supported(plan->l, plan->m, t1, t2, plan->pw)) ||
                             plan->fused == 3 || plan->fused == 4);

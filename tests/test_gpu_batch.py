@@ -127,3 +127,81 @@ def test_plans_on_two_host_threads_share_a_device(oracle):
     assert not errs, errs
     for o, w in zip(outs, wants):
         assert _same(o, w)
+
+
+def test_session_cache_serves_the_one_shot_decode(oracle):
+    """aptgpu_decode() takes its plan and device buffers from the process-wide session cache (threading
+    row): a second call with the same key reuses the session — also for a SHORTER recording and, within the headroom
+    a session is built with, a slightly longer one — a longer one gets a larger session, every result stays
+    bit-identical to the oracle, and aptgpu_cache_clear() leaves nothing idle."""
+    apt.cache_clear()
+    assert apt.cache_info() == (0, 0)
+    ctx, st, rate = apt.Context(device=0), apt.Settings(), apt.Rate.hz(48000)
+    xs = [synth_apt(48000, s, 900 + i) for i, s in enumerate((12, 12, 9, 12.5, 30))]
+    entries = []
+    for x in xs:
+        assert _same(apt.decode(ctx, st, x, rate, True), oracle.decode(x, 48000, True))
+        entries.append(apt.cache_info()[0])
+    # one session serves the first four (same key, lengths within its capacity); the 30 s recording needs another
+    assert entries[:4] == [1, 1, 1, 1] and entries[4] == 2, entries
+    assert apt.cache_info()[1] > 0
+    # another key (no sync, fast mode, another rate): separate sessions, same answers as uncached plans give
+    x = xs[0]
+    assert _same(apt.decode(ctx, st, x, rate, False), oracle.decode(x, 48000, False))
+    y = synth_apt(11025, 20, 77)
+    assert _same(apt.decode(ctx, st, y, apt.Rate.hz(11025), True), oracle.decode(y, 11025, True))
+    assert apt.cache_info()[0] == 4
+    # errors do not poison later calls
+    with pytest.raises(apt.InternalError):
+        apt.decode(ctx, st, np.zeros(48000, f32), rate, True)
+    assert _same(apt.decode(ctx, st, xs[2], rate, True), oracle.decode(xs[2], 48000, True))
+    apt.cache_clear()
+    assert apt.cache_info() == (0, 0)
+
+
+def test_session_cache_concurrent_callers_get_their_own_session(oracle):
+    import threading
+    apt.cache_clear()
+    x = synth_apt(48000, 14, 4242)
+    want = oracle.decode(x, 48000, True)
+    out = [None] * 4
+
+    def run(k):
+        out[k] = apt.decode(apt.Context(device=0), apt.Settings(), x, apt.Rate.hz(48000), True)
+
+    for _ in range(2):
+        ts = [threading.Thread(target=run, args=(k,)) for k in range(4)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert all(_same(o, want) for o in out)
+    assert 1 <= apt.cache_info()[0] <= 4
+    apt.cache_clear()
+
+
+def test_decode_batch_many_calls_in_flight_and_reused_session(oracle):
+    """More calls than buffer sets (three): every set is reused, uploads run two calls ahead of the decode, rows are
+    DMA'd into the returned buffers — twice over the same cached session."""
+    recs = [synth_apt(48000, 10.5 + 0.5 * (i % 3), 5000 + i) for i in range(14)]
+    want = [oracle.decode(x, 48000, True) for x in recs]
+    for _ in range(2):
+        got = apt.decode_batch(apt.Context(device=0), apt.Settings(), recs, apt.Rate.hz(48000), True, devices=(0,),
+                               recordings_per_call=2)
+        assert all(_same(g, w) for g, w in zip(got, want))
+    wavs = [make_wav(x.astype(np.int16), 48000) for x in recs]
+    got = apt.decode_batch(apt.Context(device=0), apt.Settings(), wavs, apt.Rate.hz(48000), True, devices=(0, 0),
+                           recordings_per_call=3)
+    assert all(_same(g, w) for g, w in zip(got, want))
+
+
+def test_decode_batch_says_why_a_wav_was_rejected():
+    good = make_wav(synth_apt(48000, 11, 1).astype(np.int16), 48000)
+    other_rate = make_wav(synth_apt(11025, 11, 2).astype(np.int16), 11025)
+    broken = bytes(good[:20])
+    got = apt.decode_batch(apt.Context(device=0), apt.Settings(), [good, other_rate, broken], apt.Rate.hz(48000), True)
+    assert not isinstance(got[0], Exception)
+    assert isinstance(got[1], apt.AptError) and "11025" in str(got[1]) and "48000" in str(got[1])
+    assert isinstance(got[2], apt.AptError) and str(got[2]) and "status" not in str(got[2])
+    # ... the same text load() / decode_wav() give for that file
+    with pytest.raises(apt.AptError) as e:
+        apt.wav_parse(broken)
+    assert str(got[2]) == str(e.value)

@@ -3,7 +3,7 @@
 # rocprofv3 is run from /tmp with TMPDIR=/tmp; counters in their own passes with --kernel-trace only.
 # Two phases (bench.py quotes the counter summaries committed under profiles/, so they come first):
 #   collect_profiles.sh counters   rocprofv3 kernel stats, HBM traffic, SQ counters -> gpurun_out/prof/
-#   (copy hbm_traffic_*.json / sq_*/summary.json to profiles/r02_*.json — tools/install_profiles.sh — then)
+#   (copy hbm_traffic_*.json / sq_*/summary.json to profiles/r03_*.json — tools/install_profiles.sh — then)
 #   collect_profiles.sh bench      the bench lines of every config -> gpurun_out/prof/
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof
@@ -23,6 +23,19 @@ for MODE in strict fast; do
      "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only, APTGPU_STREAMS=1) on bench.py --mode $MODE --steps 6: per LAUNCH = per call of 16 recordings of config 2; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B)" > $O/hbm_traffic_${MODE}_raw.json && python tools/calibrate_pmc.py $O/hbm_traffic_${MODE}_raw.json 16 1198 28800000 > $O/hbm_traffic_$MODE.json)
   # (4) SQ issue / stall counters of the front end, one recording per launch
   (cd $R && bash tools/collect_sq.sh $MODE gpurun_out/prof/sq_$MODE > /dev/null 2>&1)
+  # stamp the counter summaries with the hash of the kernel sources they were collected on (bench.py only quotes a
+  # profile whose stamp matches the sources it runs)
+  (cd $R && python - <<PY
+import json, sys
+sys.path.insert(0, "tools")
+from csrc_hash import csrc_sha16
+for f in ("$O/hbm_traffic_$MODE.json", "$O/sq_$MODE/summary.json"):
+    try:
+        d = json.load(open(f)); d["csrc_sha16"] = csrc_sha16(); json.dump(d, open(f, "w"), indent=1)
+    except Exception as e:
+        print("stamp failed", f, e)
+PY
+  )
   # keep the merge small: the per-dispatch csv files are large
   rm -rf $O/fetch_$MODE $O/write_$MODE $O/sq_$MODE/pass*/
   for d in $O/stats_$MODE $O/stats_${MODE}_streams1; do
@@ -42,6 +55,7 @@ done
 (cd $R && python bench.py --no-extras --rate 96000 --seconds 3600 --batch 1 --inputs 2 --steps 20 --warmup 3 > $O/bench_config3.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --mode fp16taps > $O/bench_fp16taps.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --batch 1 > $O/bench_strict_batch1.json 2>> $O/bench_strict.err)
+(cd $R && python bench.py --config4 > $O/bench_config4.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --batch 8 > $O/bench_strict_batch8.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --rate 44100 > $O/bench_44100.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --rate 11025 > $O/bench_11025.json 2>> $O/bench_strict.err)

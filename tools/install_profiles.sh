@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/install_profiles.sh [round]: copy the summaries tools/collect_profiles.sh left under gpurun_out/prof/ into
 # profiles/ under this round's names (what bench.py and the docs cite).
-R=${1:-r02}
+R=${1:-r03}
 P=gpurun_out/prof
 cd "$(dirname "$0")/.." || exit 1
 for MODE in strict fast; do
