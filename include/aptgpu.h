@@ -194,12 +194,14 @@ int aptgpu_plan_get_info(const aptgpu_plan *plan, aptgpu_plan_info *info);
 /* Enqueue decode() of `count` independent recordings already resident in HBM.
  * d_signals[i] points to n[i] device floats; d_rows[i] receives up to
  * rows_cap[i]*2080 device floats.  Asynchronous, no host synchronisation.
- * The plan spreads recordings round-robin over six in-order streams (also
- * across consecutive calls; APTGPU_STREAMS overrides the depth), so front ends
- * of later recordings overlap the peak picker and row gather of earlier ones;
- * it owns max(max_batch + 1, depth) workspace slots.  Calls with count >= 2 on a
- * plan created with max_batch >= 2 run ONE front-end launch for all recordings
- * (such plans own 2*max_batch slots and use 3 chain streams).  If
+ * The recordings of one call go through ONE launch per stage (front end, sync words, sync slots, orbit,
+ * row gather), in order on one of the plan's `depth` internal streams; consecutive calls go round-robin
+ * over those streams (depth = 3 for plans created with max_batch >= 4, else 6; APTGPU_STREAMS overrides),
+ * so the front end of call j+1 overlaps the latency-bound peak picker and the row gather of call j.
+ * Stream k owns the workspace slots [k*max_batch, (k+1)*max_batch) — depth*max_batch slots in all — and a
+ * slot is only reused by a later call on its own stream.  Plans with max_batch >= 4 (and no ctx.stream)
+ * additionally order the front end of call j+1 behind the front end of call j with an event, so that each
+ * front end has the whole GPU.  If
  * ctx.stream was given at plan creation the work is ordered AFTER what is
  * already enqueued on ctx.stream (inputs may be produced there); to order
  * ctx.stream after the decode, call aptgpu_plan_join().  Recordings of different

@@ -118,8 +118,9 @@ void gather_rows_call(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slo
 bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
 uint32_t fused_group_size(uint32_t l);
 // host: stage-1 tap-pair table [WIN][PS][2] (see apt_kernels_fused.hip) and its size in floats
-uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1);
-void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, float *hs);
+uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1, int ch);
+void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, int ch, float *hs);
+int fused_chunk_of(uint32_t m, bool fast);  // window samples per stage-1 chunk of the specialised kernel for (m, strict / fast)
 // host: stage-3 tap pairs h2p[k] = (h2[k-1], h2[k]), k = 0 .. t2  (2*(t2+1) floats)
 void fused_lowpass_pairs(const float *h2, uint32_t t2, float *h2p);
 // fp16-tap stage 1 (APTGPU_MODE_FP16_TAPS): table size in dwords, host-side table builder (returns

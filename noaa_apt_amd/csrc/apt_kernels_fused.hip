@@ -42,49 +42,58 @@ bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t 
 
 uint32_t fused_group_size(uint32_t l) { return 4 * l; }
 
-// floats in the stage-1 tap table: chunk-major, one run of chw = 4*(l/2) + 2 dwords
-// per chunk of two window samples, plus one chunk of zeros
-uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1)
+// floats in the stage-1 tap table: chunk-major, one run of fused_chunk_dwords() per chunk of `ch` window samples,
+// plus one chunk of zeros
+uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1, int ch)
 {
     const uint32_t tp = (t1 + l - 1) / l;
     const uint32_t clast = ((l - 1) * m + l - 1) / l;
     const uint32_t win = clast + tp;
-    const uint32_t chw = 4 * (l / 2) + 2;
-    return ((win + 1) / 2 + 1) * chw;
+    const uint32_t chw = static_cast<uint32_t>(fused_chunk_dwords(static_cast<int>(l), ch));
+    return ((win + ch - 1) / ch + 1) * chw;
 }
 
-// host: chunk c holds, for its window samples q = 2c + e (e = 0, 1), the pairs (tap of branch 2pp at q, tap of
-// branch 2pp+1 at q) at dwords e*2*np + 2*pp, then (tap of the odd branch l-1 at 2c, at 2c+1) at dwords 4*np;
+// host: chunk c holds, for its window samples q = ch*c + e (e < ch), the pairs (tap of branch 2pp at q, tap of
+// branch 2pp+1 at q) at dwords e*2*np + 2*pp; then, for an odd l, the taps of the branch l-1: those of the chunk's
+// ALIGNED sample pair (qp even, qp + 1) at dwords ch*2*np, +1, and (ch == 3) that of the sample left over at +2;
 // 0 where a branch does not use q or q lies past the window
-void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, float *hs)
+void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, int ch, float *hs)
 {
     const uint32_t tp = (t1 + l - 1) / l;
     const uint32_t clast = ((l - 1) * m + l - 1) / l;
     const uint32_t win = clast + tp;
     const uint32_t np = l / 2;
-    const uint32_t chw = 4 * np + 2;
-    auto tap = [&](uint32_t b, uint32_t q) -> float {
+    const uint32_t chw = static_cast<uint32_t>(fused_chunk_dwords(static_cast<int>(l), ch));
+    auto tap = [&](uint32_t b, int64_t q) -> float {
         const uint32_t cb = (b * m + l - 1) / l;
         const uint32_t pb = cb * l - b * m;
-        if (q < cb || q >= win) return 0.f;
+        if (q < static_cast<int64_t>(cb) || q >= static_cast<int64_t>(win)) return 0.f;
         const uint64_t j = pb + static_cast<uint64_t>(q - cb) * l;
         return j < t1 ? coeff[j] : 0.f;
     };
-    const uint32_t nch = (win + 1) / 2;
+    const uint32_t nch = (win + ch - 1) / ch;
     for (uint32_t c = 0; c <= nch; ++c) {
         float *row = hs + static_cast<size_t>(c) * chw;
         for (uint32_t i = 0; i < chw; ++i) row[i] = 0.f;
         if (c == nch) break;
-        for (uint32_t e = 0; e < 2; ++e)
+        const int64_t q0 = static_cast<int64_t>(ch) * c;
+        for (int e = 0; e < ch; ++e)
             for (uint32_t pp = 0; pp < np; ++pp) {
-                row[e * 2 * np + 2 * pp] = tap(2 * pp, 2 * c + e);
-                row[e * 2 * np + 2 * pp + 1] = tap(2 * pp + 1, 2 * c + e);
+                row[e * 2 * np + 2 * pp] = tap(2 * pp, q0 + e);
+                row[e * 2 * np + 2 * pp + 1] = tap(2 * pp + 1, q0 + e);
             }
         if (l & 1) {
-            row[4 * np] = tap(l - 1, 2 * c);
-            row[4 * np + 1] = tap(l - 1, 2 * c + 1);
+            const int64_t qp = (q0 & 1) ? q0 + 1 : q0;
+            row[ch * 2 * np] = tap(l - 1, qp);
+            row[ch * 2 * np + 1] = tap(l - 1, qp + 1);
+            if (ch == 3) row[ch * 2 * np + 2] = tap(l - 1, (q0 & 1) ? q0 : q0 + 2);
         }
     }
+}
+
+int fused_chunk_of(uint32_t m, bool fast)
+{
+    return fused_chunk(static_cast<int>(m), fast ? kModeFast : kModeStrict);
 }
 
 // host: stage-3 table h2p[k] = (h2[k-1], h2[k]) for k = 0 .. t2 (0 outside the filter)

@@ -83,9 +83,7 @@ struct FusedGeom {
     static constexpr int LDS_FLOATS = XT_LDS > W_LDS_FLOATS ? XT_LDS : W_LDS_FLOATS;
     static constexpr int GS = 4 * L;                                  // correlation group size
     static constexpr int NP = L / 2;                                  // accumulator pairs (+1 single if L odd)
-    // stage-1 tap table, chunk-major (fused_branch_taps): per chunk of two window samples, 2 x NP branch pairs,
-    // then (tap of the odd branch L-1 at sample 0, at sample 1)
-    static constexpr int CHW = 2 * 2 * NP + 2;
+    // (stage-1 tap table: chunk-major, fused_branch_taps / fused_chunk_dwords in apt_kernels_fused_launch.hpp)
     static constexpr int DW = L + T2 - 1;                             // envelope window per thread
     static_assert(PRE_K >= T2 + 1, "pre-halo too small for the low-pass");
     static_assert((kFusedThreads - kPreThreads - kOwnThreads) * L >= G - 1, "post-halo too small");
@@ -606,19 +604,22 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         for (int b = 0; b < L; ++b) r[b] = (kq + b < k_lo || kq + b >= k_hi) ? 0.f : acc[b] * f16_unscale;
     } else
     {
-        // Software pipeline over chunks of CH = 2 window samples.  The taps of a chunk are ONE contiguous run of
-        // the chunk-major table (fused_branch_taps: 2 x NP branch pairs, then the pair of the odd branch's taps
-        // of the two samples) fetched by three scalar loads written out as inline assembly — as C++ loads the
+        // Software pipeline over chunks of CH = 2 window samples (fused_chunk()).  The taps of a chunk are ONE
+        // contiguous run of the chunk-major table (fused_branch_taps: CH x NP branch pairs, then the odd branch's
+        // taps of the chunk's samples) fetched by three scalar loads written out as inline assembly — as C++ loads the
         // compiler merged them across chunks, waited for them on the spot and spilled what it had fetched early
         // (454 SGPR spills in one layout, 41 in another).  SMEM returns out of order, so the only usable wait is
         // lgkmcnt(0): chunk c waits for the loads issued one chunk ago (the wait names the tap registers as
         // in/out operands, which is what orders their uses behind it — the compiler's own counter does not
-        // see assembly loads), issues the loads of chunk c + 1, and computes under their latency.
+        // see assembly loads), issues the loads of chunk c + 1, and computes under their latency: CH * (NP + 1)
+        // packed instructions of cover in the strict modes, half that in fast mode.
         // kModeFast runs the same pipeline with one v_pk_fma_f32 per tap pair instead of a
         // v_pk_mul_f32 + v_pk_add_f32 (half the VALU instructions under the same tap loads).
-        constexpr int CH = 2;
+        constexpr int CH = fused_chunk(M, MODE);
+        static_assert(CH == 2, "two window samples per chunk (apt_kernels_fused_launch.hpp says why not three)");
         constexpr int NCH = (Gm::WIN + CH - 1) / CH;
-        static_assert(Gm::CHW == 26, "three scalar loads per chunk: 16 + 8 + 2 dwords");
+        constexpr int CHW = fused_chunk_dwords(L, CH);  // 26: 16 + 8 + 2 dwords; 40: 16 + 16 + 8
+        static_assert(CHW == 26, "three scalar loads per chunk: 16 + 8 + 2 dwords");
         auto xsrc = [&](int q) -> float {
             if constexpr (sizeof(XT) == 2) return static_cast<float>(reinterpret_cast<const int16_t *>(lds)[tid * M + q]);
             else return P[tid * M + q];
@@ -630,50 +631,56 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         typedef uint32_t u16s __attribute__((ext_vector_type(16)));
         typedef uint32_t u8s __attribute__((ext_vector_type(8)));
         typedef uint32_t u2s __attribute__((ext_vector_type(2)));
+        using TB = std::conditional_t<CH == 2, u8s, u16s>;
+        using TC = std::conditional_t<CH == 2, u2s, u8s>;
+        constexpr int NB_ = CH == 2 ? 8 : 16;  // dwords in tb
         u16s ta[2];  // dwords 0..15 of the chunk in use / in flight (SGPRs)
-        u8s tb[2];   // 16..23
-        u2s tc[2];   // 24, 25: (odd branch's tap at sample 0, at sample 1)
+        TB tb[2];    // 16..23 / 16..31
+        TC tc[2];    // 24, 25 / 32..39
         // Window samples, RW per LDS read.  Lane t reads word t*M + q: as 4-byte reads a stride of 50 words
         // reaches 16 of the 32 banks (2-way conflict, 4.1 LDS cycles per instruction measured; 100 words: 8 banks,
         // 8.5 cycles), and the compiler's ds_read2_b32 is two such reads.  An 8-byte read is banked over 64 words:
         // M = 50 is conflict-free as ds_read_b64 (2.3 cycles per TWO samples), M = 100 as ds_read_b128 (4.9 cycles
-        // per FOUR) — tools/ubench/rates.hip.  (PCM16 tiles: stride M/2 words, element-wise reads.)
+        // per FOUR) — tools/ubench/rates.hip.  (PCM16 tiles: stride M/2 words, element-wise reads.)  The read groups
+        // live in a ring of four register tuples: a chunk's samples span at most two groups, the next chunk's two more.
         constexpr int RW = (sizeof(XT) == 4) ? ((M % 4 == 0) ? 4 : ((M % 2 == 0) ? 2 : 1)) : 1;
-        constexpr int XG = RW > CH ? RW : CH;
+        constexpr int GW = RW >= 2 ? RW : 2;  // samples per register tuple (element-wise reads fill pairs)
         typedef float f4w __attribute__((ext_vector_type(4)));
-        using XV = std::conditional_t<RW == 4, f4w, f2>;
-        XV xw[2];                // window samples of the read group in use / in flight (one register tuple)
+        using XV = std::conditional_t<GW == 4, f4w, f2>;
+        XV xw[4];
+        auto g_hi = [](int c) constexpr -> int { return c < 0 ? -1 : (CH * c + CH - 1) / GW; };  // last group chunk c touches
+        auto read_group = [&](auto gg) {
+            constexpr int g = decltype(gg)::value;
+            if constexpr (RW >= 2) {
+                // (the last group may reach past the window: inside the tile's pad)
+                xw[g & 3] = *reinterpret_cast<const XV *>(P + tid * M + g * GW);
+            } else {
+#pragma unroll
+                for (int e = 0; e < GW; ++e) xw[g & 3][e] = (g * GW + e < Gm::WIN) ? xsrc(g * GW + e) : 0.f;
+            }
+        };
         auto issue = [&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int buf = c & 1;
             // (asm operands do not capture: name the registers through references first.  The tap registers are
-            // pinned — s[36:87], the two buffers side by side: left to itself the allocator put both buffers of
+            // pinned, the two buffers side by side: left to itself the allocator put both buffers of
             // the last piece into one register pair and spilled it to VGPR lanes in every chunk)
             u16s &ra = ta[buf];
-            u8s &rb = tb[buf];
-            u2s &rc = tc[buf];
+            TB &rb = tb[buf];
+            TC &rc = tc[buf];
             const cf2_ptr hsp = hs;
 #define APT_TAP_LOADS "s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx8 %1, %3, %5\n\ts_load_dwordx2 %2, %3, %6"
             if constexpr (buf == 0)
                 asm volatile(APT_TAP_LOADS
                              : "={s[36:51]}"(ra), "={s[68:75]}"(rb), "={s[84:85]}"(rc)
-                             : "s"(hsp), "n"(c * Gm::CHW * 4), "n"(c * Gm::CHW * 4 + 64), "n"(c * Gm::CHW * 4 + 96));
+                             : "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 96));
             else
                 asm volatile(APT_TAP_LOADS
                              : "={s[52:67]}"(ra), "={s[76:83]}"(rb), "={s[86:87]}"(rc)
-                             : "s"(hsp), "n"(c * Gm::CHW * 4), "n"(c * Gm::CHW * 4 + 64), "n"(c * Gm::CHW * 4 + 96));
+                             : "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 96));
 #undef APT_TAP_LOADS
-            if constexpr (RW >= CH) {
-                if constexpr ((c * CH) % RW == 0) {  // (the last group may reach past the window: inside the tile's pad)
-                    constexpr int g = (c * CH) / RW;
-                    const float *src = P + tid * M + c * CH;
-                    xw[g & 1] = *reinterpret_cast<const XV *>(src);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < CH; ++e) xw[buf][e] = (c * CH + e < Gm::WIN) ? xsrc(c * CH + e) : 0.f;
-                static_assert(CH == 2, "element-wise window reads fill an f2");
-            }
+            // the read groups chunk c touches that no earlier chunk has fetched
+            static_for<g_hi(c - 1) + 1, g_hi(c) + 1>([&](auto gg) { read_group(gg); });
         };
         // (the window samples read with the taps are operands too: the compiler then places ITS wait for that LDS
         // read here, in front of the next chunk's loads — behind them its count-based wait, which does not know
@@ -682,40 +689,44 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             constexpr int c = decltype(cc)::value;
             constexpr int buf = c & 1;
             u16s &ra = ta[buf];
-            u8s &rb = tb[buf];
-            u2s &rc = tc[buf];
-#define APT_TAP_REGS0 "+{s[36:51]}"(ra), "+{s[68:75]}"(rb), "+{s[84:85]}"(rc)
-#define APT_TAP_REGS1 "+{s[52:67]}"(ra), "+{s[76:83]}"(rb), "+{s[86:87]}"(rc)
-            if constexpr (RW >= CH && (c * CH) % RW != 0) {
-                if constexpr (buf == 0) asm volatile("s_waitcnt lgkmcnt(0)" : APT_TAP_REGS0);
-                else asm volatile("s_waitcnt lgkmcnt(0)" : APT_TAP_REGS1);
-            } else {
-                constexpr int g = RW >= CH ? ((c * CH) / RW) & 1 : buf;
-                XV &xv = xw[g];
-                if constexpr (buf == 0) asm volatile("s_waitcnt lgkmcnt(0)" : APT_TAP_REGS0, "+v"(xv));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : APT_TAP_REGS1, "+v"(xv));
-            }
-#undef APT_TAP_REGS0
-#undef APT_TAP_REGS1
+            TB &rb = tb[buf];
+            TC &rc = tc[buf];
+            constexpr int g0 = g_hi(c - 1) + 1, g1 = g_hi(c);  // groups fetched with this chunk's taps
+            constexpr int nnew = g1 - g0 + 1;
+            static_assert(nnew >= 0 && nnew <= 2, "at most two new read groups per chunk");
+            XV &x0 = xw[(nnew >= 1 ? g0 : 0) & 3];
+            XV &x1 = xw[(nnew >= 2 ? g0 + 1 : 0) & 3];
+#define APT_WAIT(REGS)                                                                                     \
+            if constexpr (nnew == 0) asm volatile("s_waitcnt lgkmcnt(0)" : REGS);                                    \
+            else if constexpr (nnew == 1) asm volatile("s_waitcnt lgkmcnt(0)" : REGS, "+v"(x0));                   \
+            else asm volatile("s_waitcnt lgkmcnt(0)" : REGS, "+v"(x0), "+v"(x1));
+#define APT_COMMA ,
+            if constexpr (buf == 0) { APT_WAIT("+{s[36:51]}"(ra) APT_COMMA "+{s[68:75]}"(rb) APT_COMMA "+{s[84:85]}"(rc)) }
+            else { APT_WAIT("+{s[52:67]}"(ra) APT_COMMA "+{s[76:83]}"(rb) APT_COMMA "+{s[86:87]}"(rc)) }
+#undef APT_WAIT
+#undef APT_COMMA
         };
-        auto xat = [&](auto cc, auto ee) -> float {
-            constexpr int c = decltype(cc)::value, e = decltype(ee)::value;
-            if constexpr (RW >= CH) return xw[((c * CH) / RW) & 1][(c * CH) % RW + e];
-            else return xw[c & 1][e];
+        // window sample q
+        auto xq_of = [&](auto qq) -> float {
+            constexpr int q = decltype(qq)::value;
+            return xw[(q / GW) & 3][q % GW];
+        };
+        // window samples (q, q + 1), q even: an aligned register pair
+        auto xpair_of = [&](auto qq) -> f2 {
+            constexpr int q = decltype(qq)::value;
+            static_assert(q % 2 == 0, "aligned pair");
+            if constexpr (GW == 2) return xw[(q / 2) & 3];
+            else return (f2){xw[(q / GW) & 3][q % GW], xw[(q / GW) & 3][q % GW + 1]};
         };
         // dword i of the chunk's taps
         auto tapd = [&](auto cc, auto ii) -> float {
             constexpr int buf = decltype(cc)::value & 1, i = decltype(ii)::value;
             if constexpr (i < 16) return __uint_as_float(ta[buf][i]);
-            else if constexpr (i < 24) return __uint_as_float(tb[buf][i - 16]);
-            else return __uint_as_float(tc[buf][i - 24]);
+            else if constexpr (i < 16 + NB_) return __uint_as_float(tb[buf][i - 16]);
+            else return __uint_as_float(tc[buf][i - 16 - NB_]);
         };
-        auto tap_pair = [&](auto cc, auto ee, auto kk) -> f2 {  // (taps of branches 2k, 2k+1 at sample e)
+        auto tap_pair = [&](auto cc, auto ee, auto kk) -> f2 {  // (taps of branches 2k, 2k+1 at sample e of the chunk)
             constexpr int i = decltype(ee)::value * 2 * Gm::NP + 2 * decltype(kk)::value;
-            return (f2){tapd(cc, std::integral_constant<int, i>{}), tapd(cc, std::integral_constant<int, i + 1>{})};
-        };
-        auto tap_odd = [&](auto cc) -> f2 {  // (taps of the odd branch L-1 at the chunk's two samples)
-            constexpr int i = CH * 2 * Gm::NP;
             return (f2){tapd(cc, std::integral_constant<int, i>{}), tapd(cc, std::integral_constant<int, i + 1>{})};
         };
         // product of window sample (c, e) with tap pair k — kept apart from the accumulation so
@@ -726,7 +737,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             constexpr int q = c * CH + e;
             f2 p = (f2){0.f, 0.f};
             if constexpr (q < Gm::WIN) {
-                const float xq = xat(cc, ee);
+                const float xq = xq_of(std::integral_constant<int, q>{});
                 const f2 t = tap_pair(cc, ee, kk);
                 constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
                 constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
@@ -745,7 +756,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             constexpr int c = decltype(cc)::value, e = decltype(ee)::value, k = decltype(kk)::value;
             constexpr int q = c * CH + e;
             if constexpr (q < Gm::WIN) {
-                const float xq = xat(cc, ee);
+                const float xq = xq_of(std::integral_constant<int, q>{});
                 const f2 t = tap_pair(cc, ee, kk);
                 constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
                 constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
@@ -773,31 +784,52 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 }
             }
         };
-        // the odd branch L-1: the products of its two taps of the chunk in ONE packed multiply (taps and samples
-        // both lie in aligned pairs), its additions one after the other in tap order
+        // the odd branch L-1.  Its taps of the chunk's samples lie behind the pairs (fused_branch_taps): first those
+        // of the chunk's aligned sample pair (q even, q + 1) — one packed multiply then forms both products, taps and
+        // samples each in an aligned register pair — then the tap of the sample left over (three-sample chunks).  The
+        // additions run one after the other in tap order.
         auto odd_branch = [&](auto cc) {
             constexpr int c = decltype(cc)::value;
             if constexpr (L & 1) {
                 constexpr int q0 = c * CH;
-                constexpr bool u0 = q0 < Gm::WIN && branch_uses<L, M, T1>(L - 1, q0);
-                constexpr bool u1 = q0 + 1 < Gm::WIN && branch_uses<L, M, T1>(L - 1, q0 + 1);
-                using I0 = std::integral_constant<int, 0>;
-                using I1 = std::integral_constant<int, 1>;
-                if constexpr (u0 || u1) {
-                    const f2 t = tap_odd(cc);
-                    const float x0 = xat(cc, I0{}), x1 = xat(cc, I1{});
-                    if constexpr (FAST) {
-                        if constexpr (u0) accl = __builtin_fmaf(t.x, x0, accl);
-                        if constexpr (u1) accl = __builtin_fmaf(t.y, x1, accl);
-                    } else if constexpr (u0 && u1) {
-                        const f2 po = t * (f2){x0, x1};
-                        accl = accl + po.x;
-                        accl = accl + po.y;
-                    } else if constexpr (u0) {
-                        accl = accl + t.x * x0;
-                    } else {
-                        accl = accl + t.y * x1;
+                constexpr int qp = (q0 & 1) ? q0 + 1 : q0;             // the aligned pair (qp, qp + 1)
+                constexpr int qs = CH == 3 ? ((q0 & 1) ? q0 : q0 + 2) : -1;  // the single sample of a three-sample chunk
+                constexpr int io = CH * 2 * Gm::NP;                      // dword of the pair's first tap; the single's: io + 2
+                auto use = [](int q) constexpr { return q >= 0 && q < Gm::WIN && branch_uses<L, M, T1>(L - 1, q); };
+                constexpr bool u0 = use(qp), u1 = use(qp + 1), us = use(qs);
+                const f2 t = (f2){tapd(cc, std::integral_constant<int, io>{}), tapd(cc, std::integral_constant<int, io + 1>{})};
+                auto single = [&]() {
+                    if constexpr (us) {
+                        const float ts = tapd(cc, std::integral_constant<int, io + 2>{});
+                        const float xs = xq_of(std::integral_constant<int, us ? qs : 0>{});
+                        if constexpr (FAST) accl = __builtin_fmaf(ts, xs, accl);
+                        else accl = accl + ts * xs;
                     }
+                };
+                auto pair = [&]() {
+                    if constexpr (u0 || u1) {
+                        const f2 xp = xpair_of(std::integral_constant<int, qp>{});
+                        if constexpr (FAST) {
+                            if constexpr (u0) accl = __builtin_fmaf(t.x, xp.x, accl);
+                            if constexpr (u1) accl = __builtin_fmaf(t.y, xp.y, accl);
+                        } else if constexpr (u0 && u1) {
+                            const f2 po = t * xp;
+                            accl = accl + po.x;
+                            accl = accl + po.y;
+                        } else if constexpr (u0) {
+                            accl = accl + t.x * xp.x;
+                        } else {
+                            accl = accl + t.y * xp.y;
+                        }
+                    }
+                };
+                // ascending tap order: the single sample comes first when the chunk starts on an odd sample
+                if constexpr (CH == 3 && (q0 & 1)) {
+                    single();
+                    pair();
+                } else {
+                    pair();
+                    single();
                 }
             }
         };

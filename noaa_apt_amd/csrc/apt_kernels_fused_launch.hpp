@@ -11,6 +11,16 @@ constexpr int kModeStrict = 0;
 constexpr int kModeF16Taps = 1;
 constexpr int kModeFast = 2;
 
+// Window samples per stage-1 chunk (one scalar-load wait per chunk) of the specialised kernels, and the dwords of a
+// chunk's run in the tap table: CH x (l/2) branch pairs, then the odd branch's taps of the chunk's two samples —
+// 26 = 16 + 8 + 2 dwords, three scalar loads.  Host (table builder) and device agree through these.
+// (Three-sample chunks — 40 dwords, 80 pinned SGPRs — would give the fast and the 96 kHz kernels the cover their
+// scalar loads lack, and were tried: with 80 of the 102 SGPRs pinned the register allocator splits the live range of
+// a tap tuple BETWEEN its load and its wait, i.e. copies registers whose load is still in flight.  Two-sample chunks
+// leave it no reason to; tools/isa_lint.py checks every build for exactly that.)
+constexpr int fused_chunk(int /*m*/, int /*mode*/) { return 2; }
+constexpr int fused_chunk_dwords(int l, int ch) { return ch == 2 ? 4 * (l / 2) + 2 : 6 * (l / 2) + 4; }
+
 // arguments of one launch: the recordings of one call (see CallArgs / SlotPtrs in apt_kernels.hpp)
 struct FusedLaunch {
     hipStream_t s;

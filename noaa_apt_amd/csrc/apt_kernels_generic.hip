@@ -349,15 +349,16 @@ __device__ __forceinline__ void gather_rows_body(const float *__restrict__ f, co
                                                  Result *__restrict__ res, uint32_t spr, uint32_t pw, int raw,
                                                  float *__restrict__ rows, uint32_t rows_cap)
 {
-    uint32_t n_rows = res->n_rows;
+    // (relaxed atomics on both sides: one thread of this launch may lower the count while the others read it —
+    // every reader takes the same minimum whichever value it sees, and the accesses are not a data race)
+    uint32_t n_rows = __hip_atomic_load(&res->n_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t px_per_row = spr / pw;  // 2080 when pw = work_rate / 4160
     if (n_rows > rows_cap) {
         // the caller's buffer holds fewer rows than the recording has: the record reports what
         // was written (reason 4), so a caller that trusts n_out never reads past its buffer.
-        // Every thread takes the same minimum, so the racing update below is benign.
         n_rows = rows_cap;
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-            res->n_rows = rows_cap;
+            __hip_atomic_store(&res->n_rows, rows_cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             res->n_out = static_cast<uint64_t>(rows_cap) * px_per_row;
             res->reason = 4;
         }

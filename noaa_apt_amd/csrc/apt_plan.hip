@@ -295,7 +295,9 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     }
     if (plan->fused == 1) {
         const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
-        Signal hs(static_cast<size_t>(gpu::fused_tap_table_floats(plan->l, plan->m, t1)) + 16, 0.f);
+        // (the kernel that will read it: fast plans run the fast instantiation, whose chunks may differ)
+        const int ch = gpu::fused_chunk_of(plan->m, plan->fused_fast);
+        Signal hs(static_cast<size_t>(gpu::fused_tap_table_floats(plan->l, plan->m, t1, ch)) + 16, 0.f);
         if (plan->fused_f16) {
             // same buffer, different content: half2 tap pairs as raw dwords
             std::vector<uint32_t> tab(gpu::fused_f16_table_dwords(plan->l, plan->m, t1) + 16, 0u);
@@ -303,7 +305,7 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
             hs.assign(tab.size(), 0.f);
             std::memcpy(hs.data(), tab.data(), tab.size() * sizeof(uint32_t));
         } else {
-            gpu::fused_branch_taps(plan->l, plan->m, plan->taps_resample.data(), t1, hs.data());
+            gpu::fused_branch_taps(plan->l, plan->m, plan->taps_resample.data(), t1, ch, hs.data());
         }
         upload(plan->d_taps_branch, hs);
         Signal h2p(2 * (plan->taps_lowpass.size() + 1) + 16, 0.f);
