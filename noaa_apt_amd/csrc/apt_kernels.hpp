@@ -65,7 +65,7 @@ struct RecArgs {
 };
 struct CallArgs {
     uint32_t count;
-    uint32_t reserved;
+    uint32_t tiles_x;  // persistent front end only: tiles of the call's longest recording (else 0)
     RecArgs rec[kMaxCall];
 };
 struct SlotPtrs {

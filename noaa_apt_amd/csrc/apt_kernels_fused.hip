@@ -187,10 +187,10 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
                 const char *e = std::getenv("APTGPU_PROBE_STOP");
                 return e ? std::atoi(e) : 0;
             }();
-            if (!pcm16 && probe >= 1 && probe <= 8) {
-                void (*const fn[8])(const FusedLaunch &) = {fused_launch_probe1, fused_launch_probe2, fused_launch_probe3,
+            if (!pcm16 && probe >= 1 && probe <= 9) {
+                void (*const fn[9])(const FusedLaunch &) = {fused_launch_probe1, fused_launch_probe2, fused_launch_probe3,
                                                             fused_launch_probe4, fused_launch_probe5, fused_launch_probe6,
-                                                            fused_launch_probe7, fused_launch_probe8};
+                                                            fused_launch_probe7, fused_launch_probe8, fused_launch_probe9};
                 fn[probe - 1](a);
             } else
 #endif
@@ -204,9 +204,9 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
                 const char *e = std::getenv("APTGPU_PROBE_STOP");
                 return e ? std::atoi(e) : 0;
             }();
-            if (!pcm16 && sprobe >= 11 && sprobe <= 16) {
-                void (*const fn[6])(const FusedLaunch &) = {fused_launch_probe11, fused_launch_probe12, fused_launch_probe13,
-                                                            fused_launch_probe14, fused_launch_probe15, fused_launch_probe16};
+            if (!pcm16 && sprobe >= 11 && sprobe <= 17) {
+                void (*const fn[7])(const FusedLaunch &) = {fused_launch_probe11, fused_launch_probe12, fused_launch_probe13,
+                                                            fused_launch_probe14, fused_launch_probe15, fused_launch_probe16, fused_launch_probe17};
                 fn[sprobe - 11](a);
             } else
 #endif

@@ -17,6 +17,24 @@
 
 #pragma clang fp contract(off)
 
+// clobber lists of the pinned tap tuples (stage 1 of k_fused)
+#define APT_S1(n) "s" #n
+#define APT_S8_(a, b, c, d, e, f, g, h) APT_S1(a), APT_S1(b), APT_S1(c), APT_S1(d), APT_S1(e), APT_S1(f), APT_S1(g), APT_S1(h)
+#define APT_S8(n) APT_S8_X(n)
+#define APT_S16(n) APT_S16_X(n)
+// (the preprocessor cannot add: the tuples in use are spelled out)
+#define APT_S8_X(n) APT_S8_##n
+#define APT_S16_X(n) APT_S16_##n
+#define APT_S8_52 APT_S8_(52, 53, 54, 55, 56, 57, 58, 59)
+#define APT_S8_68 APT_S8_(68, 69, 70, 71, 72, 73, 74, 75)
+#define APT_S8_76 APT_S8_(76, 77, 78, 79, 80, 81, 82, 83)
+#define APT_S8_92 APT_S8_(92, 93, 94, 95, 96, 97, 98, 99)
+#define APT_S16_20 APT_S8_(20, 21, 22, 23, 24, 25, 26, 27), APT_S8_(28, 29, 30, 31, 32, 33, 34, 35)
+#define APT_S16_36 APT_S8_(36, 37, 38, 39, 40, 41, 42, 43), APT_S8_(44, 45, 46, 47, 48, 49, 50, 51)
+#define APT_S16_52 APT_S8_(52, 53, 54, 55, 56, 57, 58, 59), APT_S8_(60, 61, 62, 63, 64, 65, 66, 67)
+#define APT_S16_60 APT_S8_(60, 61, 62, 63, 64, 65, 66, 67), APT_S8_(68, 69, 70, 71, 72, 73, 74, 75)
+#define APT_S16_76 APT_S8_(76, 77, 78, 79, 80, 81, 82, 83), APT_S8_(84, 85, 86, 87, 88, 89, 90, 91)
+
 namespace apt::gpu {
 
 namespace {
@@ -29,6 +47,9 @@ namespace {
 #endif
 #ifndef APT_FUSED_MIN_WAVES
 #define APT_FUSED_MIN_WAVES 3
+#endif
+#ifndef APT_FUSED_PERSIST
+#define APT_FUSED_PERSIST 0
 #endif
 constexpr int kPreThreads = 4;    // pre-halo threads (low-pass + envelope history)
 constexpr int kPostThreads = 12;  // post-halo threads (correlation look-ahead)
@@ -245,7 +266,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     };
 
     // ---- one tile through the four stages
-    auto run_tile = [&](uint32_t ri, int64_t tile, XReg (&xr)[NXR]) {
+    auto run_tile = [&](uint32_t ri, int64_t tile, XReg (&xr)[NXR], auto &&after_tile_in_lds) {
     // (field by field: only what the stages below need is loaded, and the output pointers are
     // fetched from the slot table after stage 3)
     const uint64_t w = call.rec[ri].w;
@@ -616,10 +637,10 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         // kModeFast runs the same pipeline with one v_pk_fma_f32 per tap pair instead of a
         // v_pk_mul_f32 + v_pk_add_f32 (half the VALU instructions under the same tap loads).
         constexpr int CH = fused_chunk(M, MODE);
-        static_assert(CH == 2, "two window samples per chunk (apt_kernels_fused_launch.hpp says why not three)");
+        static_assert(CH == 2 || CH == 3, "two or three window samples per chunk");
         constexpr int NCH = (Gm::WIN + CH - 1) / CH;
         constexpr int CHW = fused_chunk_dwords(L, CH);  // 26: 16 + 8 + 2 dwords; 40: 16 + 16 + 8
-        static_assert(CHW == 26, "three scalar loads per chunk: 16 + 8 + 2 dwords");
+        static_assert(CHW == (CH == 2 ? 26 : 40), "three scalar loads per chunk: 16 + 8 + 2 / 16 + 16 + 8 dwords");
         auto xsrc = [&](int q) -> float {
             if constexpr (sizeof(XT) == 2) return static_cast<float>(reinterpret_cast<const int16_t *>(lds)[tid * M + q]);
             else return P[tid * M + q];
@@ -662,23 +683,31 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         auto issue = [&](auto cc) {
             constexpr int c = decltype(cc)::value;
             constexpr int buf = c & 1;
-            // (asm operands do not capture: name the registers through references first.  The tap registers are
-            // pinned, the two buffers side by side: left to itself the allocator put both buffers of
-            // the last piece into one register pair and spilled it to VGPR lanes in every chunk)
-            u16s &ra = ta[buf];
-            TB &rb = tb[buf];
-            TC &rc = tc[buf];
+            // The loads name their destination tuples in the assembly text and declare them clobbered — NOT as outputs:
+            // a value that flowed from here to the wait would be one the register allocator may copy or spill in
+            // between (it did, with three-sample chunks), i.e. while the load is in flight.  The taps become values
+            // at the wait (its outputs).  What remains possible — a compiler temporary placed in a tuple between load
+            // and wait — is what tools/isa_lint.py checks every listing for.
             const cf2_ptr hsp = hs;
-#define APT_TAP_LOADS "s_load_dwordx16 %0, %3, %4\n\ts_load_dwordx8 %1, %3, %5\n\ts_load_dwordx2 %2, %3, %6"
-            if constexpr (buf == 0)
-                asm volatile(APT_TAP_LOADS
-                             : "={s[36:51]}"(ra), "={s[68:75]}"(rb), "={s[84:85]}"(rc)
-                             : "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 96));
-            else
-                asm volatile(APT_TAP_LOADS
-                             : "={s[52:67]}"(ra), "={s[76:83]}"(rb), "={s[86:87]}"(rc)
-                             : "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 96));
-#undef APT_TAP_LOADS
+            if constexpr (CH == 2) {
+                if constexpr (buf == 0)
+                    asm volatile("s_load_dwordx16 s[36:51], %0, %1\n\ts_load_dwordx8 s[68:75], %0, %2\n\ts_load_dwordx2 s[84:85], %0, %3"
+                                 :: "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 96)
+                                 : APT_S16(36), APT_S8(68), "s84", "s85");
+                else
+                    asm volatile("s_load_dwordx16 s[52:67], %0, %1\n\ts_load_dwordx8 s[76:83], %0, %2\n\ts_load_dwordx2 s[86:87], %0, %3"
+                                 :: "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 96)
+                                 : APT_S16(52), APT_S8(76), "s86", "s87");
+            } else {
+                if constexpr (buf == 0)
+                    asm volatile("s_load_dwordx16 s[20:35], %0, %1\n\ts_load_dwordx16 s[36:51], %0, %2\n\ts_load_dwordx8 s[52:59], %0, %3"
+                                 :: "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 128)
+                                 : APT_S16(20), APT_S16(36), APT_S8(52));
+                else
+                    asm volatile("s_load_dwordx16 s[60:75], %0, %1\n\ts_load_dwordx16 s[76:91], %0, %2\n\ts_load_dwordx8 s[92:99], %0, %3"
+                                 :: "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 128)
+                                 : APT_S16(60), APT_S16(76), APT_S8(92));
+            }
             // the read groups chunk c touches that no earlier chunk has fetched
             static_for<g_hi(c - 1) + 1, g_hi(c) + 1>([&](auto gg) { read_group(gg); });
         };
@@ -701,8 +730,14 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             else if constexpr (nnew == 1) asm volatile("s_waitcnt lgkmcnt(0)" : REGS, "+v"(x0));                   \
             else asm volatile("s_waitcnt lgkmcnt(0)" : REGS, "+v"(x0), "+v"(x1));
 #define APT_COMMA ,
-            if constexpr (buf == 0) { APT_WAIT("+{s[36:51]}"(ra) APT_COMMA "+{s[68:75]}"(rb) APT_COMMA "+{s[84:85]}"(rc)) }
-            else { APT_WAIT("+{s[52:67]}"(ra) APT_COMMA "+{s[76:83]}"(rb) APT_COMMA "+{s[86:87]}"(rc)) }
+            // (pure outputs: the taps of this buffer exist as values from here on)
+            if constexpr (CH == 2) {
+                if constexpr (buf == 0) { APT_WAIT("={s[36:51]}"(ra) APT_COMMA "={s[68:75]}"(rb) APT_COMMA "={s[84:85]}"(rc)) }
+                else { APT_WAIT("={s[52:67]}"(ra) APT_COMMA "={s[76:83]}"(rb) APT_COMMA "={s[86:87]}"(rc)) }
+            } else {
+                if constexpr (buf == 0) { APT_WAIT("={s[20:35]}"(ra) APT_COMMA "={s[36:51]}"(rb) APT_COMMA "={s[52:59]}"(rc)) }
+                else { APT_WAIT("={s[60:75]}"(ra) APT_COMMA "={s[76:91]}"(rb) APT_COMMA "={s[92:99]}"(rc)) }
+            }
 #undef APT_WAIT
 #undef APT_COMMA
         };
@@ -878,6 +913,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 #pragma unroll
     for (int b = 0; b < L; ++b) P[tid * L + b] = r[b];
     __syncthreads();
+    after_tile_in_lds();  // (persistent form: the NEXT tile's loads, in flight under stages 2 to 4)
     }  // !TABLE
 
     if constexpr (APT_FUSED_STOP == 2) return;
@@ -1302,11 +1338,52 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     };  // run_tile
 
     XReg xr[NXR];
+#if APT_FUSED_PERSIST
+    if constexpr (!Gm::TABLE) {
+        // Persistent form (experiment, probe builds): a fixed grid walks the (recording, tile) pairs of the call; the next
+        // tile's input is requested right after this tile's has been written to LDS — into the same registers — and is
+        // in flight under the four stages.
+        const uint32_t tiles_x = call.tiles_x;  // tiles of the longest recording (what the plain form's grid.x is)
+        const uint32_t total = tiles_x * call.count;
+        // first (recording, tile) pair at or after `from`, in steps of the grid, whose tile exists (wave-uniform)
+        auto first = [&](uint32_t from, uint32_t *r, int64_t *t, uint32_t *at) -> bool {
+            for (uint32_t q = from; q < total; q += gridDim.x) {
+                const uint32_t rr = q / tiles_x;
+                const uint32_t tt = q - rr * tiles_x;
+                if (static_cast<uint64_t>(tt) * Gm::OWN_K < call.rec[rr].w) {
+                    *r = rr;
+                    *t = static_cast<int64_t>(tt);
+                    *at = q;
+                    return true;
+                }
+            }
+            return false;
+        };
+        uint32_t ri = 0, ri2 = 0, at = 0;
+        int64_t tile = 0, tile2 = 0;
+        if (!first(blockIdx.x, &ri, &tile, &at)) return;
+        load_tile(ri, tile, xr);
+        while (true) {
+            uint32_t at2 = 0;
+            const bool more = first(at + gridDim.x, &ri2, &tile2, &at2);
+            run_tile(ri, tile, xr, [&] {
+                if (more) load_tile(ri2, tile2, xr);
+            });
+            if (!more) break;
+            ri = ri2;
+            tile = tile2;
+            at = at2;
+            __syncthreads();  // the slowest wave is done with this tile's LDS before the next tile lands on it
+        }
+    } else
+#endif
+    {
     const uint32_t ri = blockIdx.y;
     const int64_t tile = blockIdx.x;
     if (static_cast<uint64_t>(tile) * Gm::OWN_K >= call.rec[ri].w) return;
     if constexpr (!Gm::TABLE) load_tile(ri, tile, xr);
-    run_tile(ri, tile, xr);
+    run_tile(ri, tile, xr, [] {});
+    }
 #undef call
 }
 
@@ -1337,6 +1414,19 @@ void launch_fused_args(const FusedLaunch &a)
     constexpr auto kern = k_fused<L, M, T1, T2, PW, NTHR, XT, MODE>;
     ensure_dynamic_lds<kern>(lds);
     const unsigned tiles = static_cast<unsigned>((a.max_w + Gm::OWN_K - 1) / Gm::OWN_K);
+#if APT_FUSED_PERSIST
+    if constexpr (!Gm::TABLE) {
+        CallArgs c = *a.call;
+        c.tiles_x = tiles;
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const uint64_t total = static_cast<uint64_t>(tiles) * c.count;  // (< 2^32: kMaxCall recordings of < 2^26 tiles)
+        const unsigned wgs = static_cast<unsigned>(std::min<uint64_t>(total, static_cast<uint64_t>(cus) * APT_FUSED_MIN_WAVES));
+        hipLaunchKernelGGL(kern, dim3(wgs), dim3(NTHR), lds, a.s, c, a.prm);
+        return;
+    }
+#endif
     hipLaunchKernelGGL(kern, dim3(tiles, a.call->count), dim3(NTHR), lds, a.s, *a.call, a.prm);
 }
 

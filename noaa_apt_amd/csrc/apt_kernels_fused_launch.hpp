@@ -12,13 +12,19 @@ constexpr int kModeF16Taps = 1;
 constexpr int kModeFast = 2;
 
 // Window samples per stage-1 chunk (one scalar-load wait per chunk) of the specialised kernels, and the dwords of a
-// chunk's run in the tap table: CH x (l/2) branch pairs, then the odd branch's taps of the chunk's two samples —
-// 26 = 16 + 8 + 2 dwords, three scalar loads.  Host (table builder) and device agree through these.
-// (Three-sample chunks — 40 dwords, 80 pinned SGPRs — would give the fast and the 96 kHz kernels the cover their
-// scalar loads lack, and were tried: with 80 of the 102 SGPRs pinned the register allocator splits the live range of
-// a tap tuple BETWEEN its load and its wait, i.e. copies registers whose load is still in flight.  Two-sample chunks
-// leave it no reason to; tools/isa_lint.py checks every build for exactly that.)
-constexpr int fused_chunk(int /*m*/, int /*mode*/) { return 2; }
+// chunk's run in the tap table: CH x (l/2) branch pairs, then the odd branch's taps of the chunk — those of its
+// aligned sample pair (q even, q + 1) first, then (CH == 3) that of the sample left over — padded so that three scalar
+// loads fetch it (26 = 16 + 8 + 2 dwords; 40 = 16 + 16 + 8).  Host (table builder) and device agree through these.
+// Three-sample chunks (80 pinned SGPRs) give the 96 kHz kernels — 1.5 waves per SIMD, bound by the scalar cache's
+// latency — half as much cover again per wait: config 3 in fast mode 0.709 -> 0.631 ms per recording, strict 0.660 -> 0.654.
+constexpr int fused_chunk(int m, int mode)
+{
+#ifdef APT_FUSED_CH_ALL
+    return APT_FUSED_CH_ALL;
+#else
+    return m >= 100 ? 3 : 2;  // (48 kHz fast mode: measured 3 % slower with three)
+#endif
+}
 constexpr int fused_chunk_dwords(int l, int ch) { return ch == 2 ? 4 * (l / 2) + 2 : 6 * (l / 2) + 4; }
 
 // arguments of one launch: the recordings of one call (see CallArgs / SlotPtrs in apt_kernels.hpp)
@@ -74,6 +80,8 @@ void fused_launch_probe14(const FusedLaunch &a);
 void fused_launch_probe15(const FusedLaunch &a);
 void fused_launch_probe16(const FusedLaunch &a);  // strict, complete, no HBM reads
 void fused_launch_probe8(const FusedLaunch &a);   // fast, complete, no HBM reads
+void fused_launch_probe9(const FusedLaunch &a);   // fast, persistent with register prefetch
+void fused_launch_probe17(const FusedLaunch &a);  // strict, persistent with register prefetch
 #endif
 
 }  // namespace apt::gpu
