@@ -622,15 +622,25 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
                 });
             }
         } else {
+            // (APTGPU_DEBUG_SKIP, a bit mask — 1 words + slots, 2 orbit, 4 gather: timing experiments only, the results
+            // are then garbage: what each kernel behind the front end costs a pipelined step)
+            static const int skip = [] {
+                const char *e = std::getenv("APTGPU_DEBUG_SKIP");
+                return e ? std::atoi(e) : 0;
+            }();
             for_chunks(live, [&](const CallArgs &c, uint64_t max_w, uint32_t) {
-                timed("sync_nodes", [&] { sync_nodes(cur, c, d_slots.ptr, max_w, pw, spr, md, use_fused && fused_fast, !use_fused); });
-                timed("sync_orbit", [&] { sync_orbit(cur, c, d_slots.ptr, spr, md, pw, picker_force); });
+                if (!(skip & 1))
+                    timed("sync_nodes", [&] { sync_nodes(cur, c, d_slots.ptr, max_w, pw, spr, md, use_fused && fused_fast, !use_fused); });
+                if (!(skip & 2))
+                    timed("sync_orbit", [&] { sync_orbit(cur, c, d_slots.ptr, spr, md, pw, picker_force); });
             });
+            if (skip & 4) goto chain_done;
         }
         // 5. aligned rows + final /pw (decode.rs:120-134,158-159)
         for_chunks(live, [&](const CallArgs &c, uint64_t, uint32_t max_cap) {
             timed("gather_rows", [&] { gather_rows_call(cur, c, d_slots.ptr, spr, pw, max_cap); });
         });
+    chain_done:;
     } else {
         // decode.rs:135-159 — crop to whole rows, resample_with_filter(NoFilter)
         for (int i : live) {
