@@ -34,6 +34,23 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 achievable)
 
 
+class _QuietStdout:
+    """Rank 0 prints ONE JSON line on stdout — and nothing else may: RCCL's version banner and gloo's connection
+    notice are written to file descriptor 1 by native code.  Everything between construction and emit() goes to
+    stderr instead."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, text):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        print(text, flush=True)
+        os.dup2(2, 1)
+
+
 def config4_recordings(count, rate=48000, seconds=900.0, distinct=4):
     """The recording list of BASELINE config 4: `count` independent 15-minute recordings, seeds
     1000..., per-recording sample-rate error uniform in +-50 ppm and a random start phase so that lengths and sync
@@ -62,6 +79,7 @@ def config4_recordings(count, rate=48000, seconds=900.0, distinct=4):
 
 def run_config4(args):
     """bench.py --config4: see the argument's help.  One JSON line on rank 0."""
+    out = _QuietStdout()
     import torch
     import noaa_apt_amd as apt
     from noaa_apt_amd import shard
@@ -172,7 +190,7 @@ def run_config4(args):
                     "extrapolated.",
             "per_device": per_device,
         }
-        print(json.dumps(line))
+        out.emit(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -220,6 +238,7 @@ def main():
     if args.config4:
         return run_config4(args)
 
+    out = _QuietStdout()
     import torch
     import noaa_apt_amd as apt
     from noaa_apt_amd.testing.synth import synth_apt
@@ -729,7 +748,7 @@ def main():
                     f"rows {'equal' if same_shape else 'DIFFER'} in count, sync positions identical "
                     f"{float((off == 0).mean()):.5f} (max off {int(off.max(initial=0))}), max |err| / max |px| = {ferr:.2e} "
                     f"(tolerance 1e-4): {'within' if ok else 'OUTSIDE'} tolerance")
-        print(json.dumps(line), flush=True)
+        out.emit(json.dumps(line))
     plan.close()
     if dist is not None:
         dist.barrier()
