@@ -79,7 +79,7 @@ def config4_recordings(count, rate=48000, seconds=900.0, distinct=4):
 
 def run_config4(args):
     """bench.py --config4: see the argument's help.  One JSON line on rank 0."""
-    out = _QuietStdout()
+    json_out = _QuietStdout()
     import torch
     import noaa_apt_amd as apt
     from noaa_apt_amd import shard
@@ -190,7 +190,7 @@ def run_config4(args):
                     "extrapolated.",
             "per_device": per_device,
         }
-        out.emit(json.dumps(line))
+        json_out.emit(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -238,7 +238,7 @@ def main():
     if args.config4:
         return run_config4(args)
 
-    out = _QuietStdout()
+    json_out = _QuietStdout()
     import torch
     import noaa_apt_amd as apt
     from noaa_apt_amd.testing.synth import synth_apt
@@ -748,7 +748,7 @@ def main():
                     f"rows {'equal' if same_shape else 'DIFFER'} in count, sync positions identical "
                     f"{float((off == 0).mean()):.5f} (max off {int(off.max(initial=0))}), max |err| / max |px| = {ferr:.2e} "
                     f"(tolerance 1e-4): {'within' if ok else 'OUTSIDE'} tolerance")
-        out.emit(json.dumps(line))
+        json_out.emit(json.dumps(line))
     plan.close()
     if dist is not None:
         dist.barrier()

@@ -40,6 +40,16 @@ namespace apt::gpu {
 namespace {
 
 
+// Listing marks (tools/isa.sh -DAPT_FUSED_MARKS=1, tools/isa_budget.py --marks): comments in the assembly around the
+// code an INTERIOR tile of the specialised kernels executes, so that the per-stage instruction budget can be read off
+// a listing without following its branches by hand.  Never defined in a product build (an asm statement is a
+// scheduling fence).
+#ifdef APT_FUSED_MARKS
+#define APT_MARK(name) asm volatile("; APTMARK " name)
+#else
+#define APT_MARK(name) ((void)0)
+#endif
+
 // Probe builds (apt_kernels_fused_probe*.hip, timing experiments only): the kernel stops after stage
 // APT_FUSED_STOP — 1 tile in LDS, 2 resampler, 3 envelope, 4 low-pass, 5 F stored; 0 = the real kernel.
 #ifndef APT_FUSED_STOP
@@ -54,6 +64,17 @@ namespace {
 constexpr int kPreThreads = 4;    // pre-halo threads (low-pass + envelope history)
 constexpr int kPostThreads = 12;  // post-halo threads (correlation look-ahead)
 constexpr float kNegInfF = -__builtin_huge_valf();
+
+// max(a, b, c) of values that are results of floating-point additions (never signalling NaNs), a quiet NaN
+// counting as absent — fmaxf's semantics on such inputs — as ONE v_max3_f32.  The compiler cannot see where the
+// values come from once they have been through LDS or a select and canonicalises every operand of an fmaxf first
+// (v_max_f32 x, x, x): 25 instructions for the 13 + 12 values of stage 4's maxima.
+__device__ __forceinline__ float max3_of_sums(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F &&f)
@@ -129,6 +150,8 @@ __host__ __device__ constexpr int first_branch_of_pair(int c)
 }
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
 // The tap tables and the slot table are never written while a decode runs: pointers fetched from the
 // parameter block are cast to the constant address space, which is what makes the (wave-uniform)
 // reads of them scalar loads — a generic pointer loaded from memory would turn every tap read
@@ -207,7 +230,27 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     float *P = lds;                  // x tile -> R -> F
     float *Q = lds + Gm::D_OFF;      // D (inside the dead part of the x tile), later the pulse sums (fast mode)
     const int tid = threadIdx.x;
+    __builtin_assume(tid >= 0 && tid < NTHR);  // (the compiler only knows < 1024: it kept three always-true guards of tile loads)
+    // A (wave-uniform) 64-bit offset clamped to +-2^30, in scalar instructions.  Written in C++ the compiler
+    // evaluates it with VALU instructions (v_cmp_lt_i64, v_med3_i32, v_readfirstlane: there is no scalar 64-bit
+    // signed compare and no scalar med3) — a dozen issue slots per tile for five uniform numbers.
     auto rel = [](int64_t v) -> int { return v < -(1 << 30) ? -(1 << 30) : (v > (1 << 30) ? (1 << 30) : static_cast<int>(v)); };
+    auto rel_u = [&](int64_t v) -> int {  // v wave-uniform
+        if constexpr (Gm::TABLE) return rel(v);
+        const int32_t hi = static_cast<int32_t>(v >> 32), lo = static_cast<int32_t>(static_cast<uint32_t>(v));
+        int32_t r, t;
+        asm("s_ashr_i32 %0, %3, 31\n\t"          // sign of v
+            "s_xor_b32 %0, %0, 0x7fffffff\n\t"   // -> INT_MAX / INT_MIN: v saturated to 32 bits
+            "s_ashr_i32 %1, %2, 31\n\t"
+            "s_cmp_eq_u32 %1, %3\n\t"            // v fits 32 bits?
+            "s_cselect_b32 %0, %2, %0\n\t"
+            "s_max_i32 %0, %0, 0xc0000000\n\t"
+            "s_min_i32 %0, %0, 0x40000000"
+            : "=&s"(r), "=&s"(t)
+            : "s"(lo), "s"(hi)
+            : "scc");
+        return r;
+    };
 
     // ---- stage 0a: a tile's input -> registers (coalesced 16-byte loads, zero outside [0, n));
     // f32: 4 samples per register quad, PCM16: 4 samples per register pair
@@ -218,11 +261,19 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         const uint64_t n = call.rec[ri].n;
         const int64_t k0 = tile * Gm::OWN_K - Gm::PRE_K;   // first work sample of the tile (< 0 in tile 0)
         const int64_t xs0 = (k0 / L) * M;                  // first input sample of the tile
-        const int x_lo = rel(-xs0);                               // tile index of input sample 0
-        const int x_hi = rel(static_cast<int64_t>(n) - xs0);      // tile index of input sample n
+        const int x_lo = rel_u(-xs0);                               // tile index of input sample 0
+        const int x_hi = rel_u(static_cast<int64_t>(n) - xs0);      // tile index of input sample n
         const XT *xt = x + xs0;  // only dereferenced inside [x_lo, x_hi)
         if (x_lo <= 0 && x_hi >= Gm::XT_PAD) {
-            // interior tile (wave-uniform): every load is a whole, unguarded 16 / 8 bytes
+            // interior tile (wave-uniform): every load is a whole, unguarded 16 / 8 bytes.  The address is a scalar
+            // base, advanced per load in scalar registers (the empty asm keeps the compiler from folding the steps
+            // back into one base + constants, which it then adds per lane: a 64-bit VALU add pair per load), plus
+            // the lane's 32-bit byte offset.  Registers of lanes beyond the tile's end stay undefined:
+            // tile_to_lds applies the same guard.
+            APT_MARK("BEGIN load");
+            typedef const char __attribute__((address_space(1))) *gchar_ptr;  // (global, not flat, after the asm)
+            gchar_ptr sb = (gchar_ptr)(xt);
+            const uint32_t voff = static_cast<uint32_t>(tid) * static_cast<uint32_t>(sizeof(XReg));
 #pragma unroll
             for (int e = 0; e < NXR; ++e) {
                 const int q = (tid + e * kFusedThreads) * 4;
@@ -230,13 +281,22 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 #ifdef APT_FUSED_NOLOAD  // timing probe: the kernel without its HBM reads (synthetic tile contents)
                     xr[e] = make_float4(1000.f + q, 900.f - q, 800.f + (q & 255), 700.f - (q & 127));
 #else
-                    xr[e] = (q < Gm::XT_PAD) ? *reinterpret_cast<const float4 *>(xt + q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (q < Gm::XT_PAD) {
+                        const f4 v = *(const f4 __attribute__((address_space(1))) *)(sb + voff);
+                        xr[e] = make_float4(v.x, v.y, v.z, v.w);
+                    }
 #endif
                 } else {
                     // PCM16: x is 4-byte aligned and xs0, q are even, so sample pairs move as dwords
-                    xr[e] = (q < Gm::XT_PAD) ? *reinterpret_cast<const uint2 *>(xt + q) : make_uint2(0u, 0u);
+                    if (q < Gm::XT_PAD) {
+                        const u2 v = *(const u2 __attribute__((address_space(1))) *)(sb + voff);
+                        xr[e] = make_uint2(v.x, v.y);
+                    }
                 }
+                sb += kFusedThreads * sizeof(XReg);
+                asm volatile("" : "+s"(sb));
             }
+            APT_MARK("END load");
         } else {
             // first / last tiles of a recording: sample by sample, zero outside [0, n)
 #pragma unroll
@@ -255,6 +315,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     // ---- stage 0b: registers -> LDS (PCM16: the tile stays int16 in LDS; `*x as f32` happens when
     // stage 1 reads it)
     auto tile_to_lds = [&](const XReg (&xr)[NXR]) {
+        APT_MARK("BEGIN to_lds");
 #pragma unroll
         for (int e = 0; e < NXR; ++e) {
             const int q = (tid + e * kFusedThreads) * 4;
@@ -263,21 +324,23 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 else *reinterpret_cast<uint2 *>(reinterpret_cast<uint32_t *>(lds) + q / 2) = xr[e];
             }
         }
+        APT_MARK("END to_lds");
     };
 
     // ---- one tile through the four stages
     auto run_tile = [&](uint32_t ri, int64_t tile, XReg (&xr)[NXR], auto &&after_tile_in_lds) {
     // (field by field: only what the stages below need is loaded, and the output pointers are
     // fetched from the slot table after stage 3)
+    APT_MARK("BEGIN tile_prologue");
     const uint64_t w = call.rec[ri].w;
     const uint64_t n_corr = w - Gm::G;  // w >= 10 rows of samples > G (checked on the host)
     const int64_t o0 = tile * Gm::OWN_K;            // first owned work sample
     const int64_t k0 = o0 - Gm::PRE_K;              // first work sample of the tile (< 0 in tile 0)
     // everything below indexes relative to the tile with 32-bit integers; the global limits
     // become wave-uniform scalars
-    const int k_lo = rel(-k0);                                    // tile index of work sample 0
-    const int k_hi = rel(static_cast<int64_t>(w) - k0);           // tile index of work sample w
-    const int c_hi = rel(static_cast<int64_t>(n_corr) - k0);      // tile index of position n_corr
+    const int k_lo = rel_u(-k0);                                    // tile index of work sample 0
+    const int k_hi = rel_u(static_cast<int64_t>(w) - k0);           // tile index of work sample w
+    const int c_hi = rel_u(static_cast<int64_t>(n_corr) - k0);      // tile index of position n_corr
     const int kq = tid * L;        // this thread's first work sample, tile-relative
     const int kt = kq - k_lo;      // ... and as a global work-sample index clamped to int
     // Interior tile (wave-uniform; all but the first and the last two tiles of a recording): every work
@@ -285,6 +348,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     // stages below (a v_cmp + v_cndmask each, ~200 per thread) are compiled out of the copies of the
     // small loops that interior tiles run.
     const bool interior = k_lo < 0 && c_hi >= Gm::TILE_K;
+    APT_MARK("END tile_prologue");
     float r[L];
     if constexpr (Gm::PHASE) {
         // ---- stages 0 + 1, taps of the thread's polyphase branch in registers (dsp.rs:252-263):
@@ -562,6 +626,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     tile_to_lds(xr);
     __syncthreads();
     if constexpr (APT_FUSED_STOP == 1) return;
+    APT_MARK("BEGIN stage1");
 
     // ---- stage 1: polyphase resampler, L outputs per thread (dsp.rs:252-263)
     // Sample-stationary form: window sample q is broadcast (op_sel) against a PAIR of taps
@@ -903,12 +968,14 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             r[2 * pp + 1] = acc[pp].y;
         }
         if constexpr (L & 1) r[L - 1] = accl;
+        APT_MARK("END stage1");
         if (!interior) {
 #pragma unroll
             for (int b = 0; b < L; ++b)
                 if (kq + b < k_lo || kq + b >= k_hi) r[b] = 0.f;
         }
     }
+    APT_MARK("BEGIN r_store");
     __syncthreads();  // everyone is done reading the x tile
 #pragma unroll
     for (int b = 0; b < L; ++b) P[tid * L + b] = r[b];
@@ -928,6 +995,8 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     typedef const SlotPtrs APT_CONST_AS *cslot_ptr;
     const cslot_ptr slots = (cslot_ptr)(late->slots);
     const int want_gm = late->want_gm;
+    const float gm_slack = late->gm_slack;  // (now: the pointer pair otherwise stays live, and is spilled, across stage 3)
+    APT_MARK("END r_store");
 
     // ---- stage 2: AM envelope from consecutive samples (dsp.rs:369-377)
     auto envelope = [&](auto interior_tag) {
@@ -942,7 +1011,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 #pragma unroll
             for (int p2 = 0; p2 < (L + 1) / 2; ++p2) {
                 const f2 A = (f2){r[2 * p2], (2 * p2 + 1 < L) ? r[2 * p2 + 1] : r[2 * p2]};
-                const f2 S = (f2){p2 == 0 ? prev : r[2 * p2 - 1], r[2 * p2]};
+                const f2 S = p2 == 0 ? (f2){prev, r[0]} : (f2){P[tid * L + 2 * p2 - 1], P[tid * L + 2 * p2]};  // (see strict)
                 const f2 rad = __builtin_elementwise_fma(-(S * A), cos2, (S * S) + (A * A));
                 const f2 q = (f2){__builtin_amdgcn_sqrtf(rad.x), __builtin_amdgcn_sqrtf(rad.y)} * inv2;
                 Q[tid * L + 2 * p2] = q.x;
@@ -972,6 +1041,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             // Interior tile, two values per instruction: A[p] = (r[2p], r[2p+1]) are the stage-1 accumulator pairs,
             // S[p] = (r[2p-1], r[2p]) their predecessors; radicand = (prev^2 + curr^2) - (prev*curr)*cos2 in the
             // reference's order (envelope_radicand), element by element.
+            APT_MARK("BEGIN envelope_radicands");
             constexpr int NPE = (L + 1) / 2;
             f2 rad[NPE];
             uint32_t umin = 0xFFFFFFFFu, umax = 0u;
@@ -979,7 +1049,9 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 #pragma unroll
             for (int p2 = 0; p2 < NPE; ++p2) {
                 const f2 A = (f2){r[2 * p2], (2 * p2 + 1 < L) ? r[2 * p2 + 1] : r[2 * p2]};
-                const f2 S = (f2){p2 == 0 ? prev : r[2 * p2 - 1], r[2 * p2]};
+                // (the predecessor pairs straddle the accumulator pairs: read back from R in LDS — one two-address
+                // read each, no issue slot — where building them from the accumulators takes two v_mov_b32 apiece)
+                const f2 S = p2 == 0 ? (f2){prev, r[0]} : (f2){P[tid * L + 2 * p2 - 1], P[tid * L + 2 * p2]};
                 const f2 ss = (S * S) + (A * A);
                 const f2 cc = (S * A) * cos2;
                 rad[p2] = ss - cc;
@@ -992,9 +1064,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 umax = u1 > umax ? u1 : umax;
             }
             in_range = in_range && umin >= 0x0F800000u && umax <= 0x71800000u;
+            APT_MARK("END envelope_radicands");
             // wave-uniform choice: the exactly rounded fast path (apt_envelope.hpp) when every value
             // of the wave is in its range, the compiler's general sequences otherwise
             if (__all(in_range)) {
+                APT_MARK("BEGIN envelope_roots");
                 const f2 sin2 = (f2){sinv, sinv}, inv2 = (f2){invv, invv}, half2 = (f2){0.5f, 0.5f};
 #pragma unroll
                 for (int p2 = 0; p2 < NPE; ++p2) {
@@ -1011,6 +1085,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                     Q[tid * L + 2 * p2] = q.x;
                     if (2 * p2 + 1 < L) Q[tid * L + 2 * p2 + 1] = q.y;
                 }
+                APT_MARK("END envelope_roots");
             } else {
 #pragma unroll
                 for (int b = 0; b < L; ++b) {
@@ -1052,6 +1127,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     {
         const int base = tid * L - (T2 - 1);
         if (kt >= T2) {
+            // (the window's first word as one opaque register: the reads below then differ by immediate offsets
+            // only, where the compiler otherwise rebuilds "lane base + D_OFF + constant" with a v_add_u32 per read)
+            APT_MARK("BEGIN stage3");
+            int qofs = Gm::D_OFF + base;
+            asm volatile("" : "+v"(qofs));
             f2 fa[Gm::NP > 0 ? Gm::NP : 1];
             float fl = 0.f;
 #pragma unroll
@@ -1061,7 +1141,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 constexpr int hi = Gm::DW - 1 - decltype(cc)::value * CH3;  // walk qq downwards
                 float dv[CH3];
 #pragma unroll
-                for (int e = 0; e < CH3; ++e) dv[e] = (hi - e >= 0) ? Q[base + hi - e] : 0.f;
+                for (int e = 0; e < CH3; ++e) dv[e] = (hi - e >= 0) ? lds[qofs + hi - e] : 0.f;
                 static_for<0, CH3>([&](auto ee) {
                     constexpr int qq = hi - decltype(ee)::value;
                     if constexpr (qq >= 0) {
@@ -1128,6 +1208,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 f[2 * pp + 1] = fa[pp].y;
             }
             if constexpr (L & 1) f[L - 1] = fl;
+            APT_MARK("END stage3");
         } else {
             // first samples of the recording (tile 0 only): the reference's `i > j` guard
 #pragma unroll
@@ -1143,15 +1224,33 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             }
         }
     }
+    APT_MARK("BEGIN f_to_lds");
 #pragma unroll
     for (int b = 0; b < L; ++b) P[tid * L + b] = f[b];  // R is dead: P now holds F
     __syncthreads();
+    APT_MARK("END f_to_lds");
     if constexpr (APT_FUSED_STOP == 4) return;
     // owned F -> HBM, coalesced 16-byte stores
     uint32_t slot_late = call.rec[ri].slot;
     asm volatile("" : "+s"(slot_late));  // keeps the loads below from being hoisted above stage 1
     float *__restrict__ f_out = slots[slot_late].f;
-    {
+    if (interior) {
+        // every owned sample exists: whole 16-byte stores at a scalar base advanced in scalar registers plus the
+        // lane's 32-bit offset (as the tile loads), no per-lane 64-bit address arithmetic
+        APT_MARK("BEGIN f_store");
+        typedef char __attribute__((address_space(1))) *gchar_wptr;
+        typedef f4 __attribute__((address_space(1))) *gfloat4_wptr;
+        gchar_wptr sb = (gchar_wptr)(f_out + o0);
+        const uint32_t voff = static_cast<uint32_t>(tid) * 16u;
+#pragma unroll
+        for (int e = 0; e * kFusedThreads * 4 < Gm::OWN_K; ++e) {
+            const int q = (tid + e * kFusedThreads) * 4;
+            if (q < Gm::OWN_K) *(gfloat4_wptr)(sb + voff) = *reinterpret_cast<const f4 *>(P + Gm::PRE_K + q);
+            sb += kFusedThreads * 16;
+            asm volatile("" : "+s"(sb));
+        }
+        APT_MARK("END f_store");
+    } else {
         float *ft = f_out + o0;
         for (int q = tid * 4; q < Gm::OWN_K; q += kFusedThreads * 4) {
             if (Gm::PRE_K + q + 3 < k_hi) {
@@ -1186,23 +1285,37 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         static_assert(L == 13 && PUL == 6 && Gm::GS == 52, "the position remapping below is written for 13-sample threads and 6-sample pulses");
         float *AB = lds + Gm::D_OFF + Gm::TILE_K + 36 * PW;  // [NTHR] per-thread sums of |F|
         {
-            // pulse sums of the thread's own L positions -> Q (D is dead)
-            const float *src = P + tid * L;
-            float fw[L + PUL - 1];
+            APT_MARK("BEGIN pulse_sums");
+            // pulse sums of the thread's own L positions -> Q (D is dead).  B[p] = F[p] + ... + F[p + 2 PW - 1] as
+            // PW sums of neighbours b2[e] = F[e] + F[e + 1], two positions per instruction: the neighbour sums
+            // themselves are packed too — (b2[2p], b2[2p+1]) = (F[2p], F[2p+1]) + (F[2p+1], F[2p+2]) — with the
+            // thread's F window read TWICE from LDS, as even- and as odd-aligned pairs (a second two-address read
+            // costs no issue slot; through an offset the compiler cannot see through, or it rebuilds the second set
+            // of pairs from the first with a v_mov_b32 per value).
+            int fofs = tid * L;            // word offsets into lds (P = lds): the window, ...
+            int qofs4 = Gm::D_OFF + tid * L;  // ... and where the thread's pulse sums go (Q = lds + D_OFF)
+            int fofs_odd = fofs + 1;
+            asm volatile("" : "+v"(fofs), "+v"(fofs_odd), "+v"(qofs4));
+            constexpr int NFW = L + PUL - 1;           // 18 window values: F[0 .. 17]
+            constexpr int NB2 = (NFW + 1) / 2;         // 9 pairs of neighbour sums: b2[0 .. 17] (b2[17] unused garbage)
+            float fw[NFW];
+            f2 b2p[NB2];
 #pragma unroll
-            for (int e = 0; e < L + PUL - 1; ++e) fw[e] = src[e];  // (past the tile: unused garbage)
-            float b2[L + PUL - 1];
-#pragma unroll
-            for (int e = 0; e < L + PUL - 2; ++e) b2[e] = fw[e] + fw[e + 1];
-            b2[L + PUL - 2] = 0.f;
+            for (int p2 = 0; p2 < NB2; ++p2) {
+                const f2 ev = (f2){lds[fofs + 2 * p2], lds[fofs + 2 * p2 + 1]};           // (past the tile: unused garbage)
+                const f2 od = (f2){lds[fofs_odd + 2 * p2], lds[fofs_odd + 2 * p2 + 1]};
+                fw[2 * p2] = ev.x;
+                if (2 * p2 + 1 < NFW) fw[2 * p2 + 1] = ev.y;
+                b2p[p2] = ev + od;
+            }
             // (the sums of PW pairs two positions at a time: packed)
 #pragma unroll
             for (int b = 0; b < L; b += 2) {
-                f2 bs = (f2){b2[b], b2[b + 1]} + (f2){b2[b + 2], b2[b + 3]};
+                f2 bs = b2p[b / 2] + b2p[b / 2 + 1];
 #pragma unroll
-                for (int t = 2; t < PW; ++t) bs = bs + (f2){b2[b + 2 * t], b2[b + 2 * t + 1]};
-                Q[tid * L + b] = bs.x;
-                if (b + 1 < L) Q[tid * L + b + 1] = bs.y;
+                for (int t = 2; t < PW; ++t) bs = bs + b2p[b / 2 + t];
+                lds[qofs4 + b] = bs.x;
+                if (b + 1 < L) lds[qofs4 + b + 1] = bs.y;
             }
             if constexpr (!FAST) {
                 float a = 0.f;
@@ -1218,6 +1331,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             }
         }
         __syncthreads();  // pulse sums complete; F (region P) is dead from here on
+        APT_MARK("END pulse_sums");
         // ---- the correlation of the owned positions, REMAPPED: thread t = 6 blk + r takes the 13 positions
         // p_j = PRE_K + 78 blk + r + 6 j (one pulse apart), whose 19 pulse sums each are V[j + k] with
         // V[n] = B[p_0 + 6 n], n < 31: 31 LDS reads per thread where 13 CONSECUTIVE positions need a window of 121
@@ -1233,6 +1347,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         constexpr int NB6 = ((Gm::OWN_K + 6 * L - 1) / (6 * L)) * 6;  // threads with a block (the last may be partial)
         static_assert(NB6 <= NTHR, "one thread per block column");
         float *PMX = P;  // [groups][12]: partial maxima by group (6 from each of the two blocks that reach it, or -inf)
+        APT_MARK("BEGIN correlation");
         if (tid < NB6) {
             const uint32_t blk = static_cast<uint32_t>(tid) / 6u;
             const int rr = tid - static_cast<int>(blk) * 6;
@@ -1258,6 +1373,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 for (int j = 0; j < L; ++j) c[j] = (j & 1) ? cp[j / 2].y : cp[j / 2].x;
             }
             const bool odd = (blk & 1u) != 0u;
+            APT_MARK("END correlation");
             if (!interior) {
 #pragma unroll
                 for (int j = 0; j < L; ++j) {
@@ -1278,12 +1394,15 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             }
             // positions of the first group: r + 6 j < 52 in an even block (j <= 7, and j = 8 for r < 4), < 26 in an
             // odd one (j <= 3, and j = 4 for r < 2)
-            const float m03 = fmaxf(fmaxf(c[0], c[1]), fmaxf(c[2], c[3]));
-            const float m57 = fmaxf(fmaxf(c[5], c[6]), c[7]);
-            const float m912 = fmaxf(fmaxf(c[9], c[10]), fmaxf(c[11], c[12]));
+            APT_MARK("BEGIN partial_maxima");
+            const float m57 = max3_of_sums(c[5], c[6], c[7]);
             const bool a4 = !odd || rr < 2, a8 = !odd && rr < 4;
-            float mA = fmaxf(fmaxf(m03, a4 ? c[4] : kNegInfF), fmaxf(odd ? kNegInfF : m57, a8 ? c[8] : kNegInfF));
-            float mB = fmaxf(fmaxf(m912, a4 ? kNegInfF : c[4]), fmaxf(odd ? m57 : kNegInfF, a8 ? kNegInfF : c[8]));
+            float mA = max3_of_sums(c[0], c[1], c[2]);
+            mA = max3_of_sums(mA, c[3], a4 ? c[4] : kNegInfF);
+            mA = max3_of_sums(mA, odd ? kNegInfF : m57, a8 ? c[8] : kNegInfF);
+            float mB = max3_of_sums(c[9], c[10], c[11]);
+            mB = max3_of_sums(mB, c[12], a4 ? kNegInfF : c[4]);
+            mB = max3_of_sums(mB, odd ? m57 : kNegInfF, a8 ? kNegInfF : c[8]);
             if (any_nan) {
                 mA = __builtin_huge_valf();
                 mB = __builtin_huge_valf();
@@ -1298,16 +1417,22 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             g0[odd ? 12 : 6] = kNegInfF;              // even: group 3u, slot 6+r;  odd: group 3u+2, slot 6+r
         }
         __syncthreads();
+        APT_MARK("END partial_maxima");
         // the group's record
         auto group_bounds = [&](auto interior_tag) {
         constexpr bool INT = decltype(interior_tag)::value;  // interior tile: no edge tests
+        if constexpr (INT) APT_MARK("BEGIN group_record");
         if ((tid & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads && (INT || kq < c_hi)) {
             const int gl = (tid - kPreThreads) / 4;
             typedef float f4g __attribute__((ext_vector_type(4)));
             const f4g *pm = reinterpret_cast<const f4g *>(PMX + gl * 12);
             const f4g q0 = pm[0], q1 = pm[1], q2 = pm[2];
-            const float mx = fmaxf(fmaxf(fmaxf(fmaxf(q0.x, q0.y), fmaxf(q0.z, q0.w)), fmaxf(fmaxf(q1.x, q1.y), fmaxf(q1.z, q1.w))),
-                                   fmaxf(fmaxf(q2.x, q2.y), fmaxf(q2.z, q2.w)));
+            float mx = max3_of_sums(q0.x, q0.y, q0.z);
+            mx = max3_of_sums(mx, q0.w, q1.x);
+            mx = max3_of_sums(mx, q1.y, q1.z);
+            mx = max3_of_sums(mx, q1.w, q2.x);
+            mx = max3_of_sums(mx, q2.y, q2.z);
+            mx = max3_of_sums(mx, q2.w, q2.w);
             float hi = mx, lo = mx;
             bool open = mx == __builtin_huge_valf();  // fast mode's NaN mark (or a maximum that IS +inf: same record)
             if constexpr (!FAST) {
@@ -1315,12 +1440,14 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 constexpr int NT = (Gm::GS + Gm::G - 1 + L - 1) / L;
                 static_assert(NT - 1 <= 3 + kPostThreads, "the |F| window must end inside the tile");
                 float av[NT];
+                int abofs = Gm::D_OFF + Gm::TILE_K + 36 * PW + tid;  // (AB + tid as one opaque register: immediate offsets below)
+                asm volatile("" : "+v"(abofs));
 #pragma unroll
-                for (int e = 0; e < NT; ++e) av[e] = AB[tid + e];
+                for (int e = 0; e < NT; ++e) av[e] = lds[abofs + e];
                 float A = av[0];
 #pragma unroll
                 for (int e = 1; e < NT; ++e) A = A + av[e];
-                const float err = A * late->gm_slack;
+                const float err = A * gm_slack;
                 if (!(err < __builtin_huge_valf())) open = true;  // NaN or Inf somewhere in the window
                 hi = mx + err;
                 lo = mx - err;
@@ -1331,6 +1458,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             }
             gm_out[o0 / Gm::GS + gl] = GroupMax{hi, lo};
         }
+        if constexpr (INT) APT_MARK("END group_record");
         };
         if (interior) group_bounds(std::true_type{});
         else group_bounds(std::false_type{});

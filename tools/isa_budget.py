@@ -63,6 +63,9 @@ def parse(path):
     inside = False
     for i, line in enumerate(open(path), 1):
         s = line.strip()
+        if s.startswith("; APTMARK "):
+            out.append((i, "mark", s[len("; APTMARK "):].strip()))
+            continue
         if not s or s.startswith((";", "//")):
             continue
         if s.startswith(".") and not s.startswith(".LBB"):
@@ -92,6 +95,32 @@ def fmt(c):
 def main():
     path = sys.argv[1]
     items = parse(path)
+    if "--marks" in sys.argv:
+        # sums between "; APTMARK BEGIN x" and "; APTMARK END x" (apt_kernels_fused_impl.hpp, -DAPT_FUSED_MARKS=1):
+        # the code an interior tile executes, stage by stage
+        open_marks, sums, order = {}, {}, []
+        for ln, k, t in items:
+            if k == "mark":
+                what, name = t.split(None, 1)
+                if what == "BEGIN":
+                    open_marks[name] = Counter()
+                    if name not in sums:
+                        sums[name] = Counter()
+                        order.append(name)
+                elif name in open_marks:
+                    sums[name].update(open_marks.pop(name))
+                continue
+            if k == "label":
+                continue
+            for c in open_marks.values():
+                c[k] += 1
+        total = Counter()
+        for name in order:
+            print(f"{name:>24s}  {fmt(sums[name])}")
+            total.update(sums[name])
+        print(f"{'total':>24s}  {fmt(total)}")
+        return
+    items = [it for it in items if it[1] != "mark"]
     if "--sum" in sys.argv:
         spec = sys.argv[sys.argv.index("--sum") + 1]
         total = Counter()
