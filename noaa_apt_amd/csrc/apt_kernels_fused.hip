@@ -16,8 +16,8 @@
 //     scalar cache, no LDS traffic and no VGPRs for coefficients,
 //   * every product and sum is a separate v_mul_f32 / v_add_f32 in the reference's
 //     order: bit-identical to the scalar Rust loop (no FMA; #pragma fp contract(off)).
-// A workgroup of 256 threads covers 256*L work samples: 4 threads of pre-halo (the
-// low-pass and envelope look back 37 samples), 240 threads of owned outputs and 12
+// A workgroup of 256 threads covers 256*L work samples: 3 threads of pre-halo (the
+// low-pass and envelope look back 37 samples), 244 threads of owned outputs and 9
 // threads of post-halo (the correlation looks ahead 38*PW-1 samples).  LDS: the input
 // tile, later overwritten by R and then F (region P), plus D (region Q).
 #include "apt_kernels_fused_launch.hpp"

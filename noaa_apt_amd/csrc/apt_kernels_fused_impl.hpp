@@ -61,8 +61,13 @@ namespace {
 #ifndef APT_FUSED_PERSIST
 #define APT_FUSED_PERSIST 0
 #endif
-constexpr int kPreThreads = 4;    // pre-halo threads (low-pass + envelope history)
-constexpr int kPostThreads = 12;  // post-halo threads (correlation look-ahead)
+// Halo threads of a tile (FusedGeom::kPreThreads / kPostThreads).  The low-pass and the envelope need T2 + 1 = 38 work
+// samples of history, the correlation G - 1 = 113 of look-ahead: 3 + 9 threads of 13 samples in the specialised
+// kernels (round 2: 4 + 12 — a whole group of four either side; 244 instead of 240 of 256 threads own samples, 116
+// instead of 112 of the 96 kHz kernels' 128).  The table-driven and phase-resident forms keep 4 + 12: their
+// stage 1 is laid out for a tile that starts on a group boundary.
+constexpr int kPreThreadsWide = 4, kPostThreadsWide = 12;
+constexpr int kPreThreadsNarrow = 3, kPostThreadsNarrow = 9;
 constexpr float kNegInfF = -__builtin_huge_valf();
 
 // max(a, b, c) of values that are results of floating-point additions (never signalling NaNs), a quiet NaN
@@ -105,6 +110,8 @@ struct FusedGeom {
     static constexpr bool TABLE = M <= 0;   // run-time resampling factors (table-driven or phase-resident stage 1)
     static constexpr bool PHASE = M == -1;  // ... with the taps of a thread's polyphase branch in registers
     static constexpr int kFusedThreads = NTHR;
+    static constexpr int kPreThreads = TABLE ? kPreThreadsWide : kPreThreadsNarrow;
+    static constexpr int kPostThreads = TABLE ? kPostThreadsWide : kPostThreadsNarrow;
     static constexpr int kOwnThreads = NTHR - kPreThreads - kPostThreads;
     static constexpr int TP = (T1 + L - 1) / L;                       // taps per branch (max)
     static constexpr int CLAST = TABLE ? 0 : branch_first<L, (TABLE ? 1 : M)>(L - 1);  // last branch's first sample
@@ -112,7 +119,12 @@ struct FusedGeom {
     static constexpr int TILE_K = kFusedThreads * L;                  // work samples per tile
     static constexpr int OWN_K = kOwnThreads * L;                     // owned work samples
     static constexpr int PRE_K = kPreThreads * L;
-    static constexpr int XT = TABLE ? 4 : (kFusedThreads - 1) * M + WIN + 2;  // input floats per tile
+    // The tile's first input sample is (first thread's group index) * M: a multiple of 4 only when kPreThreads * M is
+    // (16-byte loads).  XSHIFT more samples are loaded in front of it, and every window read is XSHIFT further on.
+    static constexpr int XSHIFT = TABLE ? 0 : (4 - (kPreThreads * M) % 4) % 4;
+    static_assert(TABLE || (kOwnThreads * M) % 4 == 0, "every tile starts at the same offset from a 16-byte boundary");
+    static_assert(XSHIFT % 2 == 0, "window reads stay 8-byte aligned (and PCM16 pairs whole)");
+    static constexpr int XT = TABLE ? 4 : (kFusedThreads - 1) * M + WIN + 2 + XSHIFT;  // input floats per tile
     static constexpr int XT_PAD = (XT + 3) & ~3;
     static constexpr int G = 38 * PW;                                 // sync template length
     static constexpr int FWIN = L + G - 1;                            // F window per thread
@@ -130,6 +142,7 @@ struct FusedGeom {
     static_assert(PRE_K >= T2 + 1, "pre-halo too small for the low-pass");
     static_assert((kFusedThreads - kPreThreads - kOwnThreads) * L >= G - 1, "post-halo too small");
     static_assert(OWN_K % 4 == 0, "owned range must be float4-aligned");
+    static_assert(kOwnThreads % 4 == 0, "whole correlation groups");
 };
 
 // does polyphase branch b use window sample q?  (tap index i = q - c_b, p_b + i*L < T1)
@@ -223,7 +236,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     const cf2_ptr hs = (cf2_ptr)(prm->hs);  // [WIN][PS] tap pairs
     using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
     constexpr int kFusedThreads = NTHR;
-    constexpr int kOwnThreads = Gm::kOwnThreads;
+    constexpr int kOwnThreads = Gm::kOwnThreads, kPreThreads = Gm::kPreThreads, kPostThreads = Gm::kPostThreads;
     constexpr bool F16 = MODE == kModeF16Taps;
     constexpr bool FAST = MODE == kModeFast;
     extern __shared__ float lds[];
@@ -260,7 +273,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         const XT *__restrict__ x = static_cast<const XT *>(call.rec[ri].x);
         const uint64_t n = call.rec[ri].n;
         const int64_t k0 = tile * Gm::OWN_K - Gm::PRE_K;   // first work sample of the tile (< 0 in tile 0)
-        const int64_t xs0 = (k0 / L) * M;                  // first input sample of the tile
+        const int64_t xs0 = (k0 / L) * M - Gm::XSHIFT;     // first input sample the tile loads (16-byte aligned)
         const int x_lo = rel_u(-xs0);                               // tile index of input sample 0
         const int x_hi = rel_u(static_cast<int64_t>(n) - xs0);      // tile index of input sample n
         const XT *xt = x + xs0;  // only dereferenced inside [x_lo, x_hi)
@@ -637,8 +650,8 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         typedef _Float16 h2v __attribute__((ext_vector_type(2)));
         constexpr int NQP = (Gm::WIN + 1) / 2;  // window sample pairs
         auto xsrc = [&](int q) -> float {
-            if constexpr (sizeof(XT) == 2) return static_cast<float>(reinterpret_cast<const int16_t *>(lds)[tid * M + q]);
-            else return P[tid * M + q];
+            if constexpr (sizeof(XT) == 2) return static_cast<float>(reinterpret_cast<const int16_t *>(lds)[tid * M + Gm::XSHIFT + q]);
+            else return P[tid * M + Gm::XSHIFT + q];
         };
         typedef uint32_t u4v __attribute__((ext_vector_type(4)));
         typedef const u4v APT_CONST_AS *cu4v_ptr;
@@ -707,8 +720,8 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         constexpr int CHW = fused_chunk_dwords(L, CH);  // 26: 16 + 8 + 2 dwords; 40: 16 + 16 + 8
         static_assert(CHW == (CH == 2 ? 26 : 40), "three scalar loads per chunk: 16 + 8 + 2 / 16 + 16 + 8 dwords");
         auto xsrc = [&](int q) -> float {
-            if constexpr (sizeof(XT) == 2) return static_cast<float>(reinterpret_cast<const int16_t *>(lds)[tid * M + q]);
-            else return P[tid * M + q];
+            if constexpr (sizeof(XT) == 2) return static_cast<float>(reinterpret_cast<const int16_t *>(lds)[tid * M + Gm::XSHIFT + q]);
+            else return P[tid * M + Gm::XSHIFT + q];
         };
         f2 acc[Gm::NP > 0 ? Gm::NP : 1];
         float accl = 0.f;
@@ -739,7 +752,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             constexpr int g = decltype(gg)::value;
             if constexpr (RW >= 2) {
                 // (the last group may reach past the window: inside the tile's pad)
-                xw[g & 3] = *reinterpret_cast<const XV *>(P + tid * M + g * GW);
+                xw[g & 3] = *reinterpret_cast<const XV *>(P + tid * M + Gm::XSHIFT + g * GW);
             } else {
 #pragma unroll
                 for (int e = 0; e < GW; ++e) xw[g & 3][e] = (g * GW + e < Gm::WIN) ? xsrc(g * GW + e) : 0.f;
@@ -1245,7 +1258,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 #pragma unroll
         for (int e = 0; e * kFusedThreads * 4 < Gm::OWN_K; ++e) {
             const int q = (tid + e * kFusedThreads) * 4;
-            if (q < Gm::OWN_K) *(gfloat4_wptr)(sb + voff) = *reinterpret_cast<const f4 *>(P + Gm::PRE_K + q);
+            // (PRE_K is odd: the LDS side is four 4-byte-aligned words, read as two two-address reads)
+            if (q < Gm::OWN_K) {
+                const float *src = P + Gm::PRE_K + q;
+                *(gfloat4_wptr)(sb + voff) = (f4){src[0], src[1], src[2], src[3]};
+            }
             sb += kFusedThreads * 16;
             asm volatile("" : "+s"(sb));
         }
@@ -1254,7 +1271,8 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         float *ft = f_out + o0;
         for (int q = tid * 4; q < Gm::OWN_K; q += kFusedThreads * 4) {
             if (Gm::PRE_K + q + 3 < k_hi) {
-                *reinterpret_cast<float4 *>(ft + q) = *reinterpret_cast<const float4 *>(P + Gm::PRE_K + q);
+                const float *src = P + Gm::PRE_K + q;
+                *reinterpret_cast<float4 *>(ft + q) = make_float4(src[0], src[1], src[2], src[3]);
             } else {
                 for (int e = 0; e < 4; ++e)
                     if (Gm::PRE_K + q + e < k_hi) ft[q + e] = P[Gm::PRE_K + q + e];
@@ -1422,7 +1440,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         auto group_bounds = [&](auto interior_tag) {
         constexpr bool INT = decltype(interior_tag)::value;  // interior tile: no edge tests
         if constexpr (INT) APT_MARK("BEGIN group_record");
-        if ((tid & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads && (INT || kq < c_hi)) {
+        if (((tid - kPreThreads) & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads && (INT || kq < c_hi)) {
             const int gl = (tid - kPreThreads) / 4;
             typedef float f4g __attribute__((ext_vector_type(4)));
             const f4g *pm = reinterpret_cast<const f4g *>(PMX + gl * 12);
