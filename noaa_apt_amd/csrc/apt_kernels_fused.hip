@@ -49,6 +49,9 @@ uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1, int ch)
     const uint32_t tp = (t1 + l - 1) / l;
     const uint32_t clast = ((l - 1) * m + l - 1) / l;
     const uint32_t win = clast + tp;
+    if (ch == kSplitChunk)  // the SPLIT layout (apt_kernels_fused_launch.hpp): one table per half
+        return static_cast<uint32_t>(fused_split_table_offset(static_cast<int>(l), static_cast<int>(m), static_cast<int>(t1), 1) +
+                                     (fused_split_nch(static_cast<int>(l), static_cast<int>(m), static_cast<int>(t1), 1) + 1) * kSplitChunkDwords);
     const uint32_t chw = static_cast<uint32_t>(fused_chunk_dwords(static_cast<int>(l), ch));
     return ((win + ch - 1) / ch + 1) * chw;
 }
@@ -71,6 +74,31 @@ void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, 
         const uint64_t j = pb + static_cast<uint64_t>(q - cb) * l;
         return j < t1 ? coeff[j] : 0.f;
     };
+    if (ch == kSplitChunk) {
+        // SPLIT layout: per half h, chunk c holds for its window samples q = w0 + 4 c + e (e < 4) the pairs (tap of
+        // branch b0 + 2k at q, tap of branch b0 + 2k + 1 at q) at dwords 6 e + 2 k, k < 3, then (a half with an odd
+        // number of branches) the last branch's taps at q = w0 + 4 c .. + 3 at dwords 24 .. 27
+        const int li = static_cast<int>(l), mi = static_cast<int>(m), ti = static_cast<int>(t1);
+        for (int h = 0; h < 2; ++h) {
+            const int b0 = fused_split_b0(li, h), nbr = fused_split_nbr(li, h), w0 = fused_split_w0(li, mi, h);
+            const int nch_h = fused_split_nch(li, mi, ti, h);
+            float *base = hs + fused_split_table_offset(li, mi, ti, h);
+            for (int c = 0; c <= nch_h; ++c) {
+                float *row = base + static_cast<size_t>(c) * kSplitChunkDwords;
+                for (int i = 0; i < kSplitChunkDwords; ++i) row[i] = 0.f;
+                if (c == nch_h) break;
+                for (int e = 0; e < kSplitChunk; ++e) {
+                    const int64_t q = w0 + static_cast<int64_t>(kSplitChunk) * c + e;
+                    for (int k = 0; k < nbr / 2; ++k) {
+                        row[6 * e + 2 * k] = tap(static_cast<uint32_t>(b0 + 2 * k), q);
+                        row[6 * e + 2 * k + 1] = tap(static_cast<uint32_t>(b0 + 2 * k + 1), q);
+                    }
+                    if (nbr & 1) row[24 + e] = tap(static_cast<uint32_t>(b0 + nbr - 1), q);
+                }
+            }
+        }
+        return;
+    }
     const uint32_t nch = (win + ch - 1) / ch;
     for (uint32_t c = 0; c <= nch; ++c) {
         float *row = hs + static_cast<size_t>(c) * chw;

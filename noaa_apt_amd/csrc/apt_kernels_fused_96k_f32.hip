@@ -3,6 +3,6 @@
 
 namespace apt::gpu {
 
-void fused_launch_96k_f32(const FusedLaunch &a) { launch_fused_args<13, 100, 1915, 37, 3, 128, kModeStrict, float>(a); }
+void fused_launch_96k_f32(const FusedLaunch &a) { launch_fused_args<13, 100, 1915, 37, 3, 256, kModeStrict, float>(a); }
 
 }  // namespace apt::gpu

@@ -3,6 +3,6 @@
 
 namespace apt::gpu {
 
-void fused_launch_96k_fast_f32(const FusedLaunch &a) { launch_fused_args<13, 100, 1915, 37, 3, 128, kModeFast, float>(a); }
+void fused_launch_96k_fast_f32(const FusedLaunch &a) { launch_fused_args<13, 100, 1915, 37, 3, 256, kModeFast, float>(a); }
 
 }  // namespace apt::gpu

@@ -3,6 +3,6 @@
 
 namespace apt::gpu {
 
-void fused_launch_96k_fast_i16(const FusedLaunch &a) { launch_fused_args<13, 100, 1915, 37, 3, 128, kModeFast, int16_t>(a); }
+void fused_launch_96k_fast_i16(const FusedLaunch &a) { launch_fused_args<13, 100, 1915, 37, 3, 256, kModeFast, int16_t>(a); }
 
 }  // namespace apt::gpu

@@ -34,6 +34,11 @@
 #define APT_S16_52 APT_S8_(52, 53, 54, 55, 56, 57, 58, 59), APT_S8_(60, 61, 62, 63, 64, 65, 66, 67)
 #define APT_S16_60 APT_S8_(60, 61, 62, 63, 64, 65, 66, 67), APT_S8_(68, 69, 70, 71, 72, 73, 74, 75)
 #define APT_S16_76 APT_S8_(76, 77, 78, 79, 80, 81, 82, 83), APT_S8_(84, 85, 86, 87, 88, 89, 90, 91)
+// (SPLIT stage 1: 16 + 8 + 4 dwords per buffer)
+#define APT_S16_64 APT_S8_(64, 65, 66, 67, 68, 69, 70, 71), APT_S8_(72, 73, 74, 75, 76, 77, 78, 79)
+#define APT_S8_80 APT_S8_(80, 81, 82, 83, 84, 85, 86, 87)
+#define APT_S4_60 "s60", "s61", "s62", "s63"
+#define APT_S4_88 "s88", "s89", "s90", "s91"
 
 namespace apt::gpu {
 
@@ -113,6 +118,9 @@ struct FusedGeom {
     static constexpr int kPreThreads = TABLE ? kPreThreadsWide : kPreThreadsNarrow;
     static constexpr int kPostThreads = TABLE ? kPostThreadsWide : kPostThreadsNarrow;
     static constexpr int kOwnThreads = NTHR - kPreThreads - kPostThreads;
+    // SPLIT stage 1 (apt_kernels_fused_launch.hpp): two sub-tiles of NS = NTHR / 2 windows through the same LDS
+    static constexpr bool SPLIT = !TABLE && M >= 100 && NTHR == 256;
+    static constexpr int NS = SPLIT ? NTHR / 2 : NTHR;                // windows per input tile in LDS
     static constexpr int TP = (T1 + L - 1) / L;                       // taps per branch (max)
     static constexpr int CLAST = TABLE ? 0 : branch_first<L, (TABLE ? 1 : M)>(L - 1);  // last branch's first sample
     static constexpr int WIN = CLAST + TP;                            // input window per thread
@@ -124,7 +132,7 @@ struct FusedGeom {
     static constexpr int XSHIFT = TABLE ? 0 : (4 - (kPreThreads * M) % 4) % 4;
     static_assert(TABLE || (kOwnThreads * M) % 4 == 0, "every tile starts at the same offset from a 16-byte boundary");
     static_assert(XSHIFT % 2 == 0, "window reads stay 8-byte aligned (and PCM16 pairs whole)");
-    static constexpr int XT = TABLE ? 4 : (kFusedThreads - 1) * M + WIN + 2 + XSHIFT;  // input floats per tile
+    static constexpr int XT = TABLE ? 4 : (NS - 1) * M + WIN + 2 + XSHIFT;  // input floats per (sub-)tile
     static constexpr int XT_PAD = (XT + 3) & ~3;
     static constexpr int G = 38 * PW;                                 // sync template length
     static constexpr int FWIN = L + G - 1;                            // F window per thread
@@ -269,11 +277,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     // f32: 4 samples per register quad, PCM16: 4 samples per register pair
     constexpr int NXR = (Gm::XT_PAD / 4 + kFusedThreads - 1) / kFusedThreads;
     using XReg = std::conditional_t<sizeof(XT) == 4, float4, uint2>;
-    auto load_tile = [&](uint32_t ri, int64_t tile, XReg (&xr)[NXR]) {
+    auto load_tile = [&](uint32_t ri, int64_t tile, int sub, XReg (&xr)[NXR]) {  // (sub: the sub-tile of a SPLIT stage 1, else 0)
         const XT *__restrict__ x = static_cast<const XT *>(call.rec[ri].x);
         const uint64_t n = call.rec[ri].n;
         const int64_t k0 = tile * Gm::OWN_K - Gm::PRE_K;   // first work sample of the tile (< 0 in tile 0)
-        const int64_t xs0 = (k0 / L) * M - Gm::XSHIFT;     // first input sample the tile loads (16-byte aligned)
+        const int64_t xs0 = (k0 / L + sub * Gm::NS) * M - Gm::XSHIFT;  // first input sample the tile loads (16-byte aligned)
         const int x_lo = rel_u(-xs0);                               // tile index of input sample 0
         const int x_hi = rel_u(static_cast<int64_t>(n) - xs0);      // tile index of input sample n
         const XT *xt = x + xs0;  // only dereferenced inside [x_lo, x_hi)
@@ -701,6 +709,200 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         const float f16_unscale = prm->f16_unscale;  // 2^-s of the fp16 tap prescale
 #pragma unroll
         for (int b = 0; b < L; ++b) r[b] = (kq + b < k_lo || kq + b >= k_hi) ? 0.f : acc[b] * f16_unscale;
+    } else if constexpr (Gm::SPLIT) {
+        // ---- SPLIT stage 1 (apt_kernels_fused_launch.hpp): two sub-tiles of NS windows through the same LDS; in each,
+        // the threads of half h = tid / NS compute the branches [B0, B0 + NBR) of window wl = tid % NS.  Same
+        // software pipeline as the unsplit form below — a chunk's taps are one contiguous run of the half's table,
+        // fetched by scalar loads written as assembly into pinned tuples, waited for one chunk later — with chunks of
+        // four window samples = one 16-byte LDS read (PCM16: 8-byte), 24 + 4 tap dwords.
+        static_assert(L == 13 && M % 4 == 0 && Gm::XSHIFT == 0, "SPLIT: halves of 7 and 6 branches (three pairs each), 16-byte window reads");
+        constexpr int NS = Gm::NS;
+        const int wl = tid & (NS - 1);
+        constexpr int NH0 = fused_split_nbr(L, 0);   // 7: results a thread holds per sub-tile (half 1: 6)
+        float rh[2][NH0];
+        auto half = [&](auto hc, auto subc) {
+            constexpr int H = decltype(hc)::value, SUB = decltype(subc)::value;
+            constexpr int B0 = fused_split_b0(L, H), NBR = fused_split_nbr(L, H);
+            constexpr int NPH = NBR / 2;
+            constexpr bool ODDH = (NBR & 1) != 0;
+            static_assert(NPH == 3, "three branch pairs per half");
+            constexpr int W0 = fused_split_w0(L, M, H), NCH = fused_split_nch(L, M, T1, H);
+            constexpr int CHW = kSplitChunkDwords;
+            const cf2_ptr hsp = hs + fused_split_table_offset(L, M, T1, H) / 2;
+            typedef uint32_t u16s __attribute__((ext_vector_type(16)));
+            typedef uint32_t u8s __attribute__((ext_vector_type(8)));
+            typedef uint32_t u4s __attribute__((ext_vector_type(4)));
+            u16s ta[2];
+            u8s tb[2];
+            u4s tc[2];
+            typedef float f4w __attribute__((ext_vector_type(4)));
+            using XRaw = std::conditional_t<sizeof(XT) == 4, f4w, u2>;  // four window samples as they lie in LDS
+            XRaw xraw[2];
+            f2 acc[NPH];
+            float accl = 0.f;
+#pragma unroll
+            for (int k = 0; k < NPH; ++k) acc[k] = (f2){0.f, 0.f};
+            auto issue = [&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                // (clobbers, not outputs: see the unsplit form)
+                if constexpr ((c & 1) == 0)
+                    asm volatile("s_load_dwordx16 s[36:51], %0, %1\n\ts_load_dwordx8 s[52:59], %0, %2\n\ts_load_dwordx4 s[60:63], %0, %3"
+                                 :: "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 96)
+                                 : APT_S16(36), APT_S8(52), APT_S4_60);
+                else
+                    asm volatile("s_load_dwordx16 s[64:79], %0, %1\n\ts_load_dwordx8 s[80:87], %0, %2\n\ts_load_dwordx4 s[88:91], %0, %3"
+                                 :: "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 96)
+                                 : APT_S16(64), APT_S8(80), APT_S4_88);
+                if constexpr (sizeof(XT) == 4)
+                    xraw[c & 1] = *reinterpret_cast<const f4w *>(P + wl * M + W0 + kSplitChunk * c);
+                else
+                    xraw[c & 1] = *reinterpret_cast<const u2 *>(reinterpret_cast<const int16_t *>(lds) + wl * M + W0 + kSplitChunk * c);
+            };
+            auto wait_taps = [&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                u16s &ra = ta[c & 1];
+                u8s &rb = tb[c & 1];
+                u4s &rc = tc[c & 1];
+                XRaw &xr_ = xraw[c & 1];
+                if constexpr ((c & 1) == 0)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "={s[36:51]}"(ra), "={s[52:59]}"(rb), "={s[60:63]}"(rc), "+v"(xr_));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "={s[64:79]}"(ra), "={s[80:87]}"(rb), "={s[88:91]}"(rc), "+v"(xr_));
+            };
+            auto tapd = [&](auto cc, auto ii) -> float {
+                constexpr int buf = decltype(cc)::value & 1, i = decltype(ii)::value;
+                if constexpr (i < 16) return __uint_as_float(ta[buf][i]);
+                else if constexpr (i < 24) return __uint_as_float(tb[buf][i - 16]);
+                else return __uint_as_float(tc[buf][i - 24]);
+            };
+            issue(std::integral_constant<int, 0>{});
+            static_for<0, NCH>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                wait_taps(cc);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (c + 1 < NCH) issue(std::integral_constant<int, c + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                f4w xv;
+                if constexpr (sizeof(XT) == 4) {
+                    xv = xraw[c & 1];
+                } else {
+                    // `*x as f32` (wav.rs:37) of the four PCM16 samples
+                    const u2 u = xraw[c & 1];
+                    xv = (f4w){static_cast<float>(static_cast<int16_t>(u.x & 0xFFFFu)), static_cast<float>(static_cast<int32_t>(u.x) >> 16),
+                               static_cast<float>(static_cast<int16_t>(u.y & 0xFFFFu)), static_cast<float>(static_cast<int32_t>(u.y) >> 16)};
+                }
+                static_for<0, kSplitChunk>([&](auto ee) {
+                    constexpr int e = decltype(ee)::value;
+                    constexpr int q = W0 + kSplitChunk * c + e;
+                    const float xq = xv[e];
+                    f2 pr[NPH];
+                    // all products of the sample first, then the dependent adds
+                    static_for<0, NPH>([&](auto kk) {
+                        constexpr int k = decltype(kk)::value;
+                        constexpr bool va = branch_uses<L, M, T1>(B0 + 2 * k, q), vb = branch_uses<L, M, T1>(B0 + 2 * k + 1, q);
+                        const f2 t = (f2){tapd(cc, std::integral_constant<int, 6 * e + 2 * k>{}), tapd(cc, std::integral_constant<int, 6 * e + 2 * k + 1>{})};
+                        pr[k] = (f2){0.f, 0.f};
+                        if constexpr (FAST) {
+                            if constexpr (va && vb) acc[k] = __builtin_elementwise_fma(t, (f2){xq, xq}, acc[k]);
+                            else if constexpr (va) acc[k].x = __builtin_fmaf(t.x, xq, acc[k].x);
+                            else if constexpr (vb) acc[k].y = __builtin_fmaf(t.y, xq, acc[k].y);
+                        } else {
+                            if constexpr (va && vb) pr[k] = t * (f2){xq, xq};
+                            else if constexpr (va) pr[k].x = t.x * xq;
+                            else if constexpr (vb) pr[k].y = t.y * xq;
+                        }
+                    });
+                    if constexpr (!FAST) {
+                        static_for<0, NPH>([&](auto kk) {
+                            constexpr int k = decltype(kk)::value;
+                            constexpr bool va = branch_uses<L, M, T1>(B0 + 2 * k, q), vb = branch_uses<L, M, T1>(B0 + 2 * k + 1, q);
+                            if constexpr (va && vb) acc[k] = acc[k] + pr[k];
+                            else if constexpr (va) acc[k].x = acc[k].x + pr[k].x;
+                            else if constexpr (vb) acc[k].y = acc[k].y + pr[k].y;
+                        });
+                    }
+                });
+                if constexpr (ODDH) {
+                    // the half's last branch: the products of an aligned sample pair in one packed multiply, the additions
+                    // one after the other in tap order
+                    static_for<0, kSplitChunk / 2>([&](auto pp) {
+                        constexpr int e = 2 * decltype(pp)::value;
+                        constexpr int q = W0 + kSplitChunk * c + e;
+                        constexpr bool u0 = branch_uses<L, M, T1>(B0 + NBR - 1, q), u1 = branch_uses<L, M, T1>(B0 + NBR - 1, q + 1);
+                        const f2 t = (f2){tapd(cc, std::integral_constant<int, 24 + e>{}), tapd(cc, std::integral_constant<int, 25 + e>{})};
+                        const f2 xp = (f2){xv[e], xv[e + 1]};
+                        if constexpr (FAST) {
+                            if constexpr (u0) accl = __builtin_fmaf(t.x, xp.x, accl);
+                            if constexpr (u1) accl = __builtin_fmaf(t.y, xp.y, accl);
+                        } else if constexpr (u0 && u1) {
+                            const f2 po = t * xp;
+                            accl = accl + po.x;
+                            accl = accl + po.y;
+                        } else if constexpr (u0) {
+                            accl = accl + t.x * xp.x;
+                        } else if constexpr (u1) {
+                            accl = accl + t.y * xp.y;
+                        }
+                    });
+                }
+                // (pins the accumulators: see the unsplit form)
+                static_for<0, NPH>([&](auto kk) {
+                    f2 &a = acc[decltype(kk)::value];
+                    asm volatile("" : "+v"(a));
+                });
+                asm volatile("" : "+v"(accl));
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int k = 0; k < NPH; ++k) {
+                rh[SUB][2 * k] = acc[k].x;
+                rh[SUB][2 * k + 1] = acc[k].y;
+            }
+            if constexpr (ODDH) rh[SUB][NBR - 1] = accl;
+        };
+        // sub-tile 0 is in LDS; sub-tile 1's loads are in flight under its stage 1
+        XReg xr1[NXR];
+        load_tile(ri, tile, 1, xr1);
+        if (tid < NS) half(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        else half(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        __syncthreads();  // everyone is done reading sub-tile 0
+        tile_to_lds(xr1);
+        __syncthreads();
+        if (tid < NS) half(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        else half(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+        APT_MARK("END stage1");
+        __syncthreads();  // everyone is done reading sub-tile 1: R may land on it
+        if (tid < NS) {
+#pragma unroll
+            for (int j = 0; j < fused_split_nbr(L, 0); ++j) {
+                P[wl * L + j] = rh[0][j];
+                P[(NS + wl) * L + j] = rh[1][j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < fused_split_nbr(L, 1); ++j) {
+                P[wl * L + fused_split_b0(L, 1) + j] = rh[0][j];
+                P[(NS + wl) * L + fused_split_b0(L, 1) + j] = rh[1][j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < L; ++b) r[b] = P[tid * L + b];
+        if (!interior) {
+            bool any = false;
+#pragma unroll
+            for (int b = 0; b < L; ++b)
+                if (kq + b < k_lo || kq + b >= k_hi) {
+                    r[b] = 0.f;
+                    any = true;
+                }
+            // (the stages behind read R from LDS too: the envelope's predecessor pairs)
+            if (any) {
+#pragma unroll
+                for (int b = 0; b < L; ++b) P[tid * L + b] = r[b];
+            }
+            __syncthreads();
+        }
     } else
     {
         // Software pipeline over chunks of CH = 2 window samples (fused_chunk()).  The taps of a chunk are ONE
@@ -989,10 +1191,12 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         }
     }
     APT_MARK("BEGIN r_store");
+    if constexpr (!Gm::SPLIT) {  // (SPLIT: R went through LDS already)
     __syncthreads();  // everyone is done reading the x tile
 #pragma unroll
     for (int b = 0; b < L; ++b) P[tid * L + b] = r[b];
     __syncthreads();
+    }
     after_tile_in_lds();  // (persistent form: the NEXT tile's loads, in flight under stages 2 to 4)
     }  // !TABLE
 
@@ -1508,12 +1712,12 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         uint32_t ri = 0, ri2 = 0, at = 0;
         int64_t tile = 0, tile2 = 0;
         if (!first(blockIdx.x, &ri, &tile, &at)) return;
-        load_tile(ri, tile, xr);
+        load_tile(ri, tile, 0, xr);
         while (true) {
             uint32_t at2 = 0;
             const bool more = first(at + gridDim.x, &ri2, &tile2, &at2);
             run_tile(ri, tile, xr, [&] {
-                if (more) load_tile(ri2, tile2, xr);
+                if (more) load_tile(ri2, tile2, 0, xr);
             });
             if (!more) break;
             ri = ri2;
@@ -1527,7 +1731,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     const uint32_t ri = blockIdx.y;
     const int64_t tile = blockIdx.x;
     if (static_cast<uint64_t>(tile) * Gm::OWN_K >= call.rec[ri].w) return;
-    if constexpr (!Gm::TABLE) load_tile(ri, tile, xr);
+    if constexpr (!Gm::TABLE) load_tile(ri, tile, 0, xr);
     run_tile(ri, tile, xr, [] {});
     }
 #undef call

@@ -15,17 +15,47 @@ constexpr int kModeFast = 2;
 // chunk's run in the tap table: CH x (l/2) branch pairs, then the odd branch's taps of the chunk — those of its
 // aligned sample pair (q even, q + 1) first, then (CH == 3) that of the sample left over — padded so that three scalar
 // loads fetch it (26 = 16 + 8 + 2 dwords; 40 = 16 + 16 + 8).  Host (table builder) and device agree through these.
-// Three-sample chunks (80 pinned SGPRs) give the 96 kHz kernels — 1.5 waves per SIMD, bound by the scalar cache's
-// latency — half as much cover again per wait: config 3 in fast mode 0.709 -> 0.631 ms per recording, strict 0.660 -> 0.654.
+// m >= 100 (the 96 kHz kernels): 4 = the SPLIT layout below.  (Until round 3 those kernels were 128-thread
+// workgroups — 1.5 waves per SIMD under their 52 KB input tile — with three-sample chunks of all 13 branches.)
 constexpr int fused_chunk(int m, int mode)
 {
 #ifdef APT_FUSED_CH_ALL
     return APT_FUSED_CH_ALL;
 #else
-    return m >= 100 ? 3 : 2;  // (48 kHz fast mode: measured 3 % slower with three)
+    return m >= 100 ? 4 : 2;  // (48 kHz fast mode: measured 3 % slower with three)
 #endif
 }
 constexpr int fused_chunk_dwords(int l, int ch) { return ch == 2 ? 4 * (l / 2) + 2 : 6 * (l / 2) + 4; }
+
+// SPLIT stage 1 (m >= 100: an input tile of 256 windows would be 102 KB of LDS).  A 256-thread workgroup runs stage 1
+// over TWO sub-tiles of 128 windows, one after the other through the same LDS; in each, thread (half h, window a)
+// computes the branches [b0, b0 + nbr) of window a only — h = 0: the first (l + 1) / 2 branches, h = 1: the rest —
+// so that all 256 threads (four waves, three workgroups per CU: 3 waves per SIMD) share a 52 KB tile.  The stages
+// behind it see 256 threads x l outputs as in the 48 kHz kernels.  A half's taps: its own chunk-major table over
+// the window samples [w0, w0 + 4 nch) its branches use, w0 a multiple of 4 (16-byte LDS reads); a chunk is 4
+// samples x 3 branch pairs (24 dwords) followed by the odd branch's 4 taps (half 0 only): 28 = 16 + 8 + 4 dwords.
+constexpr int kSplitChunk = 4, kSplitChunkDwords = 28;
+constexpr int fused_branch_first(int l, int m, int b) { return (b * m + l - 1) / l; }
+constexpr int fused_branch_end(int l, int m, int t1, int b)  // one past the last window sample branch b has a tap for
+{
+    const int cb = fused_branch_first(l, m, b), pb = cb * l - b * m;
+    return cb + (t1 - pb + l - 1) / l;
+}
+constexpr int fused_split_b0(int l, int h) { return h == 0 ? 0 : (l + 1) / 2; }
+constexpr int fused_split_nbr(int l, int h) { return h == 0 ? (l + 1) / 2 : l / 2; }
+constexpr int fused_split_w0(int l, int m, int h) { return fused_branch_first(l, m, fused_split_b0(l, h)) / 4 * 4; }
+constexpr int fused_split_nch(int l, int m, int t1, int h)
+{
+    int end = 0;
+    for (int b = fused_split_b0(l, h); b < fused_split_b0(l, h) + fused_split_nbr(l, h); ++b)
+        end = fused_branch_end(l, m, t1, b) > end ? fused_branch_end(l, m, t1, b) : end;
+    return (end - fused_split_w0(l, m, h) + kSplitChunk - 1) / kSplitChunk;
+}
+// floats in front of half h's table (one zero row behind each half)
+constexpr int fused_split_table_offset(int l, int m, int t1, int h)
+{
+    return h == 0 ? 0 : (fused_split_nch(l, m, t1, 0) + 1) * kSplitChunkDwords;
+}
 
 // arguments of one launch: the recordings of one call (see CallArgs / SlotPtrs in apt_kernels.hpp)
 struct FusedLaunch {
