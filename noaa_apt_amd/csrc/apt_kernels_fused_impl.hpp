@@ -110,7 +110,7 @@ __host__ __device__ constexpr int branch_phase(int b)  // p_b = c_b*L - b*M
 // half the tile, so the other regions set the footprint and 4 instead of 3 workgroups fit a CU)
 // M == 0 selects the table-driven stage 1 (TABLE mode, see k_fused): the resampling factors, tap count and
 // input tile are then run-time quantities (FusedParams::tab) and only the work-rate geometry is static.
-template <int L, int M, int T1, int T2, int PW, int NTHR, int XB = 4>
+template <int L, int M, int T1, int T2, int PW, int NTHR, int XB = 4, bool F16TAPS = false>
 struct FusedGeom {
     static constexpr bool TABLE = M <= 0;   // run-time resampling factors (table-driven or phase-resident stage 1)
     static constexpr bool PHASE = M == -1;  // ... with the taps of a thread's polyphase branch in registers
@@ -119,7 +119,7 @@ struct FusedGeom {
     static constexpr int kPostThreads = TABLE ? kPostThreadsWide : kPostThreadsNarrow;
     static constexpr int kOwnThreads = NTHR - kPreThreads - kPostThreads;
     // SPLIT stage 1 (apt_kernels_fused_launch.hpp): two sub-tiles of NS = NTHR / 2 windows through the same LDS
-    static constexpr bool SPLIT = !TABLE && M >= 100 && NTHR == 256;
+    static constexpr bool SPLIT = !TABLE && !F16TAPS && NTHR == 256;
     static constexpr int NS = SPLIT ? NTHR / 2 : NTHR;                // windows per input tile in LDS
     static constexpr int TP = (T1 + L - 1) / L;                       // taps per branch (max)
     static constexpr int CLAST = TABLE ? 0 : branch_first<L, (TABLE ? 1 : M)>(L - 1);  // last branch's first sample
@@ -143,6 +143,9 @@ struct FusedGeom {
     // (+NTHR: the per-thread |F| sums behind the strict modes' bounds of the group maxima)
     static constexpr int W_LDS_FLOATS = D_OFF + TILE_K + 36 * PW + NTHR;  // what the work-rate stages need
     static constexpr int LDS_FLOATS = XT_LDS > W_LDS_FLOATS ? XT_LDS : W_LDS_FLOATS;
+    // workgroups a CU's 160 KB of LDS hold (the specialised kernels' occupancy; at most 8 waves per SIMD)
+    static constexpr int WGS_PER_CU_LDS = TABLE ? 2 : (160 * 1024) / (LDS_FLOATS * 4);
+    static constexpr int WGS_PER_CU = WGS_PER_CU_LDS * NTHR > 8 * 256 ? (8 * 256) / NTHR : WGS_PER_CU_LDS;
     static constexpr int GS = 4 * L;                                  // correlation group size
     static constexpr int NP = L / 2;                                  // accumulator pairs (+1 single if L odd)
     // (stage-1 tap table: chunk-major, fused_branch_taps / fused_chunk_dwords in apt_kernels_fused_launch.hpp)
@@ -228,7 +231,8 @@ template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
 // the picker's kernels of the previous call — one 1024-thread workgroup among them — run beside this one)
 __global__ void __launch_bounds__(NTHR, M == -1 ? ((NTHR > 256 ? 2 : 3) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs) or two 512-thread (<= 128) workgroups per CU */
                                      : M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
-                                               : (APT_FUSED_MIN_WAVES * NTHR + 255) / 256)
+                                               /* specialised: as many workgroups as the CU's 160 KB of LDS hold (48 kHz SPLIT: 5, 96 kHz: 3) */
+                                               : (FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), MODE == kModeF16Taps>::WGS_PER_CU * NTHR + 255) / 256)
 k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 {
     // The call's arguments are read where they lie, in the kernel-argument segment (constant address
@@ -242,7 +246,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     // use, and the register allocator answered the extra pressure by spilling the table pointer
     // itself inside the hot loop.
     const cf2_ptr hs = (cf2_ptr)(prm->hs);  // [WIN][PS] tap pairs
-    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
+    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), MODE == kModeF16Taps>;
     constexpr int kFusedThreads = NTHR;
     constexpr int kOwnThreads = Gm::kOwnThreads, kPreThreads = Gm::kPreThreads, kPostThreads = Gm::kPostThreads;
     constexpr bool F16 = MODE == kModeF16Taps;
@@ -715,7 +719,8 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         // software pipeline as the unsplit form below — a chunk's taps are one contiguous run of the half's table,
         // fetched by scalar loads written as assembly into pinned tuples, waited for one chunk later — with chunks of
         // four window samples = one 16-byte LDS read (PCM16: 8-byte), 24 + 4 tap dwords.
-        static_assert(L == 13 && M % 4 == 0 && Gm::XSHIFT == 0, "SPLIT: halves of 7 and 6 branches (three pairs each), 16-byte window reads");
+        static_assert(L == 13 && M % 2 == 0 && Gm::XSHIFT % 2 == 0, "SPLIT: halves of 7 and 6 branches (three pairs each), window reads of aligned sample pairs");
+        constexpr bool WIDE = M % 4 == 0 && Gm::XSHIFT % 4 == 0;  // a chunk's four samples are one 16-byte LDS read (else two of 8)
         constexpr int NS = Gm::NS;
         const int wl = tid & (NS - 1);
         constexpr int NH0 = fused_split_nbr(L, 0);   // 7: results a thread holds per sub-tile (half 1: 6)
@@ -753,10 +758,22 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                     asm volatile("s_load_dwordx16 s[64:79], %0, %1\n\ts_load_dwordx8 s[80:87], %0, %2\n\ts_load_dwordx4 s[88:91], %0, %3"
                                  :: "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 96)
                                  : APT_S16(64), APT_S8(80), APT_S4_88);
-                if constexpr (sizeof(XT) == 4)
-                    xraw[c & 1] = *reinterpret_cast<const f4w *>(P + wl * M + W0 + kSplitChunk * c);
-                else
-                    xraw[c & 1] = *reinterpret_cast<const u2 *>(reinterpret_cast<const int16_t *>(lds) + wl * M + W0 + kSplitChunk * c);
+                constexpr int q0 = Gm::XSHIFT + W0 + kSplitChunk * c;
+                if constexpr (sizeof(XT) == 4) {
+                    if constexpr (WIDE) {
+                        xraw[c & 1] = *reinterpret_cast<const f4w *>(P + wl * M + q0);
+                    } else {
+                        // (lane stride M = 50 words: conflict-free as 8-byte reads, see the unsplit form)
+                        const f2 lo = *reinterpret_cast<const f2 *>(P + wl * M + q0), hi = *reinterpret_cast<const f2 *>(P + wl * M + q0 + 2);
+                        xraw[c & 1] = (f4w){lo.x, lo.y, hi.x, hi.y};
+                    }
+                } else if constexpr (WIDE) {
+                    xraw[c & 1] = *reinterpret_cast<const u2 *>(reinterpret_cast<const int16_t *>(lds) + wl * M + q0);
+                } else {
+                    // (four PCM16 samples at an even sample index: two dwords, 4-byte aligned)
+                    const uint32_t *w32 = reinterpret_cast<const uint32_t *>(lds) + (wl * M + q0) / 2;
+                    xraw[c & 1] = (u2){w32[0], w32[1]};
+                }
             };
             auto wait_taps = [&](auto cc) {
                 constexpr int c = decltype(cc)::value;
@@ -916,7 +933,13 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         // packed instructions of cover in the strict modes, half that in fast mode.
         // kModeFast runs the same pipeline with one v_pk_fma_f32 per tap pair instead of a
         // v_pk_mul_f32 + v_pk_add_f32 (half the VALU instructions under the same tap loads).
-        constexpr int CH = fused_chunk(M, MODE);
+        // (The product kernels — 256 threads, f32 taps — all take the SPLIT form above since round 3; what is left here
+        // serves the 128 / 192-thread timing probes, whose tables the host no longer builds.)
+#ifdef APT_FUSED_CH_ALL
+        constexpr int CH = APT_FUSED_CH_ALL;
+#else
+        constexpr int CH = 2;
+#endif
         static_assert(CH == 2 || CH == 3, "two or three window samples per chunk");
         constexpr int NCH = (Gm::WIN + CH - 1) / CH;
         constexpr int CHW = fused_chunk_dwords(L, CH);  // 26: 16 + 8 + 2 dwords; 40: 16 + 16 + 8
@@ -1758,7 +1781,7 @@ inline void ensure_dynamic_lds(size_t lds)
 template <int L, int M, int T1, int T2, int PW, int NTHR, int MODE, typename XT>
 void launch_fused_args(const FusedLaunch &a)
 {
-    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT))>;
+    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), MODE == kModeF16Taps>;
     size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
     if constexpr (Gm::TABLE) lds = std::max<size_t>(a.table_lds_floats, Gm::W_LDS_FLOATS) * sizeof(float);
     constexpr auto kern = k_fused<L, M, T1, T2, PW, NTHR, XT, MODE>;

@@ -19,11 +19,7 @@ constexpr int kModeFast = 2;
 // workgroups — 1.5 waves per SIMD under their 52 KB input tile — with three-sample chunks of all 13 branches.)
 constexpr int fused_chunk(int m, int mode)
 {
-#ifdef APT_FUSED_CH_ALL
-    return APT_FUSED_CH_ALL;
-#else
-    return m >= 100 ? 4 : 2;  // (48 kHz fast mode: measured 3 % slower with three)
-#endif
+    return 4;  // the SPLIT layout below (round 3: every specialised kernel with f32 taps)
 }
 constexpr int fused_chunk_dwords(int l, int ch) { return ch == 2 ? 4 * (l / 2) + 2 : 6 * (l / 2) + 4; }
 
