@@ -42,31 +42,25 @@ bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t 
 
 uint32_t fused_group_size(uint32_t l) { return 4 * l; }
 
-// floats in the stage-1 tap table: chunk-major, one run of fused_chunk_dwords() per chunk of `ch` window samples,
-// plus one chunk of zeros
+// floats in the stage-1 tap table: the SPLIT layout (apt_kernels_fused_launch.hpp), one chunk-major table per half
 uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1, int ch)
 {
-    const uint32_t tp = (t1 + l - 1) / l;
-    const uint32_t clast = ((l - 1) * m + l - 1) / l;
-    const uint32_t win = clast + tp;
-    if (ch == kSplitChunk)  // the SPLIT layout (apt_kernels_fused_launch.hpp): one table per half
-        return static_cast<uint32_t>(fused_split_table_offset(static_cast<int>(l), static_cast<int>(m), static_cast<int>(t1), 1) +
-                                     (fused_split_nch(static_cast<int>(l), static_cast<int>(m), static_cast<int>(t1), 1) + 1) * kSplitChunkDwords);
-    const uint32_t chw = static_cast<uint32_t>(fused_chunk_dwords(static_cast<int>(l), ch));
-    return ((win + ch - 1) / ch + 1) * chw;
+    (void)ch;  // kSplitChunk
+    const int li = static_cast<int>(l), mi = static_cast<int>(m), ti = static_cast<int>(t1);
+    return static_cast<uint32_t>(fused_split_table_offset(li, mi, ti, 1) + (fused_split_nch(li, mi, ti, 1) + 1) * kSplitChunkDwords);
 }
 
-// host: chunk c holds, for its window samples q = ch*c + e (e < ch), the pairs (tap of branch 2pp at q, tap of
-// branch 2pp+1 at q) at dwords e*2*np + 2*pp; then, for an odd l, the taps of the branch l-1: those of the chunk's
-// ALIGNED sample pair (qp even, qp + 1) at dwords ch*2*np, +1, and (ch == 3) that of the sample left over at +2;
-// 0 where a branch does not use q or q lies past the window
+// host: per half h, chunk c holds for its window samples q = w0 + 4 c + e (e < 4) the pairs (tap of branch b0 + 2k at
+// q, tap of branch b0 + 2k + 1 at q) at dwords 6 e + 2 k, k < 3, then (a half with an odd number of branches) the last
+// branch's taps at q = w0 + 4 c .. + 3 at dwords 24 .. 27; 0 where a branch has no tap for q; one zero row behind
+// each half.  Tap of branch b at window sample q: coeff[p_b + (q - c_b) l], c_b = ceil(b m / l), p_b = c_b l - b m
+// (dsp.rs:252-263).
 void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, int ch, float *hs)
 {
+    (void)ch;
     const uint32_t tp = (t1 + l - 1) / l;
     const uint32_t clast = ((l - 1) * m + l - 1) / l;
     const uint32_t win = clast + tp;
-    const uint32_t np = l / 2;
-    const uint32_t chw = static_cast<uint32_t>(fused_chunk_dwords(static_cast<int>(l), ch));
     auto tap = [&](uint32_t b, int64_t q) -> float {
         const uint32_t cb = (b * m + l - 1) / l;
         const uint32_t pb = cb * l - b * m;
@@ -74,47 +68,23 @@ void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, 
         const uint64_t j = pb + static_cast<uint64_t>(q - cb) * l;
         return j < t1 ? coeff[j] : 0.f;
     };
-    if (ch == kSplitChunk) {
-        // SPLIT layout: per half h, chunk c holds for its window samples q = w0 + 4 c + e (e < 4) the pairs (tap of
-        // branch b0 + 2k at q, tap of branch b0 + 2k + 1 at q) at dwords 6 e + 2 k, k < 3, then (a half with an odd
-        // number of branches) the last branch's taps at q = w0 + 4 c .. + 3 at dwords 24 .. 27
-        const int li = static_cast<int>(l), mi = static_cast<int>(m), ti = static_cast<int>(t1);
-        for (int h = 0; h < 2; ++h) {
-            const int b0 = fused_split_b0(li, h), nbr = fused_split_nbr(li, h), w0 = fused_split_w0(li, mi, h);
-            const int nch_h = fused_split_nch(li, mi, ti, h);
-            float *base = hs + fused_split_table_offset(li, mi, ti, h);
-            for (int c = 0; c <= nch_h; ++c) {
-                float *row = base + static_cast<size_t>(c) * kSplitChunkDwords;
-                for (int i = 0; i < kSplitChunkDwords; ++i) row[i] = 0.f;
-                if (c == nch_h) break;
-                for (int e = 0; e < kSplitChunk; ++e) {
-                    const int64_t q = w0 + static_cast<int64_t>(kSplitChunk) * c + e;
-                    for (int k = 0; k < nbr / 2; ++k) {
-                        row[6 * e + 2 * k] = tap(static_cast<uint32_t>(b0 + 2 * k), q);
-                        row[6 * e + 2 * k + 1] = tap(static_cast<uint32_t>(b0 + 2 * k + 1), q);
-                    }
-                    if (nbr & 1) row[24 + e] = tap(static_cast<uint32_t>(b0 + nbr - 1), q);
+    const int li = static_cast<int>(l), mi = static_cast<int>(m), ti = static_cast<int>(t1);
+    for (int h = 0; h < 2; ++h) {
+        const int b0 = fused_split_b0(li, h), nbr = fused_split_nbr(li, h), w0 = fused_split_w0(li, mi, h);
+        const int nch_h = fused_split_nch(li, mi, ti, h);
+        float *base = hs + fused_split_table_offset(li, mi, ti, h);
+        for (int c = 0; c <= nch_h; ++c) {
+            float *row = base + static_cast<size_t>(c) * kSplitChunkDwords;
+            for (int i = 0; i < kSplitChunkDwords; ++i) row[i] = 0.f;
+            if (c == nch_h) break;
+            for (int e = 0; e < kSplitChunk; ++e) {
+                const int64_t q = w0 + static_cast<int64_t>(kSplitChunk) * c + e;
+                for (int k = 0; k < nbr / 2; ++k) {
+                    row[6 * e + 2 * k] = tap(static_cast<uint32_t>(b0 + 2 * k), q);
+                    row[6 * e + 2 * k + 1] = tap(static_cast<uint32_t>(b0 + 2 * k + 1), q);
                 }
+                if (nbr & 1) row[24 + e] = tap(static_cast<uint32_t>(b0 + nbr - 1), q);
             }
-        }
-        return;
-    }
-    const uint32_t nch = (win + ch - 1) / ch;
-    for (uint32_t c = 0; c <= nch; ++c) {
-        float *row = hs + static_cast<size_t>(c) * chw;
-        for (uint32_t i = 0; i < chw; ++i) row[i] = 0.f;
-        if (c == nch) break;
-        const int64_t q0 = static_cast<int64_t>(ch) * c;
-        for (int e = 0; e < ch; ++e)
-            for (uint32_t pp = 0; pp < np; ++pp) {
-                row[e * 2 * np + 2 * pp] = tap(2 * pp, q0 + e);
-                row[e * 2 * np + 2 * pp + 1] = tap(2 * pp + 1, q0 + e);
-            }
-        if (l & 1) {
-            const int64_t qp = (q0 & 1) ? q0 + 1 : q0;
-            row[ch * 2 * np] = tap(l - 1, qp);
-            row[ch * 2 * np + 1] = tap(l - 1, qp + 1);
-            if (ch == 3) row[ch * 2 * np + 2] = tap(l - 1, (q0 & 1) ? q0 : q0 + 2);
         }
     }
 }
@@ -215,10 +185,10 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
                 const char *e = std::getenv("APTGPU_PROBE_STOP");
                 return e ? std::atoi(e) : 0;
             }();
-            if (!pcm16 && probe >= 1 && probe <= 9) {
+            if (!pcm16 && probe >= 1 && probe <= 9 && probe != 6 && probe != 7) {  // (6, 7: the 128 / 192-thread forms, gone with the unsplit stage 1)
                 void (*const fn[9])(const FusedLaunch &) = {fused_launch_probe1, fused_launch_probe2, fused_launch_probe3,
-                                                            fused_launch_probe4, fused_launch_probe5, fused_launch_probe6,
-                                                            fused_launch_probe7, fused_launch_probe8, fused_launch_probe9};
+                                                            fused_launch_probe4, fused_launch_probe5, nullptr,
+                                                            nullptr, fused_launch_probe8, fused_launch_probe9};
                 fn[probe - 1](a);
             } else
 #endif

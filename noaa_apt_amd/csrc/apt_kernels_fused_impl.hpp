@@ -26,15 +26,8 @@
 #define APT_S8_X(n) APT_S8_##n
 #define APT_S16_X(n) APT_S16_##n
 #define APT_S8_52 APT_S8_(52, 53, 54, 55, 56, 57, 58, 59)
-#define APT_S8_68 APT_S8_(68, 69, 70, 71, 72, 73, 74, 75)
-#define APT_S8_76 APT_S8_(76, 77, 78, 79, 80, 81, 82, 83)
-#define APT_S8_92 APT_S8_(92, 93, 94, 95, 96, 97, 98, 99)
-#define APT_S16_20 APT_S8_(20, 21, 22, 23, 24, 25, 26, 27), APT_S8_(28, 29, 30, 31, 32, 33, 34, 35)
 #define APT_S16_36 APT_S8_(36, 37, 38, 39, 40, 41, 42, 43), APT_S8_(44, 45, 46, 47, 48, 49, 50, 51)
-#define APT_S16_52 APT_S8_(52, 53, 54, 55, 56, 57, 58, 59), APT_S8_(60, 61, 62, 63, 64, 65, 66, 67)
-#define APT_S16_60 APT_S8_(60, 61, 62, 63, 64, 65, 66, 67), APT_S8_(68, 69, 70, 71, 72, 73, 74, 75)
-#define APT_S16_76 APT_S8_(76, 77, 78, 79, 80, 81, 82, 83), APT_S8_(84, 85, 86, 87, 88, 89, 90, 91)
-// (SPLIT stage 1: 16 + 8 + 4 dwords per buffer)
+// (16 + 8 + 4 dwords per buffer)
 #define APT_S16_64 APT_S8_(64, 65, 66, 67, 68, 69, 70, 71), APT_S8_(72, 73, 74, 75, 76, 77, 78, 79)
 #define APT_S8_80 APT_S8_(80, 81, 82, 83, 84, 85, 86, 87)
 #define APT_S4_60 "s60", "s61", "s62", "s63"
@@ -148,7 +141,7 @@ struct FusedGeom {
     static constexpr int WGS_PER_CU = WGS_PER_CU_LDS * NTHR > 8 * 256 ? (8 * 256) / NTHR : WGS_PER_CU_LDS;
     static constexpr int GS = 4 * L;                                  // correlation group size
     static constexpr int NP = L / 2;                                  // accumulator pairs (+1 single if L odd)
-    // (stage-1 tap table: chunk-major, fused_branch_taps / fused_chunk_dwords in apt_kernels_fused_launch.hpp)
+    // (stage-1 tap table: chunk-major per thread half, fused_branch_taps / the layout functions in apt_kernels_fused_launch.hpp)
     static constexpr int DW = L + T2 - 1;                             // envelope window per thread
     static_assert(PRE_K >= T2 + 1, "pre-halo too small for the low-pass");
     static_assert((kFusedThreads - kPreThreads - kOwnThreads) * L >= G - 1, "post-halo too small");
@@ -812,6 +805,22 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                     constexpr int e = decltype(ee)::value;
                     constexpr int q = W0 + kSplitChunk * c + e;
                     const float xq = xv[e];
+                    // The sample, broadcast over both lanes of a packed instruction, is an op_sel on the aligned register
+                    // pair it lies in.  The compiler does that for three of a chunk's four samples and builds a pair with
+                    // a v_mov_b32 for the fourth (50 issue slots per tile): the packed multiplies / fmas that take a
+                    // broadcast sample are written out.
+                    const f2 xpair_e = (e < 2) ? __builtin_shufflevector(xv, xv, 0, 1) : __builtin_shufflevector(xv, xv, 2, 3);
+                    auto mul_bcast = [&](f2 t) -> f2 {
+                        f2 p;
+                        if constexpr ((e & 1) == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "v"(xpair_e), "s"(t));
+                        else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(p) : "v"(xpair_e), "s"(t));
+                        return p;
+                    };
+                    auto fma_bcast = [&](f2 t, f2 a) -> f2 {
+                        if constexpr ((e & 1) == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a) : "v"(xpair_e), "s"(t));
+                        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(a) : "v"(xpair_e), "s"(t));
+                        return a;
+                    };
                     f2 pr[NPH];
                     // all products of the sample first, then the dependent adds
                     static_for<0, NPH>([&](auto kk) {
@@ -820,11 +829,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                         const f2 t = (f2){tapd(cc, std::integral_constant<int, 6 * e + 2 * k>{}), tapd(cc, std::integral_constant<int, 6 * e + 2 * k + 1>{})};
                         pr[k] = (f2){0.f, 0.f};
                         if constexpr (FAST) {
-                            if constexpr (va && vb) acc[k] = __builtin_elementwise_fma(t, (f2){xq, xq}, acc[k]);
+                            if constexpr (va && vb) acc[k] = fma_bcast(t, acc[k]);
                             else if constexpr (va) acc[k].x = __builtin_fmaf(t.x, xq, acc[k].x);
                             else if constexpr (vb) acc[k].y = __builtin_fmaf(t.y, xq, acc[k].y);
                         } else {
-                            if constexpr (va && vb) pr[k] = t * (f2){xq, xq};
+                            if constexpr (va && vb) pr[k] = mul_bcast(t);
                             else if constexpr (va) pr[k].x = t.x * xq;
                             else if constexpr (vb) pr[k].y = t.y * xq;
                         }
@@ -877,19 +886,23 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             }
             if constexpr (ODDH) rh[SUB][NBR - 1] = accl;
         };
+        // Which thread half takes which branch half alternates with the tile: half 0 is 7 branches, one of them unpaired
+        // (24 % more instructions than half 1's three pairs), and a workgroup's waves 0, 1 / 2, 3 land on the same
+        // SIMDs in every workgroup — without the swap two SIMDs of a CU would carry the heavy half of every tile.
+        const bool first_half = (tid < NS) != ((tile & 1) != 0);
         // sub-tile 0 is in LDS; sub-tile 1's loads are in flight under its stage 1
         XReg xr1[NXR];
         load_tile(ri, tile, 1, xr1);
-        if (tid < NS) half(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        if (first_half) half(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         else half(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
         __syncthreads();  // everyone is done reading sub-tile 0
         tile_to_lds(xr1);
         __syncthreads();
-        if (tid < NS) half(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        if (first_half) half(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
         else half(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
         APT_MARK("END stage1");
         __syncthreads();  // everyone is done reading sub-tile 1: R may land on it
-        if (tid < NS) {
+        if (first_half) {
 #pragma unroll
             for (int j = 0; j < fused_split_nbr(L, 0); ++j) {
                 P[wl * L + j] = rh[0][j];
@@ -920,298 +933,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             }
             __syncthreads();
         }
-    } else
-    {
-        // Software pipeline over chunks of CH = 2 window samples (fused_chunk()).  The taps of a chunk are ONE
-        // contiguous run of the chunk-major table (fused_branch_taps: CH x NP branch pairs, then the odd branch's
-        // taps of the chunk's samples) fetched by three scalar loads written out as inline assembly — as C++ loads the
-        // compiler merged them across chunks, waited for them on the spot and spilled what it had fetched early
-        // (454 SGPR spills in one layout, 41 in another).  SMEM returns out of order, so the only usable wait is
-        // lgkmcnt(0): chunk c waits for the loads issued one chunk ago (the wait names the tap registers as
-        // in/out operands, which is what orders their uses behind it — the compiler's own counter does not
-        // see assembly loads), issues the loads of chunk c + 1, and computes under their latency: CH * (NP + 1)
-        // packed instructions of cover in the strict modes, half that in fast mode.
-        // kModeFast runs the same pipeline with one v_pk_fma_f32 per tap pair instead of a
-        // v_pk_mul_f32 + v_pk_add_f32 (half the VALU instructions under the same tap loads).
-        // (The product kernels — 256 threads, f32 taps — all take the SPLIT form above since round 3; what is left here
-        // serves the 128 / 192-thread timing probes, whose tables the host no longer builds.)
-#ifdef APT_FUSED_CH_ALL
-        constexpr int CH = APT_FUSED_CH_ALL;
-#else
-        constexpr int CH = 2;
-#endif
-        static_assert(CH == 2 || CH == 3, "two or three window samples per chunk");
-        constexpr int NCH = (Gm::WIN + CH - 1) / CH;
-        constexpr int CHW = fused_chunk_dwords(L, CH);  // 26: 16 + 8 + 2 dwords; 40: 16 + 16 + 8
-        static_assert(CHW == (CH == 2 ? 26 : 40), "three scalar loads per chunk: 16 + 8 + 2 / 16 + 16 + 8 dwords");
-        auto xsrc = [&](int q) -> float {
-            if constexpr (sizeof(XT) == 2) return static_cast<float>(reinterpret_cast<const int16_t *>(lds)[tid * M + Gm::XSHIFT + q]);
-            else return P[tid * M + Gm::XSHIFT + q];
-        };
-        f2 acc[Gm::NP > 0 ? Gm::NP : 1];
-        float accl = 0.f;
-#pragma unroll
-        for (int pp = 0; pp < Gm::NP; ++pp) acc[pp] = (f2){0.f, 0.f};
-        typedef uint32_t u16s __attribute__((ext_vector_type(16)));
-        typedef uint32_t u8s __attribute__((ext_vector_type(8)));
-        typedef uint32_t u2s __attribute__((ext_vector_type(2)));
-        using TB = std::conditional_t<CH == 2, u8s, u16s>;
-        using TC = std::conditional_t<CH == 2, u2s, u8s>;
-        constexpr int NB_ = CH == 2 ? 8 : 16;  // dwords in tb
-        u16s ta[2];  // dwords 0..15 of the chunk in use / in flight (SGPRs)
-        TB tb[2];    // 16..23 / 16..31
-        TC tc[2];    // 24, 25 / 32..39
-        // Window samples, RW per LDS read.  Lane t reads word t*M + q: as 4-byte reads a stride of 50 words
-        // reaches 16 of the 32 banks (2-way conflict, 4.1 LDS cycles per instruction measured; 100 words: 8 banks,
-        // 8.5 cycles), and the compiler's ds_read2_b32 is two such reads.  An 8-byte read is banked over 64 words:
-        // M = 50 is conflict-free as ds_read_b64 (2.3 cycles per TWO samples), M = 100 as ds_read_b128 (4.9 cycles
-        // per FOUR) — tools/ubench/rates.hip.  (PCM16 tiles: stride M/2 words, element-wise reads.)  The read groups
-        // live in a ring of four register tuples: a chunk's samples span at most two groups, the next chunk's two more.
-        constexpr int RW = (sizeof(XT) == 4) ? ((M % 4 == 0) ? 4 : ((M % 2 == 0) ? 2 : 1)) : 1;
-        constexpr int GW = RW >= 2 ? RW : 2;  // samples per register tuple (element-wise reads fill pairs)
-        typedef float f4w __attribute__((ext_vector_type(4)));
-        using XV = std::conditional_t<GW == 4, f4w, f2>;
-        XV xw[4];
-        auto g_hi = [](int c) constexpr -> int { return c < 0 ? -1 : (CH * c + CH - 1) / GW; };  // last group chunk c touches
-        auto read_group = [&](auto gg) {
-            constexpr int g = decltype(gg)::value;
-            if constexpr (RW >= 2) {
-                // (the last group may reach past the window: inside the tile's pad)
-                xw[g & 3] = *reinterpret_cast<const XV *>(P + tid * M + Gm::XSHIFT + g * GW);
-            } else {
-#pragma unroll
-                for (int e = 0; e < GW; ++e) xw[g & 3][e] = (g * GW + e < Gm::WIN) ? xsrc(g * GW + e) : 0.f;
-            }
-        };
-        auto issue = [&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int buf = c & 1;
-            // The loads name their destination tuples in the assembly text and declare them clobbered — NOT as outputs:
-            // a value that flowed from here to the wait would be one the register allocator may copy or spill in
-            // between (it did, with three-sample chunks), i.e. while the load is in flight.  The taps become values
-            // at the wait (its outputs).  What remains possible — a compiler temporary placed in a tuple between load
-            // and wait — is what tools/isa_lint.py checks every listing for.
-            const cf2_ptr hsp = hs;
-            if constexpr (CH == 2) {
-                if constexpr (buf == 0)
-                    asm volatile("s_load_dwordx16 s[36:51], %0, %1\n\ts_load_dwordx8 s[68:75], %0, %2\n\ts_load_dwordx2 s[84:85], %0, %3"
-                                 :: "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 96)
-                                 : APT_S16(36), APT_S8(68), "s84", "s85");
-                else
-                    asm volatile("s_load_dwordx16 s[52:67], %0, %1\n\ts_load_dwordx8 s[76:83], %0, %2\n\ts_load_dwordx2 s[86:87], %0, %3"
-                                 :: "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 96)
-                                 : APT_S16(52), APT_S8(76), "s86", "s87");
-            } else {
-                if constexpr (buf == 0)
-                    asm volatile("s_load_dwordx16 s[20:35], %0, %1\n\ts_load_dwordx16 s[36:51], %0, %2\n\ts_load_dwordx8 s[52:59], %0, %3"
-                                 :: "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 128)
-                                 : APT_S16(20), APT_S16(36), APT_S8(52));
-                else
-                    asm volatile("s_load_dwordx16 s[60:75], %0, %1\n\ts_load_dwordx16 s[76:91], %0, %2\n\ts_load_dwordx8 s[92:99], %0, %3"
-                                 :: "s"(hsp), "n"(c * CHW * 4), "n"(c * CHW * 4 + 64), "n"(c * CHW * 4 + 128)
-                                 : APT_S16(60), APT_S16(76), APT_S8(92));
-            }
-            // the read groups chunk c touches that no earlier chunk has fetched
-            static_for<g_hi(c - 1) + 1, g_hi(c) + 1>([&](auto gg) { read_group(gg); });
-        };
-        // (the window samples read with the taps are operands too: the compiler then places ITS wait for that LDS
-        // read here, in front of the next chunk's loads — behind them its count-based wait, which does not know
-        // of the assembly loads, would wait for those as well)
-        auto wait_taps = [&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            constexpr int buf = c & 1;
-            u16s &ra = ta[buf];
-            TB &rb = tb[buf];
-            TC &rc = tc[buf];
-            constexpr int g0 = g_hi(c - 1) + 1, g1 = g_hi(c);  // groups fetched with this chunk's taps
-            constexpr int nnew = g1 - g0 + 1;
-            static_assert(nnew >= 0 && nnew <= 2, "at most two new read groups per chunk");
-            XV &x0 = xw[(nnew >= 1 ? g0 : 0) & 3];
-            XV &x1 = xw[(nnew >= 2 ? g0 + 1 : 0) & 3];
-#define APT_WAIT(REGS)                                                                                     \
-            if constexpr (nnew == 0) asm volatile("s_waitcnt lgkmcnt(0)" : REGS);                                    \
-            else if constexpr (nnew == 1) asm volatile("s_waitcnt lgkmcnt(0)" : REGS, "+v"(x0));                   \
-            else asm volatile("s_waitcnt lgkmcnt(0)" : REGS, "+v"(x0), "+v"(x1));
-#define APT_COMMA ,
-            // (pure outputs: the taps of this buffer exist as values from here on)
-            if constexpr (CH == 2) {
-                if constexpr (buf == 0) { APT_WAIT("={s[36:51]}"(ra) APT_COMMA "={s[68:75]}"(rb) APT_COMMA "={s[84:85]}"(rc)) }
-                else { APT_WAIT("={s[52:67]}"(ra) APT_COMMA "={s[76:83]}"(rb) APT_COMMA "={s[86:87]}"(rc)) }
-            } else {
-                if constexpr (buf == 0) { APT_WAIT("={s[20:35]}"(ra) APT_COMMA "={s[36:51]}"(rb) APT_COMMA "={s[52:59]}"(rc)) }
-                else { APT_WAIT("={s[60:75]}"(ra) APT_COMMA "={s[76:91]}"(rb) APT_COMMA "={s[92:99]}"(rc)) }
-            }
-#undef APT_WAIT
-#undef APT_COMMA
-        };
-        // window sample q
-        auto xq_of = [&](auto qq) -> float {
-            constexpr int q = decltype(qq)::value;
-            return xw[(q / GW) & 3][q % GW];
-        };
-        // window samples (q, q + 1), q even: an aligned register pair
-        auto xpair_of = [&](auto qq) -> f2 {
-            constexpr int q = decltype(qq)::value;
-            static_assert(q % 2 == 0, "aligned pair");
-            if constexpr (GW == 2) return xw[(q / 2) & 3];
-            else return (f2){xw[(q / GW) & 3][q % GW], xw[(q / GW) & 3][q % GW + 1]};
-        };
-        // dword i of the chunk's taps
-        auto tapd = [&](auto cc, auto ii) -> float {
-            constexpr int buf = decltype(cc)::value & 1, i = decltype(ii)::value;
-            if constexpr (i < 16) return __uint_as_float(ta[buf][i]);
-            else if constexpr (i < 16 + NB_) return __uint_as_float(tb[buf][i - 16]);
-            else return __uint_as_float(tc[buf][i - 16 - NB_]);
-        };
-        auto tap_pair = [&](auto cc, auto ee, auto kk) -> f2 {  // (taps of branches 2k, 2k+1 at sample e of the chunk)
-            constexpr int i = decltype(ee)::value * 2 * Gm::NP + 2 * decltype(kk)::value;
-            return (f2){tapd(cc, std::integral_constant<int, i>{}), tapd(cc, std::integral_constant<int, i + 1>{})};
-        };
-        // product of window sample (c, e) with tap pair k — kept apart from the accumulation so
-        // that a sample's products are all issued before the first dependent add (a v_pk_add
-        // right behind the v_pk_mul it reads costs a wait state)
-        auto prod = [&](auto cc, auto ee, auto kk) -> f2 {
-            constexpr int c = decltype(cc)::value, e = decltype(ee)::value, k = decltype(kk)::value;
-            constexpr int q = c * CH + e;
-            f2 p = (f2){0.f, 0.f};
-            if constexpr (q < Gm::WIN) {
-                const float xq = xq_of(std::integral_constant<int, q>{});
-                const f2 t = tap_pair(cc, ee, kk);
-                constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
-                constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
-                if constexpr (va && vb) {
-                    p = t * (f2){xq, xq};
-                } else if constexpr (va) {
-                    p.x = t.x * xq;
-                } else if constexpr (vb) {
-                    p.y = t.y * xq;
-                }
-            }
-            return p;
-        };
-        // kModeFast: acc += tap * x in one fused operation
-        auto mac = [&](auto cc, auto ee, auto kk) {
-            constexpr int c = decltype(cc)::value, e = decltype(ee)::value, k = decltype(kk)::value;
-            constexpr int q = c * CH + e;
-            if constexpr (q < Gm::WIN) {
-                const float xq = xq_of(std::integral_constant<int, q>{});
-                const f2 t = tap_pair(cc, ee, kk);
-                constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
-                constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
-                if constexpr (va && vb) {
-                    acc[k] = __builtin_elementwise_fma(t, (f2){xq, xq}, acc[k]);
-                } else if constexpr (va) {
-                    acc[k].x = __builtin_fmaf(t.x, xq, acc[k].x);
-                } else if constexpr (vb) {
-                    acc[k].y = __builtin_fmaf(t.y, xq, acc[k].y);
-                }
-            }
-        };
-        auto accum = [&](auto cc, auto ee, auto kk, f2 p) {
-            constexpr int c = decltype(cc)::value, e = decltype(ee)::value, k = decltype(kk)::value;
-            constexpr int q = c * CH + e;
-            if constexpr (q < Gm::WIN) {
-                constexpr bool va = branch_uses<L, M, T1>(2 * k, q);
-                constexpr bool vb = branch_uses<L, M, T1>(2 * k + 1, q);
-                if constexpr (va && vb) {
-                    acc[k] = acc[k] + p;
-                } else if constexpr (va) {
-                    acc[k].x = acc[k].x + p.x;
-                } else if constexpr (vb) {
-                    acc[k].y = acc[k].y + p.y;
-                }
-            }
-        };
-        // the odd branch L-1.  Its taps of the chunk's samples lie behind the pairs (fused_branch_taps): first those
-        // of the chunk's aligned sample pair (q even, q + 1) — one packed multiply then forms both products, taps and
-        // samples each in an aligned register pair — then the tap of the sample left over (three-sample chunks).  The
-        // additions run one after the other in tap order.
-        auto odd_branch = [&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            if constexpr (L & 1) {
-                constexpr int q0 = c * CH;
-                constexpr int qp = (q0 & 1) ? q0 + 1 : q0;             // the aligned pair (qp, qp + 1)
-                constexpr int qs = CH == 3 ? ((q0 & 1) ? q0 : q0 + 2) : -1;  // the single sample of a three-sample chunk
-                constexpr int io = CH * 2 * Gm::NP;                      // dword of the pair's first tap; the single's: io + 2
-                auto use = [](int q) constexpr { return q >= 0 && q < Gm::WIN && branch_uses<L, M, T1>(L - 1, q); };
-                constexpr bool u0 = use(qp), u1 = use(qp + 1), us = use(qs);
-                const f2 t = (f2){tapd(cc, std::integral_constant<int, io>{}), tapd(cc, std::integral_constant<int, io + 1>{})};
-                auto single = [&]() {
-                    if constexpr (us) {
-                        const float ts = tapd(cc, std::integral_constant<int, io + 2>{});
-                        const float xs = xq_of(std::integral_constant<int, us ? qs : 0>{});
-                        if constexpr (FAST) accl = __builtin_fmaf(ts, xs, accl);
-                        else accl = accl + ts * xs;
-                    }
-                };
-                auto pair = [&]() {
-                    if constexpr (u0 || u1) {
-                        const f2 xp = xpair_of(std::integral_constant<int, qp>{});
-                        if constexpr (FAST) {
-                            if constexpr (u0) accl = __builtin_fmaf(t.x, xp.x, accl);
-                            if constexpr (u1) accl = __builtin_fmaf(t.y, xp.y, accl);
-                        } else if constexpr (u0 && u1) {
-                            const f2 po = t * xp;
-                            accl = accl + po.x;
-                            accl = accl + po.y;
-                        } else if constexpr (u0) {
-                            accl = accl + t.x * xp.x;
-                        } else {
-                            accl = accl + t.y * xp.y;
-                        }
-                    }
-                };
-                // ascending tap order: the single sample comes first when the chunk starts on an odd sample
-                if constexpr (CH == 3 && (q0 & 1)) {
-                    single();
-                    pair();
-                } else {
-                    pair();
-                    single();
-                }
-            }
-        };
-        issue(std::integral_constant<int, 0>{});
-        static_for<0, NCH>([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            wait_taps(cc);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (c + 1 < NCH) issue(std::integral_constant<int, c + 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FAST) {
-                static_for<0, CH>([&](auto ee) {
-                    static_for<0, Gm::NP>([&](auto kk) { mac(cc, ee, kk); });
-                });
-                odd_branch(cc);
-            } else {
-                static_for<0, CH>([&](auto ee) {
-                    f2 pr[Gm::NP > 0 ? Gm::NP : 1];
-                    static_for<0, Gm::NP>([&](auto kk) { pr[decltype(kk)::value] = prod(cc, ee, kk); });
-                    static_for<0, Gm::NP>([&](auto kk) { accum(cc, ee, kk, pr[decltype(kk)::value]); });
-                });
-                odd_branch(cc);
-            }
-            // (pins the accumulators here: their only consumer is a block further down, and the compiler would sink
-            // the ends of the chains — and keep those chunks' taps alive in spilled registers — to it)
-            static_for<0, Gm::NP>([&](auto kk) {
-                f2 &a = acc[decltype(kk)::value];
-                asm volatile("" : "+v"(a));
-            });
-            asm volatile("" : "+v"(accl));
-            __builtin_amdgcn_sched_barrier(0);
-        });
-#pragma unroll
-        for (int pp = 0; pp < Gm::NP; ++pp) {
-            r[2 * pp] = acc[pp].x;
-            r[2 * pp + 1] = acc[pp].y;
-        }
-        if constexpr (L & 1) r[L - 1] = accl;
-        APT_MARK("END stage1");
-        if (!interior) {
-#pragma unroll
-            for (int b = 0; b < L; ++b)
-                if (kq + b < k_lo || kq + b >= k_hi) r[b] = 0.f;
-        }
+    } else {
+        // (Rounds 1-3 ran an unsplit form here — every thread all 13 branches of its own window, 256 windows per
+        // 51.5 KB tile at 48 kHz, 128 at 96 kHz, two- / three-sample chunks — until the SPLIT form above made the
+        // tile a quarter of that per thread: git history)
+        static_assert(Gm::SPLIT || F16, "the specialised kernels are 256-thread workgroups");
     }
     APT_MARK("BEGIN r_store");
     if constexpr (!Gm::SPLIT) {  // (SPLIT: R went through LDS already)

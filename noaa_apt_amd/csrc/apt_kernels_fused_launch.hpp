@@ -11,23 +11,20 @@ constexpr int kModeStrict = 0;
 constexpr int kModeF16Taps = 1;
 constexpr int kModeFast = 2;
 
-// Window samples per stage-1 chunk (one scalar-load wait per chunk) of the specialised kernels, and the dwords of a
-// chunk's run in the tap table: CH x (l/2) branch pairs, then the odd branch's taps of the chunk — those of its
-// aligned sample pair (q even, q + 1) first, then (CH == 3) that of the sample left over — padded so that three scalar
-// loads fetch it (26 = 16 + 8 + 2 dwords; 40 = 16 + 16 + 8).  Host (table builder) and device agree through these.
-// m >= 100 (the 96 kHz kernels): 4 = the SPLIT layout below.  (Until round 3 those kernels were 128-thread
-// workgroups — 1.5 waves per SIMD under their 52 KB input tile — with three-sample chunks of all 13 branches.)
+// Window samples per stage-1 chunk (one scalar-load wait per chunk) of the specialised kernels; host (table builder)
+// and device agree through this and the layout functions below.  (Rounds 1-3: two samples x all 13 branches per chunk
+// at 48 kHz, three at 96 kHz, every thread a whole window — 51.5 KB of input tile per 256 / 128 threads.)
 constexpr int fused_chunk(int m, int mode)
 {
-    return 4;  // the SPLIT layout below (round 3: every specialised kernel with f32 taps)
+    return 4;  // kSplitChunk
 }
-constexpr int fused_chunk_dwords(int l, int ch) { return ch == 2 ? 4 * (l / 2) + 2 : 6 * (l / 2) + 4; }
 
-// SPLIT stage 1 (m >= 100: an input tile of 256 windows would be 102 KB of LDS).  A 256-thread workgroup runs stage 1
-// over TWO sub-tiles of 128 windows, one after the other through the same LDS; in each, thread (half h, window a)
-// computes the branches [b0, b0 + nbr) of window a only — h = 0: the first (l + 1) / 2 branches, h = 1: the rest —
-// so that all 256 threads (four waves, three workgroups per CU: 3 waves per SIMD) share a 52 KB tile.  The stages
-// behind it see 256 threads x l outputs as in the 48 kHz kernels.  A half's taps: its own chunk-major table over
+// SPLIT stage 1.  An input tile of 256 windows is 51.5 KB of LDS at 48 kHz (three workgroups per CU) and would be 102 KB
+// at 96 kHz.  A 256-thread workgroup instead runs stage 1 over TWO sub-tiles of 128 windows, one after the other through
+// the same LDS; in each, thread (half h, window a) computes the branches [b0, b0 + nbr) of window a only — h = 0: the
+// first (l + 1) / 2 branches, h = 1: the rest.  All 256 threads then share a 26 KB (48 kHz) / 52 KB (96 kHz) tile:
+// five workgroups per CU at 48 kHz (the work-rate stages' 28.5 KB set the footprint), three at 96 kHz where the
+// 128-thread workgroups of rounds 1-3 reached 1.5 waves per SIMD.  The stages behind it see 256 threads x l outputs.  A half's taps: its own chunk-major table over
 // the window samples [w0, w0 + 4 nch) its branches use, w0 a multiple of 4 (16-byte LDS reads); a chunk is 4
 // samples x 3 branch pairs (24 dwords) followed by the odd branch's 4 taps (half 0 only): 28 = 16 + 8 + 4 dwords.
 constexpr int kSplitChunk = 4, kSplitChunkDwords = 28;
@@ -90,14 +87,12 @@ void fused_launch_phase512_std_fast_f32(const FusedLaunch &a);
 void fused_launch_phase512_std_fast_i16(const FusedLaunch &a);
 #ifdef APT_WITH_PROBES
 // timing probes (make PROBES=1; APTGPU_PROBE_STOP=1..7; sources under tools/probes/): the fast 48 kHz f32
-// kernel cut off after a stage (1..5), or complete with 128 / 192-thread workgroups (6, 7)
+// kernel cut off after a stage (1..5)
 void fused_launch_probe1(const FusedLaunch &a);
 void fused_launch_probe2(const FusedLaunch &a);
 void fused_launch_probe3(const FusedLaunch &a);
 void fused_launch_probe4(const FusedLaunch &a);
 void fused_launch_probe5(const FusedLaunch &a);
-void fused_launch_probe6(const FusedLaunch &a);
-void fused_launch_probe7(const FusedLaunch &a);
 // ... and the strict kernel cut off after a stage (11..15)
 void fused_launch_probe11(const FusedLaunch &a);
 void fused_launch_probe12(const FusedLaunch &a);
