@@ -53,9 +53,6 @@ namespace {
 #ifndef APT_FUSED_STOP
 #define APT_FUSED_STOP 0
 #endif
-#ifndef APT_FUSED_MIN_WAVES
-#define APT_FUSED_MIN_WAVES 3
-#endif
 #ifndef APT_FUSED_PERSIST
 #define APT_FUSED_PERSIST 0
 #endif
@@ -100,7 +97,7 @@ __host__ __device__ constexpr int branch_phase(int b)  // p_b = c_b*L - b*M
 }
 
 // XB: bytes per input sample in the LDS tile (4: f32 Signal; 2: PCM16 kept as int16 — exact, and
-// half the tile, so the other regions set the footprint and 4 instead of 3 workgroups fit a CU)
+// half the tile)
 // M == 0 selects the table-driven stage 1 (TABLE mode, see k_fused): the resampling factors, tap count and
 // input tile are then run-time quantities (FusedParams::tab) and only the work-rate geometry is static.
 template <int L, int M, int T1, int T2, int PW, int NTHR, int XB = 4, bool F16TAPS = false>
@@ -215,13 +212,13 @@ __host__ __device__ constexpr bool sync_plus(int j)
 // pairs — half a v_pk_mul_f32 + half a v_pk_add_f32 (or half a v_pk_fma_f32), as in the specialised kernels.
 // Each output still accumulates its taps in ascending order: bit-identical in strict mode.
 // One workgroup per tile: blockIdx.y picks the recording, whose tiles are blockIdx.x < ceil(w / OWN_K).
-// The tile's input goes through registers (all loads issued before the first LDS write).  (A
-// persistent form that walked the tiles with a fixed grid and kept the NEXT tile's input in
-// registers while the stages ran was measured and dropped: 0-5 % slower in every mode, see
-// DESIGN.md §5.1 — the kernel is bound by VALU issue at three waves per SIMD, not by exposed loads.)
+// The tile's input goes through registers (all loads issued before the first LDS write).  The specialised kernels
+// (M > 0, f32 taps) run stage 1 in the SPLIT form — two sub-tiles of 128 windows through the same LDS, each thread
+// half a window's branches (apt_kernels_fused_launch.hpp) — so that the work-rate stages' 28.5 KB, not the input
+// tile, set the LDS footprint at 48 kHz: five workgroups per CU (<= 96 VGPRs), three at 96 kHz.  (A persistent form
+// that walked the tiles with a fixed grid and kept the NEXT tile's input in registers while the stages ran was measured
+// in rounds 2 and 3 and dropped: slower in every mode)
 template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
-// (104 VGPRs: three workgroups per CU then leave 200 registers per SIMD lane free, which is what lets
-// the picker's kernels of the previous call — one 1024-thread workgroup among them — run beside this one)
 __global__ void __launch_bounds__(NTHR, M == -1 ? ((NTHR > 256 ? 2 : 3) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs) or two 512-thread (<= 128) workgroups per CU */
                                      : M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
                                                /* specialised: as many workgroups as the CU's 160 KB of LDS hold (48 kHz SPLIT: 5, 96 kHz: 3) */
@@ -1521,7 +1518,7 @@ void launch_fused_args(const FusedLaunch &a)
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const uint64_t total = static_cast<uint64_t>(tiles) * c.count;  // (< 2^32: kMaxCall recordings of < 2^26 tiles)
-        const unsigned wgs = static_cast<unsigned>(std::min<uint64_t>(total, static_cast<uint64_t>(cus) * APT_FUSED_MIN_WAVES));
+        const unsigned wgs = static_cast<unsigned>(std::min<uint64_t>(total, static_cast<uint64_t>(cus) * Gm::WGS_PER_CU));
         hipLaunchKernelGGL(kern, dim3(wgs), dim3(NTHR), lds, a.s, c, a.prm);
         return;
     }
