@@ -440,8 +440,11 @@ def main():
             ref_host = apt.decode(apt.Context(device=local_rank, mode=mode), settings, host_recs[0], rate, True)
             for key, inputs, workers in (("host_fed_f32", host_recs, 1), ("host_fed_f32_two_workers", host_recs, 2),
                                          ("host_fed_pcm16_wav", host_wavs, 1), ("host_fed_pcm16_wav_two_workers", host_wavs, 2)):
-                apt.decode_batch(apt.Context(device=local_rank, mode=mode), settings, inputs[:2 * B], rate, True,
-                                 devices=(local_rank,) * workers, recordings_per_call=B)  # warm-up (host pages, session cache)
+                # warm-up: the whole list once (host pages touched; every worker has leased — i.e. created — its own
+                # session: with a shorter list one worker can finish before the other starts and share its session,
+                # and the second session is then built inside the timed call)
+                apt.decode_batch(apt.Context(device=local_rank, mode=mode), settings, inputs, rate, True,
+                                 devices=(local_rank,) * workers, recordings_per_call=B)
                 got, hres, hst = apt.decode_batch(apt.Context(device=local_rank, mode=mode), settings, inputs, rate, True,
                                                   devices=(local_rank,) * workers, recordings_per_call=B,
                                                   return_stats=True)
@@ -457,6 +460,7 @@ def main():
                     "pcie_GBps": round(moved / hst.seconds / 1e9, 2),
                     "frac_of_pcie_peak": round(moved / hst.seconds / 1e9 / PCIE_GBS, 4),
                     "rows_identical_to_one_shot_decode": same0,
+                    "session_cache_after": list(apt.cache_info()),  # (idle sessions, their device bytes)
                 }
             # (4) the one-shot aptgpu_decode() of recording 0 (plan, buffers and staging from the session cache)
             for _ in range(3):
