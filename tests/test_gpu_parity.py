@@ -797,3 +797,33 @@ def test_plan_decode_captured_in_a_hip_graph(oracle):
                     continue
                 assert_bitexact(d_rows[i][:want.size].cpu().numpy(), want, f"graph replay {rep} rec {i}")
     plan.close()
+
+
+# ------------------------------------------------------------------ SPLIT stage 1 (48 / 96 kHz front ends)
+@pytest.mark.parametrize("rate", [48000, 96000])
+def test_split_stage1_recording_ends_around_the_sub_tile_boundaries(oracle, rate):
+    """The specialised front ends run stage 1 over two sub-tiles of 128 windows (apt_kernels_fused_launch.hpp); a
+    tile owns 244 windows = 244 m input samples.  Recordings that end just inside a tile, one window either side of
+    the sub-tile boundary, deep in the second sub-tile, on the tile's last sample and on its boundary — as one ragged
+    batch (f32 Signals and PCM16 WAV images), so that the last tile's loads, its zero fill and the edge copies of the
+    stages behind see every case.  Bit-exact, sync and no-sync."""
+    from noaa_apt_amd.testing.wavfile import make_wav
+    m = rate * 13 // 12480            # input samples per window (l = 13 outputs)
+    assert m in (50, 100)
+    tile = 244 * m
+    tiles = (12 * rate) // tile       # ~12 s: more than the 10 rows decode() needs
+    full = synth_apt(rate, 14, seed=77 + rate % 7)
+    ends = [3 * m - 7, 125 * m, 128 * m - 1, 129 * m + 1, 131 * m + m // 2, 200 * m + 17, tile - 1, tile]
+    recs = [full[:tiles * tile + e] for e in ends]
+    for sync in (True, False):
+        wants = [oracle.decode(r, rate, sync) for r in recs]
+        got = apt.decode_batch(apt.Context(device=0), apt.Settings(), recs, apt.Rate.hz(rate), sync, recordings_per_call=len(recs))
+        for e, g, w in zip(ends, got, wants):
+            assert not isinstance(g, Exception), (e, g)
+            assert_bitexact(g, w, f"{rate} Hz, recording ends {e} samples into a tile, sync={sync}")
+    wavs = [make_wav(r.astype(np.int16), rate) for r in recs]
+    wants = [oracle.decode(r.astype(np.int16).astype(f32), rate, True) for r in recs]
+    got = apt.decode_batch(apt.Context(device=0), apt.Settings(), wavs, apt.Rate.hz(rate), True, recordings_per_call=3)
+    for e, g, w in zip(ends, got, wants):
+        assert not isinstance(g, Exception), (e, g)
+        assert_bitexact(g, w, f"{rate} Hz PCM16, recording ends {e} samples into a tile")
