@@ -17,7 +17,8 @@ MODE_FP16_TAPS = 2
 MODE_FAST = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libaptgpu.so")
+# (APTGPU_LIB: tools/ only — the probe build of `make -C noaa_apt_amd/csrc probe-lib` for timing experiments)
+_LIB = os.environ.get("APTGPU_LIB") or os.path.join(_HERE, "libaptgpu.so")
 _f32p = C.POINTER(C.c_float)
 _u64p = C.POINTER(C.c_uint64)
 _i8p = C.POINTER(C.c_int8)

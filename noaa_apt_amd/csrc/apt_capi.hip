@@ -294,6 +294,14 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
             bool ok = false;
             ~PoisonOnThrow() { if (!ok && l) l.poison(); }
         } guard{lease};
+        hipStream_t s_for_errors = nullptr;
+        // decode()'s own per-recording errors (decode.rs:79-83,112-118,172-176) leave the GPU state perfectly valid:
+        // wait for what the call enqueued and hand the session back to the cache — only a HIP failure or an unknown
+        // exception poisons it
+        auto decode_error = [&](const char *msg) -> Error {
+            if (s_for_errors == nullptr || hipStreamSynchronize(s_for_errors) == hipSuccess) guard.ok = true;
+            return Error{ErrorKind::Internal, msg};
+        };
         PlanPtr own_plan;
         aptgpu_plan *plan = nullptr;
         if (cached) {
@@ -314,6 +322,7 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
         }
         if (plan->spr == 0) throw Error{ErrorKind::Invalid, "work_rate too small"};
         hipStream_t s = plan->stream;  // a single-stream plan: every call runs on streams[0] == stream
+        s_for_errors = s;
         const uint64_t w = plan->work_len_for(n);
         const uint64_t out_cap =
             sync ? (plan->spr ? w / plan->spr + 2 : 2) * 2080u : plan->out_len_nosync(w) + 16;
@@ -365,7 +374,7 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
         // dsp.rs:96 / :106 — the resample filter, then the resample steps
         step(&ctx, steps, "resample_filter", 1, plan->taps_resample.data(),
              plan->taps_resample.size(), 0);
-        if (w < 10ull * plan->spr) throw Error{ErrorKind::Internal, kTooShort};  // decode.rs:79-83
+        if (w < 10ull * plan->spr) throw decode_error(kTooShort);  // decode.rs:79-83
         if (steps) {
             if (plan->l > 1) {
                 // dsp.rs:281-285: expanded signal is empty unless export_resample_filtered
@@ -392,14 +401,14 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
         aptgpu_result res{};
         if (sync) {
             status(&ctx, 0.5f, "Syncing");  // decode.rs:107
-            if (!plan->work_is_multiple) throw Error{ErrorKind::Internal, kNotMultiple};
+            if (!plan->work_is_multiple) throw decode_error(kNotMultiple);
             if (steps) {
                 apt::Signal c = download(sl.correlation.ptr, w - plan->n_sync_taps, s);
                 step(&ctx, steps, "sync_correlation", 0, c.data(), c.size(), 0);
             }
             if (aptgpu_plan_results(plan, 1, &res) != APTGPU_OK)
                 throw Error{ErrorKind::Hip, "could not read the result record"};
-            if (res.n_sync < 5) throw Error{ErrorKind::Internal, kFewSync};  // decode.rs:112-118
+            if (res.n_sync < 5) throw decode_error(kFewSync);  // decode.rs:112-118
             if (steps) {
                 // "sync_result": the aligned rows at work_rate (decode.rs:150)
                 apt::DeviceBuffer<float> d_al;
@@ -451,9 +460,7 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
             }
         }
         if (res.status != APTGPU_OK)
-            throw Error{ErrorKind::Internal, res.reason == 2 ? kFewSync
-                                             : res.reason == 3 ? kNotMultiple
-                                                               : kTooShort};
+            throw decode_error(res.reason == 2 ? kFewSync : res.reason == 3 ? kNotMultiple : kTooShort);
 
         float *rows = host_alloc<float>(res.n_out);
         if (res.n_out) {

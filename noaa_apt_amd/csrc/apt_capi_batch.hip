@@ -38,7 +38,7 @@ namespace apt::capi {
 // ------------------------------------------------------------------ session cache
 bool SessionKey::operator==(const SessionKey &o) const
 {
-    return device == o.device && mode == o.mode && rate == o.rate && sync == o.sync && per_call == o.per_call &&
+    return device == o.device && mode == o.mode && rate == o.rate && sync == o.sync && per_call == o.per_call && depth == o.depth &&
            settings.work_rate == o.settings.work_rate &&
            std::memcmp(&settings.resample_atten, &o.settings.resample_atten, sizeof(float)) == 0 &&
            std::memcmp(&settings.resample_delta_freq, &o.settings.resample_delta_freq, sizeof(float)) == 0 &&
@@ -83,10 +83,28 @@ void Session::ensure_set(int k, uint64_t in_bytes, uint64_t out_cap)
         s.out.resize(B);
     }
     if (!s.h_res) apt::hip_check(hipHostMalloc(reinterpret_cast<void **>(&s.h_res), B * sizeof(apt::gpu::Result), hipHostMallocDefault), "hipHostMalloc");
+    // (an allocation that fails for lack of device memory while idle sessions hold some: drop them, try once more)
+    auto alloc = [&](auto &buf, uint64_t count) {
+        try {
+            buf.alloc(count);
+        } catch (const Error &e) {
+            buf.count = 0;
+            if (e.kind != ErrorKind::Hip || e.message.find("out of memory") == std::string::npos) throw;
+            (void)hipGetLastError();
+            session_cache_clear();
+            try {
+                buf.alloc(count);
+            } catch (...) {
+                buf.count = 0;
+                throw;
+            }
+        }
+    };
     if (in_bytes > s.in_bytes) {
         for (auto &b : s.in) {
             device_bytes -= b.count;
-            b.alloc(in_bytes);
+            b.release();
+            alloc(b, in_bytes);
             device_bytes += in_bytes;
         }
         s.in_bytes = in_bytes;
@@ -94,7 +112,8 @@ void Session::ensure_set(int k, uint64_t in_bytes, uint64_t out_cap)
     if (out_cap > s.out_cap) {
         for (auto &b : s.out) {
             device_bytes -= b.count * sizeof(float);
-            b.alloc(out_cap);
+            b.release();
+            alloc(b, out_cap);
             device_bytes += out_cap * sizeof(float);
         }
         if (s.h_rows) (void)hipHostFree(s.h_rows);  // (re-created at the new size if it is ever needed)
@@ -119,11 +138,19 @@ struct Cache {
     std::list<std::unique_ptr<Session>> idle;  // most recently used first
     uint64_t clock = 0;
     static constexpr size_t kMaxIdle = 8;
+    // APTGPU_SESSION_CACHE_MB (0 disables the cache); unset: a quarter of the current device's memory — idle sessions
+    // are invisible to whatever else allocates on the GPU in this process (torch, another library), so they may
+    // not sit on most of it
     static uint64_t budget_bytes()
     {
-        static const uint64_t v = [] {
-            const char *e = std::getenv("APTGPU_SESSION_CACHE_MB");
-            return (e ? static_cast<uint64_t>(std::strtoull(e, nullptr, 10)) : 65536ull) << 20;
+        static const uint64_t v = []() -> uint64_t {
+            if (const char *e = std::getenv("APTGPU_SESSION_CACHE_MB")) return static_cast<uint64_t>(std::strtoull(e, nullptr, 10)) << 20;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) {
+                (void)hipGetLastError();
+                return 16384ull << 20;
+            }
+            return static_cast<uint64_t>(total_b) / 4u;
         }();
         return v;
     }
@@ -136,8 +163,18 @@ Cache &cache()
 
 uint64_t plan_device_bytes(const aptgpu_plan &p)
 {
-    // the workspace is dominated by four work-rate arrays per slot
-    return static_cast<uint64_t>(p.slots.size()) * p.max_work_len * 4u * sizeof(float);
+    // what plan_create allocated, buffer by buffer (buffers a slot only gets on first use — the unfused kernels'
+    // intermediates, the WAV staging, the image scratch — are counted when the session comes back to the cache)
+    uint64_t b = 0;
+    auto add = [&](const auto &buf) { b += static_cast<uint64_t>(buf.count) * sizeof(*buf.ptr); };
+    for (const auto &sl : p.slots) {
+        add(sl.resampled); add(sl.demodulated); add(sl.filtered); add(sl.correlation); add(sl.bits); add(sl.peaks);
+        add(sl.gm); add(sl.words); add(sl.nanw); add(sl.slot_nt); add(sl.slot_cnt); add(sl.flags); add(sl.orbit_ws);
+        add(sl.image_ws); add(sl.ingest);
+    }
+    add(p.d_taps_resample); add(p.d_taps_lowpass); add(p.d_taps_branch); add(p.d_taps_lowpass_pairs); add(p.d_taps_any);
+    add(p.d_taps_f16); add(p.d_slots); add(p.d_results); add(p.d_image_results);
+    return b;
 }
 
 }  // namespace
@@ -156,19 +193,32 @@ SessionLease session_acquire(const SessionKey &key, uint64_t max_n)
         }
     }
     // a new one, with headroom so that the next, slightly longer recording still fits
-    auto s = std::make_unique<Session>();
-    s->key = key;
-    s->max_n = max_n + max_n / 8 + 4096;
-    apt::hip_check(hipSetDevice(key.device), "hipSetDevice");
-    aptgpu_context ctx{};
-    ctx.device = key.device;
-    ctx.mode = key.mode;
-    s->plan.reset(apt::plan_create(&ctx, key.settings, key.rate, key.sync, s->max_n, key.per_call,
-                                   key.per_call > 1 ? Session::kSets : 1));
-    apt::hip_check(hipStreamCreateWithFlags(&s->up, hipStreamNonBlocking), "hipStreamCreate");
-    apt::hip_check(hipStreamCreateWithFlags(&s->down, hipStreamNonBlocking), "hipStreamCreate");
-    s->device_bytes = plan_device_bytes(*s->plan);
-    return SessionLease(std::move(s));
+    auto build = [&]() {
+        auto s = std::make_unique<Session>();
+        s->key = key;
+        s->max_n = max_n + max_n / 8 + 4096;
+        apt::hip_check(hipSetDevice(key.device), "hipSetDevice");
+        aptgpu_context ctx{};
+        ctx.device = key.device;
+        ctx.mode = key.mode;
+        // `depth` calls in flight: a batch worker pipelines Session::kSets calls whatever `per_call` is — with one
+        // stream and one slot per recording, decode(c+1) would write the result record download(c) is still copying
+        s->plan.reset(apt::plan_create(&ctx, key.settings, key.rate, key.sync, s->max_n, key.per_call, std::max(1, key.depth)));
+        apt::hip_check(hipStreamCreateWithFlags(&s->up, hipStreamNonBlocking), "hipStreamCreate");
+        apt::hip_check(hipStreamCreateWithFlags(&s->down, hipStreamNonBlocking), "hipStreamCreate");
+        s->plan_bytes = plan_device_bytes(*s->plan);
+        s->device_bytes = s->plan_bytes;
+        return s;
+    };
+    try {
+        return SessionLease(build());
+    } catch (const Error &e) {
+        // out of device memory while idle sessions hold some: drop them and try once more
+        if (e.kind != ErrorKind::Hip || e.message.find("out of memory") == std::string::npos) throw;
+        (void)hipGetLastError();
+        session_cache_clear();
+        return SessionLease(build());
+    }
 }
 
 SessionLease::~SessionLease()
@@ -180,6 +230,9 @@ SessionLease::~SessionLease()
     }
     Cache &c = cache();
     std::list<std::unique_ptr<Session>> evicted;  // destroyed outside the lock (their destructors synchronise)
+    // (slots grow buffers on first use: account what the plan holds now)
+    s_->device_bytes += plan_device_bytes(*s_->plan) - s_->plan_bytes;
+    s_->plan_bytes = plan_device_bytes(*s_->plan);
     {
         std::lock_guard<std::mutex> lock(c.mu);
         s_->last_used = ++c.clock;
@@ -285,6 +338,7 @@ void worker(Shared &sh, int device, std::vector<Item> items)
         key.rate = sh.rate;
         key.sync = sh.sync;
         key.per_call = B;
+        key.depth = Session::kSets;
         key.settings = *sh.settings;
         key.settings.export_wav = 0;
         key.settings.export_resample_filtered = 0;

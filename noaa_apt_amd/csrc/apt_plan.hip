@@ -607,6 +607,7 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
         for (int i : live)
             set_result(cur, d_results.ptr + slot0 + i, Result{APTGPU_ERR_INTERNAL, 3, 0, 0, wlen[static_cast<size_t>(i)], 0});
     } else if (sync) {
+        bool gather_wanted = true;
         // 4. find_sync (decode.rs:204-263): terminal flags, orbit
         if (mode == APTGPU_MODE_GENERIC) {
             // reference-shaped picker: full sliding-window terminals + sequential orbit
@@ -622,25 +623,30 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
                 });
             }
         } else {
-            // (APTGPU_DEBUG_SKIP, a bit mask — 1 words + slots, 2 orbit, 4 gather: timing experiments only, the results
-            // are then garbage: what each kernel behind the front end costs a pipelined step)
+            // (probe builds only — make PROBES=1, or libaptgpu_probe.so of `make probe-lib` — APTGPU_DEBUG_SKIP, a bit mask: 1 words + slots, 2 orbit,
+            // 4 gather.  Timing experiments: what each kernel behind the front end costs a pipelined step; the results
+            // are then garbage, so a product build does not even read the variable.)
+#if defined(APT_WITH_PROBES) || defined(APT_DEBUG_SKIP)
             static const int skip = [] {
                 const char *e = std::getenv("APTGPU_DEBUG_SKIP");
                 return e ? std::atoi(e) : 0;
             }();
+#else
+            constexpr int skip = 0;
+#endif
             for_chunks(live, [&](const CallArgs &c, uint64_t max_w, uint32_t) {
                 if (!(skip & 1))
                     timed("sync_nodes", [&] { sync_nodes(cur, c, d_slots.ptr, max_w, pw, spr, md, use_fused && fused_fast, !use_fused); });
                 if (!(skip & 2))
                     timed("sync_orbit", [&] { sync_orbit(cur, c, d_slots.ptr, spr, md, pw, picker_force); });
             });
-            if (skip & 4) goto chain_done;
+            gather_wanted = !(skip & 4);
         }
         // 5. aligned rows + final /pw (decode.rs:120-134,158-159)
-        for_chunks(live, [&](const CallArgs &c, uint64_t, uint32_t max_cap) {
-            timed("gather_rows", [&] { gather_rows_call(cur, c, d_slots.ptr, spr, pw, max_cap); });
-        });
-    chain_done:;
+        if (gather_wanted)
+            for_chunks(live, [&](const CallArgs &c, uint64_t, uint32_t max_cap) {
+                timed("gather_rows", [&] { gather_rows_call(cur, c, d_slots.ptr, spr, pw, max_cap); });
+            });
     } else {
         // decode.rs:135-159 — crop to whole rows, resample_with_filter(NoFilter)
         for (int i : live) {

@@ -8,8 +8,9 @@
 // it for one (device, settings, input rate, sync, mode, recordings per call); aptgpu_decode, aptgpu_decode_wav
 // and aptgpu_decode_batch[_wav] lease one from the cache for the duration of a call (one user at a time — a
 // second concurrent caller with the same key gets a second Session) and hand it back; idle sessions are kept
-// least-recently-used first up to kMaxIdle and APTGPU_SESSION_CACHE_MB of device memory (default 65536;
-// 0 disables the cache), and aptgpu_cache_clear() drops them all.
+// least-recently-used first up to kMaxIdle and APTGPU_SESSION_CACHE_MB of device memory (default: a quarter of
+// the device's memory; 0 disables the cache; a session that cannot be built for lack of device memory empties
+// the cache and tries once more), and aptgpu_cache_clear() drops them all.
 #pragma once
 
 #include <cstdint>
@@ -26,6 +27,7 @@ struct SessionKey {
     uint32_t rate = 0;
     bool sync = true;
     int per_call = 1;
+    int depth = 1;  // calls in flight the plan is built for: 1 (aptgpu_decode: one stream, `plan->stream`), kSets (batch workers)
     aptgpu_settings settings{};  // the five fields decode() reads (export flags zeroed)
     bool operator==(const SessionKey &o) const;
 };
@@ -53,7 +55,8 @@ struct Session {
     hipStream_t up = nullptr, down = nullptr;  // H2D and D2H copy streams (the link is full duplex)
     static constexpr int kSets = 3;            // call k decodes while k+1 (and k+2) upload and k-1 downloads
     IoSet sets[kSets];
-    uint64_t device_bytes = 0;  // what the session holds in HBM (cache accounting)
+    uint64_t device_bytes = 0;  // what the session holds in HBM (cache accounting): the plan's buffers + the sets'
+    uint64_t plan_bytes = 0;    // ... of which the plan's (re-counted when the session returns to the cache)
     uint64_t last_used = 0;
 
     ~Session();
