@@ -86,6 +86,8 @@ void aptgpu_plan_destroy(aptgpu_plan *plan)
     if (plan->ev_user) (void)hipEventDestroy(plan->ev_user);
     for (hipStream_t st : plan->streams) (void)hipStreamDestroy(st);
     for (hipEvent_t ev : plan->ev_front) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : plan->ev_pre) (void)hipEventDestroy(ev);
+    if (plan->front_stream) (void)hipStreamDestroy(plan->front_stream);
     delete plan;
 }
 

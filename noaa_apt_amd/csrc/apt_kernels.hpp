@@ -187,10 +187,12 @@ bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, int mode, bool 
 bool fused_any_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
 uint32_t fused_any_table_floats(uint32_t l, uint32_t t1);
 void fused_any_table(uint32_t l, const float *coeff, uint32_t t1, float *table);  // host
-bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
-                         const void *x, bool pcm16, uint64_t n, const float *table, const float *h2,
-                         const float *h2p /* fused_lowpass_pairs */, float cosphi2, float sinphi, float inv_sinphi, float *f_out,
-                         GroupMax *gm_out, uint64_t w, uint64_t n_corr);
+// One launch over the recordings of `call` (f32 Signals, or — pcm16 — mono int16 payloads at even addresses): F into
+// the slots' filtered buffers and, if want_gm, the per-group maxima of the sync correlation into their gm buffers.
+bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, bool pcm16,
+                         const CallArgs &call, const SlotPtrs *d_slots, uint64_t max_w, const float *table,
+                         const float *h2, const float *h2p /* fused_lowpass_pairs */, float cosphi2, float sinphi,
+                         float inv_sinphi, bool want_gm);
 
 // ---- parallel peak picker (apt_kernels_sync.hip) ------------------------------------
 // Each launch covers the recordings of one call (CallArgs by value, slot table in HBM).

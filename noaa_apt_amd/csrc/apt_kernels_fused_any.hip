@@ -150,26 +150,25 @@ void fused_any_table(uint32_t l, const float *coeff, uint32_t t1, float *table)
         }
 }
 
-bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw,
-                         const void *x, bool pcm16, uint64_t n, const float *table, const float *h2,
-                         const float *h2p, float cosphi2, float sinphi, float inv_sinphi, float *f_out,
-                         GroupMax *gm_out, uint64_t w, uint64_t n_corr)
+bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, bool pcm16,
+                         const CallArgs &call, const SlotPtrs *d_slots, uint64_t max_w, const float *table,
+                         const float *h2, const float *h2p, float cosphi2, float sinphi, float inv_sinphi, bool want_gm)
 {
     Candidate c;
     AnyGeom g;
     size_t lds;
+    if (call.count == 0) return true;
     if (!choose(l, m, t1, t2, pw, &c, &g, &lds)) return false;
-    if (pcm16 && (reinterpret_cast<uintptr_t>(x) & 1u)) return false;
+    if (pcm16)
+        for (uint32_t i = 0; i < call.count; ++i)
+            if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 1u) return false;
     const int prof = (t2 == 37 && pw == 3) ? 1 : (t2 == 43 && pw == 4) ? 2 : (t2 == 61 && pw == 5) ? 3 : 0;
     if (c.nthr == 256 && c.kpt == 8)
-        fused_any_launch_256x8(s, x, pcm16, n, table, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, gm_out, w,
-                               n_corr, g, lds, prof);
+        fused_any_launch_256x8(s, call, d_slots, max_w, pcm16, table, h2, h2p, cosphi2, sinphi, inv_sinphi, want_gm, g, lds, prof);
     else if (c.nthr == 1024 && c.kpt == 8)
-        fused_any_launch_1024x8(s, x, pcm16, n, table, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, gm_out, w,
-                                n_corr, g, lds, prof);
+        fused_any_launch_1024x8(s, call, d_slots, max_w, pcm16, table, h2, h2p, cosphi2, sinphi, inv_sinphi, want_gm, g, lds, prof);
     else if (c.nthr == 1024 && c.kpt == 4)
-        fused_any_launch_1024x4(s, x, pcm16, n, table, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, gm_out, w,
-                                n_corr, g, lds, prof);
+        fused_any_launch_1024x4(s, call, d_slots, max_w, pcm16, table, h2, h2p, cosphi2, sinphi, inv_sinphi, want_gm, g, lds, prof);
     else
         return false;
     return true;

@@ -5,8 +5,7 @@ namespace apt::gpu {
 
 void fused_any_launch_1024x4(APT_ANY_SHAPE_ARGS)
 {
-    launch_any_shape<1024, 4>(s, x, pcm16, n, table, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out, gm_out, w,
-                              n_corr, g, lds, prof);
+    launch_any_shape<1024, 4>(s, call, d_slots, max_w, pcm16, table, h2, h2p, cosphi2, sinphi, inv_sinphi, want_gm, g, lds, prof);
 }
 
 }  // namespace apt::gpu

@@ -54,13 +54,22 @@ __host__ __device__ constexpr bool sync_plus(int j)
 // form of k_fused: every sample is broadcast against a PAIR of taps (one SGPR pair) or signs
 // (neg modifiers) feeding a pair of accumulators, half the VALU instructions of the run-time
 // loops.  0: run-time loops.
+// One launch covers the recordings of a call (blockIdx.y; CallArgs by value, workspace pointers from the plan's slot
+// table — as every k_fused; until round 4 this kernel was launched once per recording).
 template <int NTHR, int KPT, typename XT, int T2C, int PWC>
 __global__ void __launch_bounds__(NTHR)
-k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ table /*[l][tpp]*/,
+k_fused_any(const CallArgs call, const SlotPtrs *__restrict__ slots, const float *__restrict__ table /*[l][tpp]*/,
             const float *__restrict__ h2, const f2 *__restrict__ h2p /*[t2+1] (h2[k-1], h2[k])*/,
-            float cosphi2, float sinphi, float inv_sinphi, float *__restrict__ f_out,
-            GroupMax *__restrict__ gm_out, uint64_t w, uint64_t n_corr, AnyGeom G)
+            float cosphi2, float sinphi, float inv_sinphi, int want_gm, AnyGeom G)
 {
+    const RecArgs rec = call.rec[blockIdx.y];
+    const uint64_t w = rec.w;
+    if (static_cast<uint64_t>(blockIdx.x) * G.own >= w) return;  // (the grid is sized for the call's longest recording)
+    const XT *__restrict__ x = static_cast<const XT *>(rec.x);
+    const uint64_t n = rec.n;
+    const uint64_t n_corr = w - G.g;  // w >= 10 rows of samples > G (checked on the host)
+    float *__restrict__ f_out = slots[rec.slot].f;
+    GroupMax *__restrict__ gm_out = want_gm ? slots[rec.slot].gm : nullptr;
     extern __shared__ float lds[];
     float *T = lds;
     float *X = lds + G.off_x;
@@ -397,8 +406,8 @@ k_fused_any(const XT *__restrict__ x, uint64_t n, const float *__restrict__ tabl
 }
 
 template <int NTHR, int KPT, int T2C, int PWC, typename XT>
-void launch_any(hipStream_t s, const XT *x, uint64_t n, const float *table, const float *h2, const float *h2p,
-                float cosphi2, float sinphi, float inv_sinphi, float *f_out, GroupMax *gm_out, uint64_t w, uint64_t n_corr,
+void launch_any(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint64_t max_w, const float *table,
+                const float *h2, const float *h2p, float cosphi2, float sinphi, float inv_sinphi, bool want_gm,
                 const AnyGeom &g, size_t lds)
 {
     auto kern = k_fused_any<NTHR, KPT, XT, T2C, PWC>;
@@ -413,29 +422,26 @@ void launch_any(hipStream_t s, const XT *x, uint64_t n, const float *table, cons
                                   static_cast<int>(lds));
         attr_lds[dev].store(lds, std::memory_order_release);
     }
-    const unsigned tiles = static_cast<unsigned>((w + g.own - 1) / g.own);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NTHR), lds, s, x, n, table, h2, reinterpret_cast<const f2 *>(h2p), cosphi2,
-                       sinphi, inv_sinphi, f_out,
-                       gm_out, w, n_corr, g);
+    const unsigned tiles = static_cast<unsigned>((max_w + g.own - 1) / g.own);
+    hipLaunchKernelGGL(kern, dim3(tiles, call.count), dim3(NTHR), lds, s, call, d_slots, table, h2,
+                       reinterpret_cast<const f2 *>(h2p), cosphi2, sinphi, inv_sinphi, want_gm ? 1 : 0, g);
 }
 
 
 // all profiles x input types of one launch shape
 template <int NT, int KP>
-void launch_any_shape(hipStream_t s, const void *x, bool pcm16, uint64_t n, const float *table, const float *h2,
-                      const float *h2p, float cosphi2, float sinphi, float inv_sinphi, float *f_out,
-                      GroupMax *gm_out, uint64_t w, uint64_t n_corr, const AnyGeom &g, size_t lds, int prof)
+void launch_any_shape(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint64_t max_w, bool pcm16,
+                      const float *table, const float *h2, const float *h2p, float cosphi2, float sinphi,
+                      float inv_sinphi, bool want_gm, const AnyGeom &g, size_t lds, int prof)
 {
-    const float *xf = static_cast<const float *>(x);
-    const int16_t *xi = static_cast<const int16_t *>(x);
 #define APT_ANY_LAUNCH(T2C, PWC)                                                                                \
     do {                                                                                                        \
         if (pcm16)                                                                                              \
-            launch_any<NT, KP, T2C, PWC>(s, xi, n, table, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out,          \
-                                         gm_out, w, n_corr, g, lds);                                            \
+            launch_any<NT, KP, T2C, PWC, int16_t>(s, call, d_slots, max_w, table, h2, h2p, cosphi2, sinphi,     \
+                                                  inv_sinphi, want_gm, g, lds);                                 \
         else                                                                                                    \
-            launch_any<NT, KP, T2C, PWC>(s, xf, n, table, h2, h2p, cosphi2, sinphi, inv_sinphi, f_out,          \
-                                         gm_out, w, n_corr, g, lds);                                            \
+            launch_any<NT, KP, T2C, PWC, float>(s, call, d_slots, max_w, table, h2, h2p, cosphi2, sinphi,       \
+                                                inv_sinphi, want_gm, g, lds);                                   \
         return;                                                                                                 \
     } while (0)
     // the W-rate stages of the three stock profiles (default_settings.toml:108-140) at any input

@@ -19,10 +19,10 @@ struct AnyGeom {
     uint64_t sign[4];              // bit j set <=> sync template[j] = +1 (decode.rs:188-198)
 };
 
-#define APT_ANY_SHAPE_ARGS                                                                                       \
-    hipStream_t s, const void *x, bool pcm16, uint64_t n, const float *table, const float *h2, const float *h2p, \
-        float cosphi2, float sinphi, float inv_sinphi, float *f_out, GroupMax *gm_out, uint64_t w,    \
-        uint64_t n_corr, const AnyGeom &g, size_t lds, int prof
+#define APT_ANY_SHAPE_ARGS                                                                                          \
+    hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint64_t max_w, bool pcm16, const float *table,   \
+        const float *h2, const float *h2p, float cosphi2, float sinphi, float inv_sinphi, bool want_gm,             \
+        const AnyGeom &g, size_t lds, int prof
 void fused_any_launch_256x8(APT_ANY_SHAPE_ARGS);
 void fused_any_launch_1024x8(APT_ANY_SHAPE_ARGS);
 void fused_any_launch_1024x4(APT_ANY_SHAPE_ARGS);

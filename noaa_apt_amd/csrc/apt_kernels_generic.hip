@@ -10,6 +10,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -414,6 +416,45 @@ k_gather_rows_call(const CallArgs call, const SlotPtrs *__restrict__ slots, uint
     gather_rows_body(sp.f, sp.peaks, sp.res, spr, pw, 0, rec.rows, rec.rows_cap);
 }
 
+// The same rows with the (row, pixel quad) pairs of a recording as ONE flat index walked by a fixed number of
+// workgroups (grid.x) per recording: no workgroup of a row's third, nearly empty block of quads (2080 px = 520 quads =
+// 2.03 blocks of 256 threads), and `iters` quads per thread instead of one wave launch per 256 pixels — the kernel
+// runs beside the next call's front end, whose workgroups are dispatched through the same pipe.  QPR: quads per row
+// at compile time (520 whenever the work rate is a multiple of 4160 Hz: the division by it is a multiply).
+template <uint32_t QPR>
+__global__ void __launch_bounds__(kBlock)
+k_gather_rows_flat(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t spr, uint32_t pw)
+{
+    const RecArgs rec = call.rec[blockIdx.y];
+    const SlotPtrs sp = slots[rec.slot];
+    Result *__restrict__ res = sp.res;
+    uint32_t n_rows = __hip_atomic_load(&res->n_rows, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n_rows > rec.rows_cap) {  // (see gather_rows_body)
+        n_rows = rec.rows_cap;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            __hip_atomic_store(&res->n_rows, rec.rows_cap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            res->n_out = static_cast<uint64_t>(rec.rows_cap) * (QPR * 4u);
+            res->reason = 4;
+        }
+    }
+    const float *__restrict__ f = sp.f;
+    const uint32_t *__restrict__ peaks = sp.peaks;
+    float *__restrict__ rows = rec.rows;
+    const uint32_t total = n_rows * QPR;  // < 2^32: rows_cap <= 32768 rows of 520 quads
+    for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < total; q += gridDim.x * kBlock) {
+        const uint32_t r = q / QPR, k = q - r * QPR;
+        const float *p4 = f + peaks[r] + static_cast<uint64_t>(4u * k) * pw;
+        float4 v = make_float4(p4[0], p4[pw], p4[2u * pw], p4[3u * pw]);
+        // filter([1.]): sum = 0.0 + x*1.0 (x*1.0 is x; the addition turns -0.0 into +0.0), and nothing at all for i == 0
+        v.x = __fadd_rn(0.f, __fmul_rn(v.x, 1.f));
+        v.y = __fadd_rn(0.f, __fmul_rn(v.y, 1.f));
+        v.z = __fadd_rn(0.f, __fmul_rn(v.z, 1.f));
+        v.w = __fadd_rn(0.f, __fmul_rn(v.w, 1.f));
+        if (q == 0) v.x = 0.f;
+        *reinterpret_cast<float4 *>(rows + static_cast<uint64_t>(q) * 4u) = v;
+    }
+}
+
 __global__ void k_set_result(Result *res, Result value) { *res = value; }
 
 }  // namespace
@@ -511,6 +552,19 @@ void gather_rows_call(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slo
                       uint32_t max_rows_cap)
 {
     if (call.count == 0) return;
+    // APTGPU_GATHER_ITERS=n (A/B switch, read per launch): the flat form, n quads per thread
+    if (const char *e = std::getenv("APTGPU_GATHER_ITERS")) {
+        const int iters = std::atoi(e);
+        bool aligned = true;
+        for (uint32_t i = 0; i < call.count; ++i) aligned = aligned && (reinterpret_cast<uintptr_t>(call.rec[i].rows) & 15u) == 0;
+        if (iters > 0 && spr / pw == 2080u && spr % pw == 0 && aligned && max_rows_cap > 0) {
+            const uint64_t quads = static_cast<uint64_t>(max_rows_cap < 32768u ? max_rows_cap : 32768u) * 520u;
+            const uint64_t per_wg = static_cast<uint64_t>(kBlock) * static_cast<uint64_t>(iters);
+            const unsigned gx = static_cast<unsigned>((quads + per_wg - 1) / per_wg);
+            hipLaunchKernelGGL(k_gather_rows_flat<520u>, dim3(gx ? gx : 1, call.count), dim3(kBlock), 0, s, call, d_slots, spr, pw);
+            return;
+        }
+    }
     // eight rows per workgroup (one row each made 57 600 workgroups of three loop iterations per thread for a call of
     // 16 recordings: the kernel ran at the rate workgroups can be dispatched, 118 us whatever it read)
     const unsigned rows_cap = max_rows_cap < 32768u ? max_rows_cap : 32768u;

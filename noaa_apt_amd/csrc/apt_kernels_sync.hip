@@ -100,6 +100,47 @@ constexpr uint32_t kPosMask = 0x7FFFFFFFu;      // (positions are < 2^31: longer
 // GS + 38*pw - 1 samples
 __host__ __device__ constexpr uint32_t nodes_window(uint32_t pw) { return (GS + 38u * pw - 1u + 3u) & ~3u; }
 
+// Wave-wide scans of maxima with DPP row operations (no LDS traffic, no address arithmetic: a ds_bpermute step costs a
+// v_add for its address, the LDS round trip and a compare + select for the wave's edge — six of them per scan, two
+// scans per candidate group, were a quarter of this kernel's VALU instructions and most of a candidate's latency).
+// The values are never NaN here (NaN correlations were replaced by -inf).  All 64 lanes must be active.
+// "s_nop 1": a DPP operand written by the previous VALU instruction needs two wait states, and the compiler's hazard
+// recogniser does not look inside an asm statement.
+// inclusive prefix maximum: lane i <- max(x[0 .. i])
+__device__ __forceinline__ float wave_prefix_max_dpp(float x)
+{
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"   // row 0 -> 1, row 2 -> 3
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"   // rows 0-1 -> 2, 3
+                 "s_nop 1"
+                 : "+v"(x));
+    return x;
+}
+// exclusive suffix maximum: lane i <- max(x[i+1 .. 63]), -inf in lane 63
+__device__ __forceinline__ float wave_suffix_max_excl_dpp(float x, int lane)
+{
+    // y[i] = x[i+1] (lane 63: -inf), then the inclusive suffix maximum of y inside every row of 16 lanes ...
+    float y = -__builtin_huge_valf();
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(y)
+                 : "v"(x));
+    // ... and the rows behind: their totals sit in their first lanes
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), 48));
+    const float m23 = fmaxf(r2, r3), m123 = fmaxf(r1, m23);
+    const float tail = lane < 16 ? m123 : lane < 32 ? m23 : lane < 48 ? r3 : -__builtin_huge_valf();
+    return fmaxf(y, tail);
+}
+
 // bytes of dynamic LDS of k_sync_words for r = md/GS groups of look-ahead: terminal and NaN words of the own
 // groups | hi, lo bounds and two buffers of running maxima over own + look-ahead groups | window maxima |
 // candidate list | one F window per wave
@@ -164,7 +205,9 @@ __device__ __forceinline__ float nodes_eval_window(float *win, bool on, int lane
 // the md/GS + 1 groups BEHIND its own: it evaluated the candidates of that look-behind halo a second
 // time, 76 % more work.  The lists are now a second, trivially cheap launch, k_sync_slots, that reads
 // the words back — a kernel boundary instead of an inter-workgroup hand-over inside one launch.)
-template <int NL, int PWC>
+// DPP: the two scans of a candidate's terminal test with DPP row operations (the default; APTGPU_WORDS_DPP=0 keeps
+// the ds_bpermute form for A/B).
+template <int NL, int PWC, bool DPP>
 __global__ void __launch_bounds__(kNodesThreads, 4)  // <= 128 VGPRs: must fit beside the front end's waves
 k_sync_words(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t pw_arg, uint32_t r_groups /* md/GS */,
              int fast, int use_corr)
@@ -281,13 +324,18 @@ k_sync_words(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
         const unsigned long long nanword = __ballot(in_v && cv != cv) & kGroupMask;
         if (cv != cv) cv = kNegInf;
         // suffix max over lanes > lane (rest of this group)
-        float sfx = cv;
-        for (int d = 1; d < 64; d <<= 1) {
-            const float o = __shfl_down(sfx, d, 64);
-            if (lane + d < 64) sfx = fmaxf(sfx, o);
+        float sfx_ex;
+        if constexpr (DPP) {
+            sfx_ex = wave_suffix_max_excl_dpp(cv, lane);
+        } else {
+            float sfx = cv;
+            for (int d = 1; d < 64; d <<= 1) {
+                const float o = __shfl_down(sfx, d, 64);
+                if (lane + d < 64) sfx = fmaxf(sfx, o);
+            }
+            sfx_ex = __shfl_down(sfx, 1, 64);
+            if (lane == 63) sfx_ex = kNegInf;
         }
-        float sfx_ex = __shfl_down(sfx, 1, 64);
-        if (lane == 63) sfx_ex = kNegInf;
         float wm = s_wm[q];
         const bool open_lo = in_v && !(sfx_ex > cv) && !(wm > cv);
         if (__ballot(open_lo) != 0ull) {
@@ -341,9 +389,13 @@ k_sync_words(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
         if (c2v != c2v) c2v = kNegInf;
         // prefix max over lanes <= lane of the group md positions ahead
         float pfx = c2v;
-        for (int d = 1; d < 64; d <<= 1) {
-            const float o = __shfl_up(pfx, d, 64);
-            if (lane >= d) pfx = fmaxf(pfx, o);
+        if constexpr (DPP) {
+            pfx = wave_prefix_max_dpp(pfx);
+        } else {
+            for (int d = 1; d < 64; d <<= 1) {
+                const float o = __shfl_up(pfx, d, 64);
+                if (lane >= d) pfx = fmaxf(pfx, o);
+            }
         }
         wmax = fmaxf(wmax, pfx);
         const bool term = in_v && !(wmax > cv);
@@ -510,7 +562,7 @@ k_sync_slots(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
 }
 
 // ------------------------------------------------------------------ k_sync_orbit
-constexpr int kOrbitThreads = 1024;
+constexpr int kOrbitThreadsMax = 1024;
 constexpr int kMaxLevels = 64;    // breadth-first levels before giving up on the parallel path
 
 struct OrbitGeom {
@@ -601,7 +653,10 @@ __device__ __forceinline__ void gst(uint32_t *p, uint32_t v)
 // front end.  Node terminals are looked up straight in the per-chunk slots k_sync_slots wrote
 // (no gather pass): chunk = position / (128*52), then the first entry >= s of that slot or of the
 // next non-empty one.  Node ids: 0 root, 1..n_grid grid cells 2..kc, base_d + slot entry, END.
-__global__ void __launch_bounds__(kOrbitThreads, 8)
+// NT threads: 1024 (the latency-bound phases finish soonest when the kernel has a CU's slots to itself) or 256 (a
+// workgroup that still finds room on a CU whose LDS and wave slots five front-end workgroups have taken).
+template <int NT>
+__global__ void __launch_bounds__(NT, NT >= 1024 ? 8 : 2)
 k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t spr_in, uint32_t md_in,
                     uint32_t pw, int force_walk, uint32_t lds_entries)
 {
@@ -708,11 +763,11 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
     // ---- reachable set by breadth-first marking from the root and every grid node
     uint32_t count = 0;
     if (!walk) {
-        for (uint32_t wq = tid; wq < n_nodes / 32 + 1; wq += kOrbitThreads) gst(w_mark + wq, 0u);
-        for (uint32_t c = tid; c < kc + 3; c += kOrbitThreads) gst(w_succ + c, 0xFFFFFFFFu);
+        for (uint32_t wq = tid; wq < n_nodes / 32 + 1; wq += NT) gst(w_mark + wq, 0u);
+        for (uint32_t c = tid; c < kc + 3; c += NT) gst(w_succ + c, 0xFFFFFFFFu);
         if (tid == 0) { s_count = base_d; s_conflict = 0; s_endcell = kc + 2; }
         __syncthreads();
-        for (uint32_t v = tid; v < base_d; v += kOrbitThreads) {
+        for (uint32_t v = tid; v < base_d; v += NT) {
             gst(w_list + v, v);
             atomicOr(w_mark + (v >> 5), 1u << (v & 31));
         }
@@ -720,7 +775,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         uint32_t lo = 0, hi = base_d;
         int level = 0;
         for (; level < kMaxLevels && lo < hi; ++level) {
-            for (uint32_t idx = lo + tid; idx < hi; idx += kOrbitThreads) {
+            for (uint32_t idx = lo + tid; idx < hi; idx += NT) {
                 const uint32_t v = gld(w_list + idx);
                 uint32_t cell, u = 0, nx = END, nxcell = 0;
                 const uint32_t sv = node_start(v, &cell);
@@ -790,7 +845,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         // orbit is read off without any pointer chasing: path[0] = root (acts as cell 1),
         // path[k] = succ[k] up to the first cell whose successor is END
         const uint32_t endc = s_endcell;
-        for (uint32_t k = tid + 1; k < path_cap; k += kOrbitThreads)
+        for (uint32_t k = tid + 1; k < path_cap; k += NT)
             gst(w_path + k, k < endc ? gld(w_succ + k) : END);
         __syncthreads();
     }
@@ -808,19 +863,19 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         uint16_t *la = pth + path_cap;          // [count + 1]
         uint16_t *lb = la + (count + 1);        // [count + 1]
         const uint16_t ENDC = static_cast<uint16_t>(count);
-        for (uint32_t idx = tid; idx < count; idx += kOrbitThreads) {
+        for (uint32_t idx = tid; idx < count; idx += NT) {
             const uint32_t nx = gld(w_ja + gld(w_list + idx));
             la[idx] = nx == END ? ENDC : static_cast<uint16_t>(nx < base_d ? nx : gld(w_jb + nx));  // seeds: index == id
         }
         if (tid == 0) { la[count] = ENDC; lb[count] = ENDC; pth[0] = 0; }
         __syncthreads();
         for (uint32_t span = 1; span < path_cap; span <<= 1) {
-            for (uint32_t mI = tid; mI < span && mI + span < path_cap; mI += kOrbitThreads) pth[mI + span] = la[pth[mI]];
-            for (uint32_t idx = tid; idx < count; idx += kOrbitThreads) lb[idx] = la[la[idx]];
+            for (uint32_t mI = tid; mI < span && mI + span < path_cap; mI += NT) pth[mI + span] = la[pth[mI]];
+            for (uint32_t idx = tid; idx < count; idx += NT) lb[idx] = la[la[idx]];
             __syncthreads();
             uint16_t *t = la; la = lb; lb = t;
         }
-        for (uint32_t k = tid; k < path_cap; k += kOrbitThreads)
+        for (uint32_t k = tid; k < path_cap; k += NT)
             gst(w_path + k, pth[k] == ENDC ? END : gld(w_list + pth[k]));
         __syncthreads();
     }
@@ -830,19 +885,19 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
     uint32_t vk[kKeep], jk[kKeep];
 #pragma unroll
     for (int j = 0; j < kKeep; ++j) {
-        const uint32_t idx = tid + j * kOrbitThreads;
+        const uint32_t idx = tid + j * NT;
         vk[j] = (idx < count) ? gld(w_list + idx) : END;
     }
 #pragma unroll
     for (int j = 0; j < kKeep; ++j) jk[j] = gld(ja + vk[j]);
     for (uint32_t span = 1; span < path_cap; span <<= 1) {
-        for (uint32_t mI = tid; mI < span && mI + span < path_cap; mI += kOrbitThreads)
+        for (uint32_t mI = tid; mI < span && mI + span < path_cap; mI += NT)
             gst(w_path + mI + span, gld(ja + gld(w_path + mI)));
 #pragma unroll
         for (int j = 0; j < kKeep; ++j) jk[j] = gld(ja + jk[j]);  // J[J[v]], one round trip
 #pragma unroll
         for (int j = 0; j < kKeep; ++j) gst(jb + vk[j], jk[j]);
-        for (uint32_t idx = tid + kKeep * kOrbitThreads; idx < count; idx += kOrbitThreads) {
+        for (uint32_t idx = tid + kKeep * NT; idx < count; idx += NT) {
             const uint32_t v = gld(w_list + idx);
             gst(jb + v, gld(ja + gld(ja + v)));
         }
@@ -857,7 +912,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
     if (tid == 0) { s_plen = 1; s_fit = 0ull; }
     __syncthreads();
     unsigned long long fit_local = 0;
-    for (uint32_t k = tid; k < path_cap; k += kOrbitThreads) {
+    for (uint32_t k = tid; k < path_cap; k += NT) {
         const uint32_t v = gld(w_path + k);
         if (v == END) continue;
         uint32_t cell;
@@ -930,9 +985,17 @@ void sync_nodes(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, ui
     const size_t lds = words_win_ofs(r) + static_cast<size_t>(kNodesWaves) * nodes_window(pw) * sizeof(float);
     const dim3 grid(chunks, call.count);
     const uint32_t wneed = GS + 38u * pw - 1u;
-#define APT_WORDS_LAUNCH(NL, PWC)                                                                              \
-    hipLaunchKernelGGL((k_sync_words<NL, PWC>), grid, dim3(kNodesThreads), lds, s, call, d_slots, pw, r, fast ? 1 : 0, \
-                       use_corr ? 1 : 0)
+    const char *e_dpp = std::getenv("APTGPU_WORDS_DPP");  // A/B switch (read per launch: tools/sweep.py flips it between plans)
+    const bool dpp = !(e_dpp && e_dpp[0] == '0');
+#define APT_WORDS_LAUNCH(NL, PWC)                                                                                       \
+    do {                                                                                                                \
+        if (dpp)                                                                                                        \
+            hipLaunchKernelGGL((k_sync_words<NL, PWC, true>), grid, dim3(kNodesThreads), lds, s, call, d_slots, pw, r,  \
+                               fast ? 1 : 0, use_corr ? 1 : 0);                                                         \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_sync_words<NL, PWC, false>), grid, dim3(kNodesThreads), lds, s, call, d_slots, pw, r, \
+                               fast ? 1 : 0, use_corr ? 1 : 0);                                                         \
+    } while (0)
     if (pw == 3) APT_WORDS_LAUNCH(3, 3);        // standard profile
     else if (pw == 4) APT_WORDS_LAUNCH(4, 4);   // fast profile
     else if (pw == 5) APT_WORDS_LAUNCH(4, 5);   // slow profile
@@ -969,8 +1032,13 @@ void sync_orbit(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, ui
     // (APTGPU_ORBIT_LDS=0, tests: always through global memory)
     const char *e = std::getenv("APTGPU_ORBIT_LDS");
     const uint32_t kOrbitLdsEntries = (e && e[0] == '0') ? 0u : 12288u;
-    hipLaunchKernelGGL(k_sync_orbit_global, dim3(call.count), dim3(kOrbitThreads), kOrbitLdsEntries * sizeof(uint16_t), s,
-                       call, d_slots, spr, md, pw, force == 1 ? 1 : 0, kOrbitLdsEntries);
+    const char *e_nt = std::getenv("APTGPU_ORBIT_THREADS");  // A/B switch (read per launch)
+    if (e_nt && std::atoi(e_nt) == 256)
+        hipLaunchKernelGGL(k_sync_orbit_global<256>, dim3(call.count), dim3(256), kOrbitLdsEntries * sizeof(uint16_t), s,
+                           call, d_slots, spr, md, pw, force == 1 ? 1 : 0, kOrbitLdsEntries);
+    else
+        hipLaunchKernelGGL(k_sync_orbit_global<kOrbitThreadsMax>, dim3(call.count), dim3(kOrbitThreadsMax), kOrbitLdsEntries * sizeof(uint16_t), s,
+                           call, d_slots, spr, md, pw, force == 1 ? 1 : 0, kOrbitLdsEntries);
 }
 
 }  // namespace apt::gpu

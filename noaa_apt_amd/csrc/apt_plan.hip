@@ -189,14 +189,39 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     }
     depth = std::max(1, std::min(depth, 16));
     plan->streams.resize(static_cast<size_t>(depth));
-    for (auto &st : plan->streams)
-        hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+    // A/B switches of the pipeline's shape (tools/sweep.py; read at plan creation):
+    //   APTGPU_FRONT_STREAM=1  all front ends on one extra stream (apt_plan.hpp)
+    //   APTGPU_CHAIN_CUS=n     with it: the per-call streams (words, slots, orbit, gather) are created with a CU mask of
+    //                          n CUs, APTGPU_FRONT_EXCL=1: and the front-end stream with the mask of the others
+    int cu_count = 0;
+    (void)hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, plan->device);
+    const char *e_fs = std::getenv("APTGPU_FRONT_STREAM");
+    const bool want_front_stream = e_fs && e_fs[0] == '1' && !plan->user_stream && depth > 1 && max_batch >= 4;
+    const char *e_cc = std::getenv("APTGPU_CHAIN_CUS");
+    plan->chain_cus = (want_front_stream && e_cc) ? std::max(0, std::min(std::atoi(e_cc), cu_count - 8)) : 0;
+    auto masked_stream = [&](hipStream_t *st, int first, int count) {
+        // bit i of the mask = CU i in the runtime's numbering (consecutive bits go round the XCDs)
+        std::vector<uint32_t> mask(static_cast<size_t>((cu_count + 31) / 32), 0u);
+        for (int c = first; c < first + count && c < cu_count; ++c) mask[static_cast<size_t>(c / 32)] |= 1u << (c % 32);
+        hip_check(hipExtStreamCreateWithCUMask(st, static_cast<uint32_t>(mask.size()), mask.data()), "hipExtStreamCreateWithCUMask");
+    };
+    for (auto &st : plan->streams) {
+        if (plan->chain_cus > 0) masked_stream(&st, 0, plan->chain_cus);
+        else hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+    }
     plan->stream = plan->streams[0];
+    if (want_front_stream) {
+        const char *e_ex = std::getenv("APTGPU_FRONT_EXCL");
+        if (plan->chain_cus > 0 && e_ex && e_ex[0] == '1') masked_stream(&plan->front_stream, plan->chain_cus, cu_count - plan->chain_cus);
+        else hip_check(hipStreamCreateWithFlags(&plan->front_stream, hipStreamNonBlocking), "hipStreamCreate");
+        plan->ev_pre.resize(static_cast<size_t>(depth));
+        for (auto &ev : plan->ev_pre) hip_check(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+    }
     {
         // (not with a user stream: such plans may be captured into a HIP graph, call by call, and an event
         // recorded before the capture cannot be waited for inside it)
         const char *e = std::getenv("APTGPU_FRONT_SERIAL");  // A/B switch
-        plan->front_serial = (e ? e[0] != '0' : max_batch >= 4) && !plan->user_stream && depth > 1;
+        plan->front_serial = ((e ? e[0] != '0' : max_batch >= 4) && !plan->user_stream && depth > 1) || plan->front_stream;
         if (plan->front_serial) {
             plan->ev_front.resize(static_cast<size_t>(depth));
             for (auto &ev : plan->ev_front) hip_check(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
@@ -409,6 +434,7 @@ uint64_t aptgpu_plan::out_len_nosync(uint64_t work_len) const
 
 void aptgpu_plan::sync_all()
 {
+    if (front_stream) apt::hip_check(hipStreamSynchronize(front_stream), "hipStreamSynchronize");
     for (hipStream_t st : streams) apt::hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
 }
 
@@ -527,7 +553,12 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
         // 1-3 fused: resample -> envelope -> low-pass (-> correlation maxima) in one launch per input
         // kind (apt_kernels_fused.hip), behind the previous call's front end (see front_serial, apt_plan.hpp)
         hipStream_t fs = cur;
-        if (front_serial && !live.empty() && prev_front >= 0 && prev_front != last_stream)
+        if (front_stream && !live.empty()) {
+            // the front end runs on the front-end stream, behind everything the call's stream holds so far
+            fs = front_stream;
+            apt::hip_check(hipEventRecord(ev_pre[static_cast<size_t>(last_stream)], cur), "hipEventRecord");
+            apt::hip_check(hipStreamWaitEvent(fs, ev_pre[static_cast<size_t>(last_stream)], 0), "hipStreamWaitEvent");
+        } else if (front_serial && !live.empty() && prev_front >= 0 && prev_front != last_stream)
             apt::hip_check(hipStreamWaitEvent(cur, ev_front[static_cast<size_t>(prev_front)], 0), "hipStreamWaitEvent");
         for (int kind = 0; kind < 2; ++kind) {
             std::vector<int> idx;
@@ -548,18 +579,24 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
             });
         }
         if (front_serial && !live.empty()) {
-            apt::hip_check(hipEventRecord(ev_front[static_cast<size_t>(last_stream)], cur), "hipEventRecord");
+            apt::hip_check(hipEventRecord(ev_front[static_cast<size_t>(last_stream)], fs), "hipEventRecord");
             prev_front = last_stream;
+            // (the chain follows on the call's stream)
+            if (front_stream) apt::hip_check(hipStreamWaitEvent(cur, ev_front[static_cast<size_t>(last_stream)], 0), "hipStreamWaitEvent");
         }
     } else if (use_fused) {
-        for (int i : live) {
-            Slot &sl = slots[static_cast<size_t>(slot0 + i)];
-            const uint64_t w = wlen[static_cast<size_t>(i)];
-            timed("fused_front_end", [&] {
-                fused_any_front_end(cur, l, m, t1, t2, pw, xin[static_cast<size_t>(i)], is_pcm[static_cast<size_t>(i)] != 0,
-                                    ins[i].n, d_taps_any.ptr, d_taps_lowpass.ptr, d_taps_lowpass_pairs.ptr, cosphi2,
-                                    sinphi, inv_sinphi, sl.filtered.ptr, want_sync ? sl.gm.ptr : nullptr, w,
-                                    w - n_sync_taps);
+        // the run-time front end (k_fused_any: fast / slow profiles, odd rates): one launch per input kind too
+        for (int kind = 0; kind < 2; ++kind) {
+            std::vector<int> idx;
+            for (int i : live)
+                if (is_pcm[static_cast<size_t>(i)] == kind) idx.push_back(i);
+            for_chunks(idx, [&](const CallArgs &c, uint64_t max_w, uint32_t) {
+                timed("fused_front_end", [&] {
+                    if (!fused_any_front_end(cur, l, m, t1, t2, pw, kind == 1, c, d_slots.ptr, max_w, d_taps_any.ptr,
+                                             d_taps_lowpass.ptr, d_taps_lowpass_pairs.ptr, cosphi2, sinphi, inv_sinphi,
+                                             want_sync))
+                        throw apt::Error{apt::ErrorKind::Internal, "fused front end: no kernel for this geometry"};
+                });
             });
         }
     } else {

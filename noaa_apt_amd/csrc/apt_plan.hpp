@@ -103,6 +103,14 @@ struct aptgpu_plan {
     bool front_serial = false;
     std::vector<hipEvent_t> ev_front;   // [depth]: behind the front end of the latest call on that stream
     int prev_front = -1;                // stream index whose ev_front the next front end waits for
+    // Alternative (APTGPU_FRONT_STREAM=1, an A/B switch): every front end on ONE extra in-order stream — consecutive
+    // front ends then follow each other inside one hardware queue instead of through a cross-queue event — and the
+    // chain of call j on stream j % depth behind an event recorded after its front end.  The front-end stream
+    // waits for an event recorded on the call's stream first (whatever the caller ordered the call behind, and the
+    // previous chain on those workspace slots).
+    hipStream_t front_stream = nullptr;
+    std::vector<hipEvent_t> ev_pre;     // [depth]: the call's stream just before its front end is enqueued
+    int chain_cus = 0;                  // APTGPU_CHAIN_CUS=n: the per-call (chain) streams run on n CUs only
     hipStream_t user_stream = nullptr;  // ctx.stream: inputs are ordered after it (may be null)
     hipEvent_t ev_user = nullptr;
     uint64_t calls = 0;             // calls enqueued so far (stream = calls % depth)

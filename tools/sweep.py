@@ -4,7 +4,9 @@ recordings-per-call / calls-in-flight, one process, inputs generated once.
 
     python tools/sweep.py --configs strict:1:6,strict:8:3,fast:1:6,fast:8:3 --steps 40
 
-Each config is mode:batch:streams.  Prints one JSON line per config: ms per recording in the
+Each config is mode:batch:streams[:ENV=VALUE;ENV=VALUE...] — the optional fourth field sets environment switches of
+the library (APTGPU_WORDS_DPP, APTGPU_GATHER_ITERS, APTGPU_FRONT_STREAM, ...: read at plan creation or per launch)
+for that config only.  Prints one JSON line per config: ms per recording in the
 pipelined loop, Msamples/s, and the per-kernel times with one call in flight at a time.
 """
 import argparse
@@ -50,9 +52,13 @@ def main():
     spec = apt.WavSpec(1, 16, 2, 0, args.rate, 1, 0, 2 * n, n, n)
 
     for cfg in args.configs.split(","):
-        mode_s, b_s, st_s = cfg.split(":")
+        parts = cfg.split(":")
+        mode_s, b_s, st_s = parts[:3]
         B, S = int(b_s), int(st_s)
         os.environ["APTGPU_STREAMS"] = str(S)
+        extra_env = dict(kv.split("=", 1) for kv in parts[3].split(";") if kv) if len(parts) > 3 else {}
+        saved_env = {k_: os.environ.get(k_) for k_ in extra_env}
+        os.environ.update(extra_env)
         plan = apt.Plan(apt.Settings(), apt.Rate.hz(args.rate), not args.no_sync, max_samples=n, max_batch=B, mode=modes[mode_s])
         cap = int(plan.info.max_rows)
         # every call in flight needs its own output buffers
@@ -86,14 +92,26 @@ def main():
         alone = plan.collect_timing()
         plan.enable_timing(0)
         res = plan.results(B)
+        # a checksum of the rows of every recording of the last call (A/B variants must agree bit for bit)
+        torch.cuda.synchronize()
+        last = outs[(k[0] - 1) % S]
+        chk = 0
+        for b_ in range(B):
+            nb = int(res[b_].n_out)
+            chk = (chk * 1000003 + int(last[b_][:nb].view(torch.int32).to(torch.int64).sum().item()) + nb) % (1 << 61)
         ms_rec = 1e3 * (b - a) / (args.steps * B)
         print(json.dumps({
             "config": cfg, "ms_per_recording": round(ms_rec, 5), "Msamples_per_s": round(n / ms_rec / 1e3, 1),
             "host_enqueue_ms_per_call": round(1e3 * (t_enq - a) / args.steps, 4),
-            "status": [int(r.status) for r in res][:4], "rows": int(res[0].n_rows), "fused": int(plan.info.fused),
+            "status": [int(r.status) for r in res][:4], "rows": int(res[0].n_rows), "fused": int(plan.info.fused), "rows_checksum": chk,
             "alone_ms_per_call": {kk: round(v[0], 5) for kk, v in sorted(alone.items())},
         }), flush=True)
         plan.close()
+        for k_, v_ in saved_env.items():
+            if v_ is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v_
 
 
 if __name__ == "__main__":
