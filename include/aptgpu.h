@@ -14,8 +14,11 @@
  *    receives the same message string the reference puts in its err::Error.
  *  - "host" pointers are ordinary process memory; "d_" pointers are device
  *    (HBM) memory on the plan's GPU.
- *  - thread-safe and re-entrant: no mutable global state; a plan must not be
- *    used from two threads at once (make one plan per thread / per stream).
+ *  - thread-safe and re-entrant; a plan must not be used from two threads at
+ *    once (make one plan per thread / per stream).  The only process-global
+ *    mutable state is the mutex-guarded session cache behind the host-array
+ *    entry points (aptgpu_cache_clear / aptgpu_cache_info) and per-device
+ *    caches of kernel attributes and of the envelope's divide check.
  *  - numerics: f32 throughout, every product and sum rounded separately and
  *    accumulated in the reference's order, so outputs are bit-identical to
  *    the reference's scalar loops (APTGPU_MODE_STRICT, the default).
@@ -142,8 +145,9 @@ void aptgpu_free(void *p);
  * pinned staging — in a process-wide, mutex-guarded, least-recently-used cache keyed by (device, the five
  * settings decode() reads, input rate, sync, mode, recordings per call): SURVEY.md section 8(b), threading
  * row.  A cached session serves one call at a time (concurrent callers with the same key each get their own);
- * at most 8 idle sessions / APTGPU_SESSION_CACHE_MB (default 65536; 0 = no caching) of device memory are
- * kept.  Calls that export steps or run on a caller's stream do not use it.
+ * at most 8 idle sessions / APTGPU_SESSION_CACHE_MB (default: a quarter of the device's memory; 0 = no caching)
+ * of device memory are kept, and a session that cannot be built for lack of device memory empties the cache and
+ * tries once more.  Calls that export steps or run on a caller's stream do not use it.
  * aptgpu_cache_clear() releases every idle session; aptgpu_cache_info() reports what is idle. */
 void aptgpu_cache_clear(void);
 void aptgpu_cache_info(int32_t *entries /* nullable */, uint64_t *device_bytes /* nullable */);
@@ -258,10 +262,11 @@ int aptgpu_plan_read_internal(aptgpu_plan *plan, int i, const char *name, void *
  * any kind; every entry gets a host thread and a cached session (plan, device buffers, copy streams) and keeps
  * the uploads of calls k+1 / k+2, the kernels of call k and the download of call k-1 in flight together
  * (recordings_per_call recordings per call, <= 0 = 16); rows are DMA'd straight into the returned buffers.
- * Measured on BASELINE config 4's per-GPU share (32 x 15 min at 48 kHz, pageable inputs, one worker, 16 per
- * call): 52 GB/s over PCIe as f32 Signals (12 Gsamples/s), 50 GB/s as PCM16 WAV images (21.5).  All recordings of
- * a batch share (settings, input_rate_hz, sync); ctx supplies mode (and the device when n_devices == 0),
- * callbacks are not used.
+ * Every worker thread pins itself to the CPUs of its GPU's NUMA node first (sysfs: the device's numa_node and
+ * that node's cpulist; APTGPU_NUMA_PIN=0 turns it off), so the buffers it allocates and the staging copies it
+ * drives stay on the socket the GPU hangs off.  (Throughput figures: DESIGN.md section 7, profiles/.)  All
+ * recordings of a batch share (settings, input_rate_hz, sync); ctx supplies mode (and the device when
+ * n_devices == 0), callbacks are not used.
  *   rows_out[i] / n_out[i]: malloc'd rows of recording i (aptgpu_free), NULL / 0 when status[i] != 0;
  *   status[i]: APTGPU_OK, or the error decode() would have returned for that recording
  *              (APTGPU_ERR_INTERNAL: too short / too few sync frames; for WAV images also the
@@ -296,6 +301,14 @@ int aptgpu_decode_batch_wav(const aptgpu_context *ctx, const aptgpu_settings *se
 /* Pinned host memory (hipHostMalloc) for inputs that should cross PCIe by direct DMA; NULL on failure. */
 void *aptgpu_host_alloc(size_t bytes);
 void aptgpu_host_free(void *p);
+/* Which host CPUs a worker of `device` pins itself to: the device's PCI address (hipDeviceGetPCIBusId), its NUMA
+ * node and that node's CPU list as sysfs prints it ("0-63,128-191").  numa_node = -1 and an empty list when the
+ * platform does not say (single-socket hosts, containers without sysfs): no pinning then.  The second form is the
+ * same lookup on a given PCI address under a given sysfs root ("/sys" on a real host) and needs no GPU. */
+int aptgpu_host_affinity(int device, char *pci_bdf /* >= 16 bytes, nullable */, int32_t *numa_node,
+                         char *cpulist, size_t cpulist_cap);
+int aptgpu_host_affinity_from_sysfs(const char *sysfs_root, const char *pci_bdf, int32_t *numa_node,
+                                    char *cpulist, size_t cpulist_cap);
 
 /* ====================================================================== */
 /* 3. the dsp.rs / filters.rs / decode.rs building blocks (host buffers)    */

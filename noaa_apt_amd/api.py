@@ -240,6 +240,8 @@ def lib():
     L.aptgpu_host_alloc.restype = vp
     L.aptgpu_host_free.argtypes = [vp]
     L.aptgpu_host_free.restype = None
+    L.aptgpu_host_affinity.argtypes = [i32, C.c_char_p, C.POINTER(C.c_int32), C.c_char_p, sz]
+    L.aptgpu_host_affinity_from_sysfs.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int32), C.c_char_p, sz]
     L.aptgpu_get_min.argtypes = [cp, _f32p, sz, _f32p, C.c_char_p, sz]
     L.aptgpu_get_max.argtypes = [cp, _f32p, sz, _f32p, C.c_char_p, sz]
     L.aptgpu_percent.argtypes = [cp, _f32p, sz, f, _f32p, _f32p, C.c_char_p, sz]
@@ -274,6 +276,23 @@ def cache_info():
     e, b = C.c_int32(0), C.c_uint64(0)
     lib().aptgpu_cache_info(C.byref(e), C.byref(b))
     return int(e.value), int(b.value)
+
+
+def host_affinity(device=0):
+    """(PCI address, NUMA node, CPU list) a batch worker of `device` pins itself to; node -1 / '' when the
+    platform does not say."""
+    bdf, node, cpus = C.create_string_buffer(32), C.c_int32(-1), C.create_string_buffer(4096)
+    lib().aptgpu_host_affinity(int(device), bdf, C.byref(node), cpus, 4096)
+    return bdf.value.decode(), int(node.value), cpus.value.decode()
+
+
+def host_affinity_from_sysfs(sysfs_root, pci_bdf):
+    """The same lookup on a PCI address under a given sysfs root (no GPU needed): (NUMA node, CPU list)."""
+    node, cpus = C.c_int32(-1), C.create_string_buffer(4096)
+    rc = lib().aptgpu_host_affinity_from_sysfs(str(sysfs_root).encode(), str(pci_bdf).encode(), C.byref(node), cpus, 4096)
+    if rc != 0:
+        raise InvalidError("bad argument to aptgpu_host_affinity_from_sysfs")
+    return int(node.value), cpus.value.decode()
 
 
 def _take(ptr, n, dtype=np.float32):

@@ -20,9 +20,15 @@
 // for PCM16) and converted on the device.  Pageable host buffers are handed to hipMemcpyAsync as they are: the
 // runtime's pinned staging moves them at 56 GB/s here, as fast as a caller-pinned buffer (57 GB/s;
 // tools/ubench/hostpath.cpp — pinning 173 MB on the fly costs 4.7 ms, more than its transfer).
+#include <pthread.h>
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
+#include <cctype>
+#include <cstdio>
 #include <cstring>
+#include <fstream>
 #include <list>
 #include <mutex>
 #include <numeric>
@@ -278,6 +284,118 @@ namespace {
 
 using namespace apt::capi;
 
+// ------------------------------------------------------------------ NUMA placement of the workers
+// A worker feeds its GPU from host memory at PCIe rate: with eight of them on a two-socket host, threads (and the
+// rows buffers and staging copies they first touch) that sit on the other socket cross the inter-socket link for
+// every byte.  sysfs says where a PCI device hangs: <root>/bus/pci/devices/<bdf>/numa_node, and the node's CPUs in
+// <root>/devices/system/node/node<N>/cpulist (the device's own local_cpulist as a fallback).
+struct HostAffinity {
+    int node = -1;
+    std::string cpulist;    // as sysfs prints it: "0-63,128-191"
+    std::vector<int> cpus;  // parsed
+};
+
+std::string read_line(const std::string &path)
+{
+    std::ifstream f(path);
+    std::string line;
+    if (f) std::getline(f, line);
+    while (!line.empty() && (line.back() == '\n' || line.back() == '\r' || line.back() == ' ')) line.pop_back();
+    return line;
+}
+
+std::vector<int> parse_cpulist(const std::string &s)
+{
+    std::vector<int> out;
+    size_t i = 0;
+    while (i < s.size()) {
+        size_t j = s.find(',', i);
+        if (j == std::string::npos) j = s.size();
+        const std::string tok = s.substr(i, j - i);
+        i = j + 1;
+        if (tok.empty()) continue;
+        const size_t dash = tok.find('-');
+        char *end = nullptr;
+        const long a = std::strtol(tok.c_str(), &end, 10);
+        if (end == tok.c_str() || a < 0) return {};
+        long b = a;
+        if (dash != std::string::npos) {
+            const char *bs = tok.c_str() + dash + 1;
+            b = std::strtol(bs, &end, 10);
+            if (end == bs || b < a) return {};
+        }
+        if (b - a > 65536) return {};
+        for (long c = a; c <= b; ++c) out.push_back(static_cast<int>(c));
+    }
+    return out;
+}
+
+HostAffinity affinity_from_sysfs(const std::string &root, const std::string &bdf_in)
+{
+    HostAffinity h;
+    std::string bdf = bdf_in;
+    for (char &c : bdf) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));  // sysfs spells addresses in lower case
+    const std::string dev = root + "/bus/pci/devices/" + bdf;
+    const std::string node_s = read_line(dev + "/numa_node");
+    if (node_s.empty()) return h;
+    char *end = nullptr;
+    const long node = std::strtol(node_s.c_str(), &end, 10);
+    if (end == node_s.c_str() || node < 0) return h;  // -1: the platform does not say
+    std::string list = read_line(root + "/devices/system/node/node" + std::to_string(node) + "/cpulist");
+    if (list.empty()) list = read_line(dev + "/local_cpulist");
+    std::vector<int> cpus = parse_cpulist(list);
+    if (cpus.empty()) return h;
+    h.node = static_cast<int>(node);
+    h.cpulist = list;
+    h.cpus = std::move(cpus);
+    return h;
+}
+
+HostAffinity affinity_of_device(int device, std::string *bdf_out)
+{
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return {};
+    }
+    if (bdf_out) *bdf_out = bdf;
+    const char *root = std::getenv("APTGPU_SYSFS_ROOT");  // tests: a mocked tree
+    return affinity_from_sysfs(root ? root : "/sys", bdf);
+}
+
+// the calling thread onto the CPUs of `device`'s NUMA node (no-op when unknown, or APTGPU_NUMA_PIN=0)
+void pin_worker_to_device_node(int device)
+{
+    const char *e = std::getenv("APTGPU_NUMA_PIN");
+    if (e && e[0] == '0') return;
+    const HostAffinity h = affinity_of_device(device, nullptr);
+    if (h.node < 0) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n = 0;
+    for (int c : h.cpus)
+        if (c >= 0 && c < CPU_SETSIZE) {
+            CPU_SET(c, &set);
+            ++n;
+        }
+    // (only CPUs this process may run on anyway: a container's cpuset stays in force)
+    cpu_set_t allowed;
+    if (n && pthread_getaffinity_np(pthread_self(), sizeof allowed, &allowed) == 0) {
+        cpu_set_t both;
+        CPU_AND(&both, &set, &allowed);
+        if (CPU_COUNT(&both) > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof both, &both);
+    }
+}
+
+int put_affinity(const HostAffinity &h, int32_t *numa_node, char *cpulist, size_t cap)
+{
+    if (numa_node) *numa_node = h.node;
+    if (cpulist && cap) {
+        std::snprintf(cpulist, cap, "%s", h.cpulist.c_str());
+    }
+    return APTGPU_OK;
+}
+
 struct Item {
     int index;            // position in the caller's arrays
     const uint8_t *data;  // f32 samples, or the payload of the WAV data chunk
@@ -326,6 +444,7 @@ void worker(Shared &sh, int device, std::vector<Item> items)
     SessionLease lease;
     try {
         apt::hip_check(hipSetDevice(device), "hipSetDevice");
+        pin_worker_to_device_node(device);  // before anything is allocated or first touched by this thread
         uint64_t max_n = 0, max_bytes = 0;
         for (const Item &it : items) {
             max_n = std::max(max_n, it.n);
@@ -685,6 +804,21 @@ void *aptgpu_host_alloc(size_t bytes)
 void aptgpu_host_free(void *p)
 {
     if (p) (void)hipHostFree(p);
+}
+
+int aptgpu_host_affinity(int device, char *pci_bdf, int32_t *numa_node, char *cpulist, size_t cpulist_cap)
+{
+    std::string bdf;
+    const HostAffinity h = affinity_of_device(device, &bdf);
+    if (pci_bdf) std::snprintf(pci_bdf, 16, "%s", bdf.c_str());
+    return put_affinity(h, numa_node, cpulist, cpulist_cap);
+}
+
+int aptgpu_host_affinity_from_sysfs(const char *sysfs_root, const char *pci_bdf, int32_t *numa_node, char *cpulist,
+                                    size_t cpulist_cap)
+{
+    if (!sysfs_root || !pci_bdf) return APTGPU_ERR_INVALID;
+    return put_affinity(affinity_from_sysfs(sysfs_root, pci_bdf), numa_node, cpulist, cpulist_cap);
 }
 
 }  // extern "C"

@@ -229,3 +229,11 @@ def test_decode_batch_one_per_call_neighbours_differ(oracle):
             assert not isinstance(g, Exception), (rep, i, g)
             assert _same(g, wants[i]), (rep, i)
             assert results[i].n_rows == wants[i].size // 2080
+
+
+def test_worker_affinity_lookup_on_this_host():
+    """The real lookup: the GPU has a PCI address; whatever sysfs says about its NUMA node, a worker that pins itself
+    (or finds nothing to pin to) still decodes — the batch tests above ran that way."""
+    bdf, node, cpus = apt.host_affinity(0)
+    assert len(bdf.split(":")) == 3, bdf
+    assert (node < 0 and cpus == "") or (node >= 0 and cpus != "")
