@@ -283,6 +283,11 @@ typedef struct aptgpu_batch_stats {
     double d2h_seconds;
     int32_t workers;
     int32_t recordings_per_call;
+    double gate_wait_seconds; /* summed over the workers: time spent waiting for the per-device upload gate    */
+    double setup_seconds;     /* summed: leasing (or building) the session and sizing its buffers, before the
+                                 first upload — a session built inside the call shows here                      */
+    int32_t sessions_created; /* sessions that were not in the cache (0 in a warmed-up process)                 */
+    int32_t workers_pinned;   /* workers that found their GPU's NUMA node and pinned themselves to its CPUs     */
 } aptgpu_batch_stats;
 
 int aptgpu_decode_batch(const aptgpu_context *ctx, const aptgpu_settings *settings,

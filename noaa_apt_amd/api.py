@@ -131,7 +131,9 @@ class BatchStats(C.Structure):
     """aptgpu_batch_stats: what a host-fed batch moved and how long it took."""
     _fields_ = [("seconds", C.c_double), ("samples", C.c_uint64), ("h2d_bytes", C.c_uint64),
                 ("d2h_bytes", C.c_uint64), ("h2d_seconds", C.c_double), ("d2h_seconds", C.c_double),
-                ("workers", C.c_int32), ("recordings_per_call", C.c_int32)]
+                ("workers", C.c_int32), ("recordings_per_call", C.c_int32),
+                ("gate_wait_seconds", C.c_double), ("setup_seconds", C.c_double),
+                ("sessions_created", C.c_int32), ("workers_pinned", C.c_int32)]
 
 
 class KernelTime(C.Structure):

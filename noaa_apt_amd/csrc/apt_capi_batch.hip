@@ -194,6 +194,7 @@ SessionLease session_acquire(const SessionKey &key, uint64_t max_n)
             if ((*it)->key == key && (*it)->max_n >= max_n) {
                 std::unique_ptr<Session> s = std::move(*it);
                 c.idle.erase(it);
+                s->fresh = false;
                 return SessionLease(std::move(s));
             }
         }
@@ -364,12 +365,12 @@ HostAffinity affinity_of_device(int device, std::string *bdf_out)
 }
 
 // the calling thread onto the CPUs of `device`'s NUMA node (no-op when unknown, or APTGPU_NUMA_PIN=0)
-void pin_worker_to_device_node(int device)
+bool pin_worker_to_device_node(int device)
 {
     const char *e = std::getenv("APTGPU_NUMA_PIN");
-    if (e && e[0] == '0') return;
+    if (e && e[0] == '0') return false;
     const HostAffinity h = affinity_of_device(device, nullptr);
-    if (h.node < 0) return;
+    if (h.node < 0) return false;
     cpu_set_t set;
     CPU_ZERO(&set);
     int n = 0;
@@ -383,8 +384,9 @@ void pin_worker_to_device_node(int device)
     if (n && pthread_getaffinity_np(pthread_self(), sizeof allowed, &allowed) == 0) {
         cpu_set_t both;
         CPU_AND(&both, &set, &allowed);
-        if (CPU_COUNT(&both) > 0) (void)pthread_setaffinity_np(pthread_self(), sizeof both, &both);
+        if (CPU_COUNT(&both) > 0) return pthread_setaffinity_np(pthread_self(), sizeof both, &both) == 0;
     }
+    return false;
 }
 
 int put_affinity(const HostAffinity &h, int32_t *numa_node, char *cpulist, size_t cap)
@@ -420,6 +422,8 @@ struct Shared {
     int first_error_code = APTGPU_OK;
     double h2d_seconds = 0, d2h_seconds = 0;  // summed over workers (host wall time inside the copy calls / collects)
     uint64_t h2d_bytes = 0, d2h_bytes = 0;
+    double gate_wait_seconds = 0, setup_seconds = 0;
+    int sessions_created = 0, workers_pinned = 0;
 };
 
 std::mutex &upload_gate(int device)
@@ -444,7 +448,9 @@ void worker(Shared &sh, int device, std::vector<Item> items)
     SessionLease lease;
     try {
         apt::hip_check(hipSetDevice(device), "hipSetDevice");
-        pin_worker_to_device_node(device);  // before anything is allocated or first touched by this thread
+        const auto t_setup0 = clock::now();
+        const bool pinned = pin_worker_to_device_node(device);  // before anything is allocated or first touched by this thread
+        double t_gate = 0;
         uint64_t max_n = 0, max_bytes = 0;
         for (const Item &it : items) {
             max_n = std::max(max_n, it.n);
@@ -472,6 +478,8 @@ void worker(Shared &sh, int device, std::vector<Item> items)
         const size_t n_chunks = (items.size() + static_cast<size_t>(B) - 1) / static_cast<size_t>(B);
         const int n_sets = static_cast<int>(std::min<size_t>(Session::kSets, n_chunks));
         for (int k = 0; k < n_sets; ++k) S.ensure_set(k, max_bytes + 64, out_cap);
+        const double t_setup = seconds(t_setup0, clock::now());
+        const bool created = S.fresh;
         double t_h2d = 0, t_d2h = 0;
         uint64_t b_h2d = 0, b_d2h = 0;
 
@@ -491,7 +499,9 @@ void worker(Shared &sh, int device, std::vector<Item> items)
             // busy for the duration of the copy.  Two workers of one device doing that at once contend for the link
             // and for the runtime's staging path (measured: 34 GB/s together against 52 GB/s one after the other),
             // so uploads to one device take turns; the worker that waits has its decode / download in flight meanwhile.
+            const auto g0 = clock::now();
             std::lock_guard<std::mutex> gate(upload_gate(device));
+            t_gate += seconds(g0, clock::now());
             for (size_t k = from; k < to; ++k) {
                 const Item &it = items[k];
                 if (it.bytes)
@@ -652,6 +662,10 @@ void worker(Shared &sh, int device, std::vector<Item> items)
         sh.d2h_seconds += t_d2h;
         sh.h2d_bytes += b_h2d;
         sh.d2h_bytes += b_d2h;
+        sh.gate_wait_seconds += t_gate;
+        sh.setup_seconds += t_setup;
+        sh.sessions_created += created ? 1 : 0;
+        sh.workers_pinned += pinned ? 1 : 0;
     } catch (const Error &e) {
         lease.poison();  // (its destructor synchronises the streams before anything is freed)
         std::lock_guard<std::mutex> lock(sh.mu);
@@ -760,6 +774,10 @@ int decode_batch_impl(const aptgpu_context *ctx, const aptgpu_settings *settings
             stats->d2h_seconds = sh.d2h_seconds;
             stats->workers = static_cast<int32_t>(threads.size());
             stats->recordings_per_call = sh.per_call;
+            stats->gate_wait_seconds = sh.gate_wait_seconds;
+            stats->setup_seconds = sh.setup_seconds;
+            stats->sessions_created = sh.sessions_created;
+            stats->workers_pinned = sh.workers_pinned;
         }
         if (sh.first_error_code != APTGPU_OK) {
             put_err(err, err_cap, sh.first_error);

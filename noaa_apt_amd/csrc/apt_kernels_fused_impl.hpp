@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 #pragma clang fp contract(off)
@@ -126,12 +127,22 @@ struct FusedGeom {
     static constexpr int XT_PAD = (XT + 3) & ~3;
     static constexpr int G = 38 * PW;                                 // sync template length
     static constexpr int FWIN = L + G - 1;                            // F window per thread
-    // one LDS region: the x tile, then R/F at [0, TILE_K+G), D and later C at D_OFF
-    static constexpr int D_OFF = (TILE_K + G + 3) & ~3;
+    // one LDS region: the x tile, then R / F at [0, TILE_K) (+ the few words the last thread's pulse-sum window reads past
+    // it: never used), D and later the pulse sums at D_OFF.  Until round 4 the R / F region kept G words of slack from
+    // the days when stage 4 read 13 + G - 1 consecutive F values per thread, the pulse sums 36 PW (they need QTAIL),
+    // and the per-thread |F| sums had 256 words of their own: 28.5 KB, five workgroups per CU.  Trimmed — the |F| sums
+    // now land on the dead F region — the work-rate stages need 26.1 KB: SIX workgroups per CU for kernels of <= 80 VGPRs.
+    static constexpr int D_OFF = (TILE_K + 2 * PW + 2 + 3) & ~3;
     static constexpr int XT_LDS = XB == 2 ? (XT_PAD / 2 + 4) : XT_PAD;  // floats of LDS under the x tile
-    // (+36*PW: the fast correlation's pulse-sum window of the last thread reaches past the tile)
-    // (+NTHR: the per-thread |F| sums behind the strict modes' bounds of the group maxima)
-    static constexpr int W_LDS_FLOATS = D_OFF + TILE_K + 36 * PW + NTHR;  // what the work-rate stages need
+    // the pulse sums a thread of stage 4 reads: positions p0 + 2 PW n, n <= 31, p0 <= PRE_K + (blocks - 1) * 2 PW L + 2 PW - 1
+    static constexpr int NBLK4 = (OWN_K + 2 * PW * L - 1) / (2 * PW * L);
+    static constexpr int QMAX = PRE_K + (NBLK4 - 1) * 2 * PW * L + 2 * PW - 1 + 2 * PW * 31;
+    static constexpr int QTAIL = QMAX + 1 > TILE_K ? ((QMAX + 1 - TILE_K + 3) & ~3) : 0;
+    static constexpr int Q_FLOATS = TILE_K + QTAIL;
+    // per-thread |F| sums of the strict modes' bounds: inside the R / F region, behind the partial maxima (stage 4)
+    static constexpr int AB_OFF = ((OWN_K / (4 * L) + 2) * 12 + 3) & ~3;
+    static_assert(AB_OFF + NTHR + 8 <= D_OFF, "|F| sums and partial maxima both fit the dead F region");
+    static constexpr int W_LDS_FLOATS = D_OFF + Q_FLOATS;  // what the work-rate stages need
     static constexpr int LDS_FLOATS = XT_LDS > W_LDS_FLOATS ? XT_LDS : W_LDS_FLOATS;
     // workgroups a CU's 160 KB of LDS hold (the specialised kernels' occupancy; at most 8 waves per SIMD)
     static constexpr int WGS_PER_CU_LDS = TABLE ? 2 : (160 * 1024) / (LDS_FLOATS * 4);
@@ -1251,7 +1262,8 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         GroupMax *__restrict__ gm_out = slots[slot_late].gm;
         constexpr int PUL = 2 * PW;
         static_assert(L == 13 && PUL == 6 && Gm::GS == 52, "the position remapping below is written for 13-sample threads and 6-sample pulses");
-        float *AB = lds + Gm::D_OFF + Gm::TILE_K + 36 * PW;  // [NTHR] per-thread sums of |F|
+        // [NTHR] per-thread sums of |F|: written once F (region P) is dead, behind the partial maxima
+        float ab_mine = 0.f;
         {
             APT_MARK("BEGIN pulse_sums");
             // pulse sums of the thread's own L positions -> Q (D is dead).  B[p] = F[p] + ... + F[p + 2 PW - 1] as
@@ -1295,10 +1307,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                     for (int b = 0; b < L; ++b)
                         a = a + ((kq + b >= k_lo && kq + b < k_hi) ? __builtin_fabsf(fw[b]) : 0.f);
                 }
-                AB[tid] = a;
+                ab_mine = a;
             }
         }
         __syncthreads();  // pulse sums complete; F (region P) is dead from here on
+        if constexpr (!FAST) lds[Gm::AB_OFF + tid] = ab_mine;  // (read after the next barrier, by the threads that write group records)
         APT_MARK("END pulse_sums");
         // ---- the correlation of the owned positions, REMAPPED: thread t = 6 blk + r takes the 13 positions
         // p_j = PRE_K + 78 blk + r + 6 j (one pulse apart), whose 19 pulse sums each are V[j + k] with
@@ -1408,7 +1421,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 constexpr int NT = (Gm::GS + Gm::G - 1 + L - 1) / L;
                 static_assert(NT - 1 <= 3 + kPostThreads, "the |F| window must end inside the tile");
                 float av[NT];
-                int abofs = Gm::D_OFF + Gm::TILE_K + 36 * PW + tid;  // (AB + tid as one opaque register: immediate offsets below)
+                int abofs = Gm::AB_OFF + tid;  // (AB + tid as one opaque register: immediate offsets below)
                 asm volatile("" : "+v"(abofs));
 #pragma unroll
                 for (int e = 0; e < NT; ++e) av[e] = lds[abofs + e];
@@ -1507,6 +1520,9 @@ void launch_fused_args(const FusedLaunch &a)
     using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), MODE == kModeF16Taps>;
     size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
     if constexpr (Gm::TABLE) lds = std::max<size_t>(a.table_lds_floats, Gm::W_LDS_FLOATS) * sizeof(float);
+    // APTGPU_FUSED_LDS_PAD=bytes (A/B switch, read per launch): more dynamic LDS than the kernel uses = fewer workgroups
+    // per CU (2048 takes the 48 kHz kernels from six back to five)
+    if (const char *e = std::getenv("APTGPU_FUSED_LDS_PAD")) lds += static_cast<size_t>(std::max(0, std::atoi(e)));
     constexpr auto kern = k_fused<L, M, T1, T2, PW, NTHR, XT, MODE>;
     ensure_dynamic_lds<kern>(lds);
     const unsigned tiles = static_cast<unsigned>((a.max_w + Gm::OWN_K - 1) / Gm::OWN_K);

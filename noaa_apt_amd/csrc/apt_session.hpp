@@ -58,6 +58,7 @@ struct Session {
     uint64_t device_bytes = 0;  // what the session holds in HBM (cache accounting): the plan's buffers + the sets'
     uint64_t plan_bytes = 0;    // ... of which the plan's (re-counted when the session returns to the cache)
     uint64_t last_used = 0;
+    bool fresh = true;          // built for the current lease (false once it has been through the cache)
 
     ~Session();
     // (re)sizes set `k` for inputs of `in_bytes` bytes and rows of `out_cap` floats; no-op when large enough
