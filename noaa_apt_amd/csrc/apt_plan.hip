@@ -564,6 +564,12 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
             std::vector<int> idx;
             for (int i : live)
                 if (is_pcm[static_cast<size_t>(i)] == kind) idx.push_back(i);
+#if defined(APT_WITH_PROBES) || defined(APT_DEBUG_SKIP)
+            const int rep_f = [] { const char *e = std::getenv("APTGPU_DEBUG_REPEAT_FRONT"); return e ? std::max(1, std::atoi(e)) : 1; }();
+#else
+            constexpr int rep_f = 1;
+#endif
+            for (int rf = 0; rf < rep_f; ++rf)
             for_chunks(idx, [&](const CallArgs &c, uint64_t max_w, uint32_t) {
                 timed_on(fs, "fused_front_end", [&] {
                     const int kmode = fused_f16 ? 1 : (fused_fast ? 2 : 0);
@@ -645,6 +651,7 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
             set_result(cur, d_results.ptr + slot0 + i, Result{APTGPU_ERR_INTERNAL, 3, 0, 0, wlen[static_cast<size_t>(i)], 0});
     } else if (sync) {
         bool gather_wanted = true;
+        int gather_reps = 1;
         // 4. find_sync (decode.rs:204-263): terminal flags, orbit
         if (mode == APTGPU_MODE_GENERIC) {
             // reference-shaped picker: full sliding-window terminals + sequential orbit
@@ -664,26 +671,36 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
             // 4 gather.  Timing experiments: what each kernel behind the front end costs a pipelined step; the results
             // are then garbage, so a product build does not even read the variable.)
 #if defined(APT_WITH_PROBES) || defined(APT_DEBUG_SKIP)
-            static const int skip = [] {
+            const int skip = [] {
                 const char *e = std::getenv("APTGPU_DEBUG_SKIP");
                 return e ? std::atoi(e) : 0;
             }();
+            // APTGPU_DEBUG_REPEAT_WORDS / _ORBIT / _GATHER = n: the kernel is launched n times instead of once (each is
+            // idempotent: same inputs, same outputs) — what ONE more launch of it costs a pipelined step, with every
+            // result still valid
+            const int rep_w = [] { const char *e = std::getenv("APTGPU_DEBUG_REPEAT_WORDS"); return e ? std::max(1, std::atoi(e)) : 1; }();
+            const int rep_o = [] { const char *e = std::getenv("APTGPU_DEBUG_REPEAT_ORBIT"); return e ? std::max(1, std::atoi(e)) : 1; }();
+            const int rep_g = [] { const char *e = std::getenv("APTGPU_DEBUG_REPEAT_GATHER"); return e ? std::max(1, std::atoi(e)) : 1; }();
 #else
-            constexpr int skip = 0;
+            constexpr int skip = 0, rep_w = 1, rep_o = 1, rep_g = 1;
 #endif
+            gather_reps = rep_g;
             for_chunks(live, [&](const CallArgs &c, uint64_t max_w, uint32_t) {
                 if (!(skip & 1))
-                    timed("sync_nodes", [&] { sync_nodes(cur, c, d_slots.ptr, max_w, pw, spr, md, use_fused && fused_fast, !use_fused); });
+                    for (int r = 0; r < rep_w; ++r)
+                        timed("sync_nodes", [&] { sync_nodes(cur, c, d_slots.ptr, max_w, pw, spr, md, use_fused && fused_fast, !use_fused); });
                 if (!(skip & 2))
-                    timed("sync_orbit", [&] { sync_orbit(cur, c, d_slots.ptr, spr, md, pw, picker_force); });
+                    for (int r = 0; r < rep_o; ++r)
+                        timed("sync_orbit", [&] { sync_orbit(cur, c, d_slots.ptr, spr, md, pw, picker_force); });
             });
             gather_wanted = !(skip & 4);
         }
         // 5. aligned rows + final /pw (decode.rs:120-134,158-159)
         if (gather_wanted)
-            for_chunks(live, [&](const CallArgs &c, uint64_t, uint32_t max_cap) {
-                timed("gather_rows", [&] { gather_rows_call(cur, c, d_slots.ptr, spr, pw, max_cap); });
-            });
+            for (int r = 0; r < gather_reps; ++r)
+                for_chunks(live, [&](const CallArgs &c, uint64_t, uint32_t max_cap) {
+                    timed("gather_rows", [&] { gather_rows_call(cur, c, d_slots.ptr, spr, pw, max_cap); });
+                });
     } else {
         // decode.rs:135-159 — crop to whole rows, resample_with_filter(NoFilter)
         for (int i : live) {
