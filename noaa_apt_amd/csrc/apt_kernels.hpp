@@ -180,8 +180,8 @@ bool fused_table_front_end(hipStream_t s, const TableGeom &geom, int mode, bool 
 bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom);
 uint32_t fused_phase_table_floats(uint32_t l, uint32_t t1);
 void fused_phase_table(uint32_t l, const float *coeff, uint32_t t1, float *table);  // host: [l][tpp], rows 16-byte aligned
-bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, int mode, bool pcm16, const CallArgs &call,
-                           const FusedParams *d_prm, uint64_t max_w);
+bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, uint32_t t2, uint32_t pw, int mode, bool pcm16,
+                           const CallArgs &call, const FusedParams *d_prm, uint64_t max_w);
 
 // ---- fused front end for any rate / profile (apt_kernels_fused_any.hip) -------------
 // run-time parameters, taps phase-major in LDS; same outputs as fused_front_end

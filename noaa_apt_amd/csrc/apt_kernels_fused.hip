@@ -37,6 +37,7 @@ bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t 
 {
     if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) return true;    // 48 kHz, standard
     if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3) return true;  // 96 kHz, standard
+    if (l == 13 && m == 30 && t1 == 2783 && t2 == 61 && pw == 5) return true;    // 48 kHz, slow profile
     return false;
 }
 
@@ -214,6 +215,13 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
         }
         return true;
     }
+    if (l == 13 && m == 30 && t1 == 2783 && t2 == 61 && pw == 5 && mode != kModeF16Taps) {
+        if (mode == kModeFast)
+            pcm16 ? fused_launch_48k_slow_fast_i16(a) : fused_launch_48k_slow_fast_f32(a);
+        else
+            pcm16 ? fused_launch_48k_slow_i16(a) : fused_launch_48k_slow_f32(a);
+        return true;
+    }
     if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3 && mode != kModeF16Taps) {
         // twice the input per work sample: 128-thread workgroups keep the x tile at 51.8 KB
         if (mode == kModeFast)
@@ -361,7 +369,10 @@ bool phase_geom(uint32_t threads, uint32_t l, uint32_t m, uint32_t t1, TableGeom
 
 bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom)
 {
-    if (l < 2 || m == 0 || t1 == 0 || t2 != 37 || pw != 3) return false;  // (work-rate stages: standard profile)
+    if (l < 2 || m == 0 || t1 == 0) return false;
+    // work-rate stages: the standard profile's (256- and 512-thread workgroups), the fast profile's (256)
+    if (t2 == 43 && pw == 4) return phase_geom(256, l, m, t1, geom);
+    if (t2 != 37 || pw != 3) return false;
     return phase_geom(256, l, m, t1, geom) || phase_geom(512, l, m, t1, geom);
 }
 
@@ -378,8 +389,8 @@ void fused_phase_table(uint32_t l, const float *coeff, uint32_t t1, float *table
         }
 }
 
-bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, int mode, bool pcm16, const CallArgs &call,
-                           const FusedParams *d_prm, uint64_t max_w)
+bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, uint32_t t2, uint32_t pw, int mode, bool pcm16,
+                           const CallArgs &call, const FusedParams *d_prm, uint64_t max_w)
 {
     if (call.count == 0 || call.count > static_cast<uint32_t>(kMaxCall)) return false;
     if (pcm16)
@@ -387,6 +398,13 @@ bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, int mode, bool 
             if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 1u) return false;
     const FusedLaunch a{s, &call, d_prm, max_w, static_cast<size_t>(geom.xt)};
     const bool wide = geom.step_r > 256;  // 512-thread workgroups
+    if (t2 == 43 && pw == 4) {  // the fast profile's work-rate stages
+        if (wide) return false;
+        if (mode == kModeFast) pcm16 ? fused_launch_phase_fastp_fast_i16(a) : fused_launch_phase_fastp_fast_f32(a);
+        else if (mode == kModeStrict) pcm16 ? fused_launch_phase_fastp_i16(a) : fused_launch_phase_fastp_f32(a);
+        else return false;
+        return true;
+    }
     if (mode == kModeFast) {
         if (wide) pcm16 ? fused_launch_phase512_std_fast_i16(a) : fused_launch_phase512_std_fast_f32(a);
         else pcm16 ? fused_launch_phase_std_fast_i16(a) : fused_launch_phase_std_fast_f32(a);

@@ -62,8 +62,8 @@ namespace {
 // kernels (round 2: 4 + 12 — a whole group of four either side; 244 instead of 240 of 256 threads own samples, 116
 // instead of 112 of the 96 kHz kernels' 128).  The table-driven and phase-resident forms keep 4 + 12: their
 // stage 1 is laid out for a tile that starts on a group boundary.
-constexpr int kPreThreadsWide = 4, kPostThreadsWide = 12;
-constexpr int kPreThreadsNarrow = 3, kPostThreadsNarrow = 9;
+// (Round 4: computed from T2 and PW — FusedGeom — so that the work-rate stages also serve the fast and slow profiles:
+// 43 / 61-tap low-pass, pixel width 4 / 5.)
 constexpr float kNegInfF = -__builtin_huge_valf();
 
 // max(a, b, c) of values that are results of floating-point additions (never signalling NaNs), a quiet NaN
@@ -106,9 +106,13 @@ struct FusedGeom {
     static constexpr bool TABLE = M <= 0;   // run-time resampling factors (table-driven or phase-resident stage 1)
     static constexpr bool PHASE = M == -1;  // ... with the taps of a thread's polyphase branch in registers
     static constexpr int kFusedThreads = NTHR;
-    static constexpr int kPreThreads = TABLE ? kPreThreadsWide : kPreThreadsNarrow;
-    static constexpr int kPostThreads = TABLE ? kPostThreadsWide : kPostThreadsNarrow;
-    static constexpr int kOwnThreads = NTHR - kPreThreads - kPostThreads;
+    // threads of L samples in front of / behind the owned ones: T2 + 1 samples of history, 38 PW - 1 of look-ahead;
+    // whole groups of four threads where stage 1 is laid out for a tile that starts on a group boundary (TABLE, PHASE);
+    // the owned threads are whole groups of four in every form (standard profile: 3 + 9 / 4 + 12 as before)
+    static constexpr int kPreNeed = (T2 + 1 + L - 1) / L, kPostNeed = (38 * PW - 1 + L - 1) / L;
+    static constexpr int kPreThreads = TABLE ? (kPreNeed + 3) / 4 * 4 : kPreNeed;
+    static constexpr int kOwnThreads = (NTHR - kPreThreads - (TABLE ? (kPostNeed + 3) / 4 * 4 : kPostNeed)) / 4 * 4;
+    static constexpr int kPostThreads = NTHR - kPreThreads - kOwnThreads;
     // SPLIT stage 1 (apt_kernels_fused_launch.hpp): two sub-tiles of NS = NTHR / 2 windows through the same LDS
     static constexpr bool SPLIT = !TABLE && !F16TAPS && NTHR == 256;
     static constexpr int NS = SPLIT ? NTHR / 2 : NTHR;                // windows per input tile in LDS
@@ -139,10 +143,14 @@ struct FusedGeom {
     static constexpr int QMAX = PRE_K + (NBLK4 - 1) * 2 * PW * L + 2 * PW - 1 + 2 * PW * 31;
     static constexpr int QTAIL = QMAX + 1 > TILE_K ? ((QMAX + 1 - TILE_K + 3) & ~3) : 0;
     static constexpr int Q_FLOATS = TILE_K + QTAIL;
-    // per-thread |F| sums of the strict modes' bounds: inside the R / F region, behind the partial maxima (stage 4)
-    static constexpr int AB_OFF = ((OWN_K / (4 * L) + 2) * 12 + 3) & ~3;
-    static_assert(AB_OFF + NTHR + 8 <= D_OFF, "|F| sums and partial maxima both fit the dead F region");
-    static constexpr int W_LDS_FLOATS = D_OFF + Q_FLOATS;  // what the work-rate stages need
+    // Stage 4 comes in two forms: COMPACT4 (pixel width 3: the block / group bookkeeping written out for 6-sample pulses,
+    // partial maxima through LDS) and a general one (any pixel width: the correlation values themselves go through the
+    // dead F region).  Per-thread |F| sums of the strict modes' bounds: COMPACT4 — inside the R / F region, behind the
+    // partial maxima; general — a region of their own behind the pulse sums.
+    static constexpr bool COMPACT4 = PW == 3 && L == 13;
+    static constexpr int AB_OFF = COMPACT4 ? (((OWN_K / (4 * L) + 2) * 12 + 3) & ~3) : D_OFF + Q_FLOATS;
+    static_assert(!COMPACT4 || AB_OFF + NTHR + 8 <= D_OFF, "|F| sums and partial maxima both fit the dead F region");
+    static constexpr int W_LDS_FLOATS = D_OFF + Q_FLOATS + (COMPACT4 ? 0 : NTHR);  // what the work-rate stages need
     static constexpr int LDS_FLOATS = XT_LDS > W_LDS_FLOATS ? XT_LDS : W_LDS_FLOATS;
     // workgroups a CU's 160 KB of LDS hold (the specialised kernels' occupancy; at most 8 waves per SIMD)
     static constexpr int WGS_PER_CU_LDS = TABLE ? 2 : (160 * 1024) / (LDS_FLOATS * 4);
@@ -152,6 +160,7 @@ struct FusedGeom {
     // (stage-1 tap table: chunk-major per thread half, fused_branch_taps / the layout functions in apt_kernels_fused_launch.hpp)
     static constexpr int DW = L + T2 - 1;                             // envelope window per thread
     static_assert(PRE_K >= T2 + 1, "pre-halo too small for the low-pass");
+    static_assert(kOwnThreads > 0, "no owned threads");
     static_assert((kFusedThreads - kPreThreads - kOwnThreads) * L >= G - 1, "post-halo too small");
     static_assert(OWN_K % 4 == 0, "owned range must be float4-aligned");
     static_assert(kOwnThreads % 4 == 0, "whole correlation groups");
@@ -1265,7 +1274,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     if (want_gm) {
         GroupMax *__restrict__ gm_out = slots[slot_late].gm;
         constexpr int PUL = 2 * PW;
-        static_assert(L == 13 && PUL == 6 && Gm::GS == 52, "the position remapping below is written for 13-sample threads and 6-sample pulses");
+        static_assert(Gm::GS == 4 * L, "a group is four threads' samples");
         // [NTHR] per-thread sums of |F|: written once F (region P) is dead, behind the partial maxima
         float ab_mine = 0.f;
         {
@@ -1329,10 +1338,42 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         // A block of 78 positions is 1.5 groups of 52: the thread reduces its values to two partial maxima,
         // for the group its first positions lie in and for the next one, and the block pair's six partial
         // lists go through LDS (region P) to the thread that writes a group's record.
-        constexpr int NB6 = ((Gm::OWN_K + 6 * L - 1) / (6 * L)) * 6;  // threads with a block (the last may be partial)
+        constexpr int NB6 = Gm::NBLK4 * PUL;  // threads with a block (the last may be partial)
         static_assert(NB6 <= NTHR, "one thread per block column");
-        float *PMX = P;  // [groups][12]: partial maxima by group (6 from each of the two blocks that reach it, or -inf)
+        float *PMX = P;  // COMPACT4: [groups][12] partial maxima by group (6 from each of the two blocks that reach it, or -inf)
+        float *CV = P;   // general form: the correlation values themselves, by tile position (F is dead)
         APT_MARK("BEGIN correlation");
+        if constexpr (!Gm::COMPACT4) {
+            // ---- general form (any pixel width; the fast / slow profiles' 8- and 10-sample pulses): the same evaluation
+            // at positions one pulse apart — thread t = PUL blk + r takes p_j = PRE_K + PUL L blk + r + PUL j — and the
+            // values go to LDS where the thread that writes a group's record takes the maximum of its 52.
+            if (tid < NB6) {
+                const uint32_t blk = static_cast<uint32_t>(tid) / static_cast<uint32_t>(PUL);
+                const int rr = tid - static_cast<int>(blk) * PUL;
+                const int p0 = Gm::PRE_K + static_cast<int>(blk) * (PUL * L) + rr;
+                const float *vsrc = Q + p0;
+                constexpr int NP2 = (L + 1) / 2;
+                f2 VA[NP2 + 9], VS[NP2 + 8], cp[NP2];
+#pragma unroll
+                for (int p2 = 0; p2 < NP2 + 9; ++p2) VA[p2] = (f2){vsrc[PUL * (2 * p2)], vsrc[PUL * (2 * p2 + 1)]};
+                int odd_ofs = PUL;
+                asm volatile("" : "+v"(odd_ofs));  // (see the compact form)
+                const float *vsrc_odd = vsrc + odd_ofs;
+#pragma unroll
+                for (int p2 = 0; p2 < NP2 + 8; ++p2) VS[p2] = (f2){vsrc_odd[PUL * (2 * p2)], vsrc_odd[PUL * (2 * p2 + 1)]};
+                sync_corr_pulse_stride<NP2>(VA, VS, cp);
+#pragma unroll
+                for (int j = 0; j < L; ++j) {
+                    float cj = (j & 1) ? cp[j / 2].y : cp[j / 2].x;
+                    const int pq = p0 + PUL * j;
+                    if (!interior) {
+                        if (pq == k_lo && !(cj > 0.f)) cj = 0.f;     // the picker starts from the peak (0, 0.)
+                        if (pq < k_lo || pq >= c_hi) cj = kNegInfF;  // not a correlation position
+                    }
+                    if (pq < Gm::PRE_K + Gm::OWN_K) CV[pq] = cj;
+                }
+            }
+        } else
         if (tid < NB6) {
             const uint32_t blk = static_cast<uint32_t>(tid) / 6u;
             const int rr = tid - static_cast<int>(blk) * 6;
@@ -1409,17 +1450,39 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         if constexpr (INT) APT_MARK("BEGIN group_record");
         if (((tid - kPreThreads) & 3) == 0 && tid >= kPreThreads && tid < kPreThreads + kOwnThreads && (INT || kq < c_hi)) {
             const int gl = (tid - kPreThreads) / 4;
-            typedef float f4g __attribute__((ext_vector_type(4)));
-            const f4g *pm = reinterpret_cast<const f4g *>(PMX + gl * 12);
-            const f4g q0 = pm[0], q1 = pm[1], q2 = pm[2];
-            float mx = max3_of_sums(q0.x, q0.y, q0.z);
-            mx = max3_of_sums(mx, q0.w, q1.x);
-            mx = max3_of_sums(mx, q1.y, q1.z);
-            mx = max3_of_sums(mx, q1.w, q2.x);
-            mx = max3_of_sums(mx, q2.y, q2.z);
-            mx = max3_of_sums(mx, q2.w, q2.w);
+            float mx;
+            bool open;
+            if constexpr (Gm::COMPACT4) {
+                typedef float f4g __attribute__((ext_vector_type(4)));
+                const f4g *pm = reinterpret_cast<const f4g *>(PMX + gl * 12);
+                const f4g q0 = pm[0], q1 = pm[1], q2 = pm[2];
+                mx = max3_of_sums(q0.x, q0.y, q0.z);
+                mx = max3_of_sums(mx, q0.w, q1.x);
+                mx = max3_of_sums(mx, q1.y, q1.z);
+                mx = max3_of_sums(mx, q1.w, q2.x);
+                mx = max3_of_sums(mx, q2.y, q2.z);
+                mx = max3_of_sums(mx, q2.w, q2.w);
+                open = mx == __builtin_huge_valf();  // fast mode's NaN mark (or a maximum that IS +inf: same record)
+            } else {
+                // the group's 52 values from LDS (NaNs drop out of v_max3_f32; fast mode finds them in the sum)
+                float cv[Gm::GS];
+                int cofs = Gm::PRE_K + gl * Gm::GS;
+                asm volatile("" : "+v"(cofs));
+#pragma unroll
+                for (int e = 0; e < Gm::GS; ++e) cv[e] = lds[cofs + e];
+                mx = max3_of_sums(cv[0], cv[1], cv[2]);
+#pragma unroll
+                for (int e = 3; e + 1 < Gm::GS; e += 2) mx = max3_of_sums(mx, cv[e], cv[e + 1]);
+                if constexpr ((Gm::GS & 1) == 0) mx = max3_of_sums(mx, cv[Gm::GS - 1], cv[Gm::GS - 1]);
+                open = mx == __builtin_huge_valf();
+                if constexpr (FAST) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int e = 0; e < Gm::GS; ++e) sum = sum + ((cv[e] == kNegInfF) ? 0.f : cv[e]);
+                    if (sum != sum) open = true;  // a NaN position (decode.rs:250), or +inf and -inf values: always evaluated
+                }
+            }
             float hi = mx, lo = mx;
-            bool open = mx == __builtin_huge_valf();  // fast mode's NaN mark (or a maximum that IS +inf: same record)
             if constexpr (!FAST) {
                 // |F| over the group's window: the threads that hold positions kq .. kq + GS + G - 2
                 constexpr int NT = (Gm::GS + Gm::G - 1 + L - 1) / L;

@@ -552,9 +552,13 @@ void gather_rows_call(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slo
                       uint32_t max_rows_cap)
 {
     if (call.count == 0) return;
-    // APTGPU_GATHER_ITERS=n (A/B switch, read per launch): the flat form, n quads per thread
-    if (const char *e = std::getenv("APTGPU_GATHER_ITERS")) {
-        const int iters = std::atoi(e);
+    // The flat form wherever a row is 520 quads (every work rate that is a multiple of 4160 Hz) and the rows buffers are
+    // 16-byte aligned: ONE quad per thread measured best beside the front end (pipelined step, 16 recordings per call:
+    // 0.843 ms against 0.853 / 0.847 / 0.855 with 2 / 4 / 8 quads per thread and 0.869 with the form below;
+    // profiles/r04_sweeps.txt).  APTGPU_GATHER_ITERS=n (A/B switch, read per launch): n quads per thread, 0 = the form below.
+    {
+        const char *e = std::getenv("APTGPU_GATHER_ITERS");
+        const int iters = e ? std::atoi(e) : 1;
         bool aligned = true;
         for (uint32_t i = 0; i < call.count; ++i) aligned = aligned && (reinterpret_cast<uintptr_t>(call.rec[i].rows) & 15u) == 0;
         if (iters > 0 && spr / pw == 2080u && spr % pw == 0 && aligned && max_rows_cap > 0) {

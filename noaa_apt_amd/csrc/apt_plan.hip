@@ -573,7 +573,7 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
             for_chunks(idx, [&](const CallArgs &c, uint64_t max_w, uint32_t) {
                 timed_on(fs, "fused_front_end", [&] {
                     const int kmode = fused_f16 ? 1 : (fused_fast ? 2 : 0);
-                    const bool ok = fused == 4 ? fused_phase_front_end(fs, table_geom, kmode, kind == 1, c,
+                    const bool ok = fused == 4 ? fused_phase_front_end(fs, table_geom, t2, pw, kmode, kind == 1, c,
                                                                        d_fused_params.ptr, max_w)
                                   : fused == 3 ? fused_table_front_end(fs, table_geom, kmode, kind == 1, c,
                                                                        d_fused_params.ptr, max_w)

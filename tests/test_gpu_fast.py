@@ -91,6 +91,20 @@ def test_fast_mode_tolerance(oracle, rate, seconds, kw):
     assert 0 < err <= PX_TOL  # it really is the reassociated arithmetic, and within tolerance
 
 
+@pytest.mark.parametrize("rate,seconds,profile,want_fused", [(48000, 14, "slow", 1), (48000, 14, "fast", 4), (96000, 12, "fast", 4)])
+def test_fast_mode_tolerance_on_the_other_profiles(oracle, rate, seconds, profile, want_fused):
+    """APTGPU_MODE_FAST on the fast and slow settings profiles (round 4: their kernels have fast-mode instantiations)."""
+    x = synth_apt(rate, seconds, seed=31)
+    s = apt.Settings.profile(profile)
+    os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                       "resample_cutout", "demodulation_atten")}
+    want, st = oracle.decode(x, rate, True, settings=os_, want_steps=True)
+    rows, pos, res, fused = decode_on_plan(x, rate, apt.MODE_FAST, settings=s)
+    assert fused == want_fused and res.status == 0
+    frac, err = check_tolerance(rows, pos, want, st["sync_pos"], f"{rate} {profile}")
+    assert 0 < err <= PX_TOL
+
+
 def test_fast_mode_pure_noise(oracle):
     """No sync pulses at all: every maximum the picker tracks is a noise maximum."""
     x = synth_noise(48000, 30.0, 5, sigma=4000.0)

@@ -296,7 +296,8 @@ def test_fused_specialisations_are_used(ctx):
     (4); the rest the run-time fused kernel (2); l == 1 the unfused kernels (0)."""
     for rate, profile, want in ((48000, "standard", 1), (96000, "standard", 1), (44100, "standard", 4),
                                 (11025, "standard", 3), (8000, "standard", 3), (22050, "standard", 4),
-                                (48000, "fast", 2), (48000, "slow", 2), (24960, "standard", 0)):
+                                (48000, "fast", 4), (48000, "slow", 1), (96000, "fast", 4), (16000, "fast", 4),
+                                (11025, "fast", 2), (96000, "slow", 2), (24960, "standard", 0)):
         _, st = apt.decode(ctx, apt.Settings.profile(profile), synth_apt(rate, 11, 3), apt.Rate.hz(rate),
                            True, return_stats=True)
         assert st.fused == want, (rate, profile)
@@ -417,6 +418,70 @@ def test_phase_stage1_long_ragged_batched_and_pcm16(oracle):
             res = plan.results(4)
             for i, (want, _) in enumerate(wants[:4]):
                 assert_bitexact(d_out[i][:res[i].n_out].cpu().numpy(), want, f"phase pcm16 {i}")
+        plan.close()
+
+
+PROFILE_CASES = [  # (rate, seconds, profile, fused): the fast and slow profiles on the specialised kernels (round 4)
+    (48000, 14, "slow", 1),    # SPLIT stage 1 for 13 / 30 with 2783 taps; 61-tap low-pass, pixel width 5
+    (48000, 14, "fast", 4),    # phase-resident stage 1 (l = 26) + the fast profile's work-rate stages (43 taps, pw 4)
+    (96000, 12, "fast", 4),    # l = 13, m = 75
+    (16000, 30, "fast", 4), (32000, 16, "fast", 4), (8000, 50, "fast", 4), (12000, 40, "fast", 4), (24000, 20, "fast", 4),
+]
+
+
+@pytest.mark.parametrize("rate,seconds,profile,fused", PROFILE_CASES)
+@pytest.mark.parametrize("sync", [True, False])
+def test_profile_kernels_bitexact(oracle, rate, seconds, profile, fused, sync):
+    """default_settings.toml:120-140: the reference's other two stock profiles on the same kernels as the standard one —
+    the work-rate stages are templates over the low-pass length and the pixel width, stage 4 in its general form."""
+    x = synth_apt(rate, seconds, seed=rate % 97 + seconds)
+    s = apt.Settings.profile(profile)
+    os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                       "resample_cutout", "demodulation_atten")}
+    want = oracle.decode(x, rate, sync, settings=os_)
+    got, st = apt.decode(apt.Context(device=0), s, x, apt.Rate.hz(rate), sync, return_stats=True)
+    assert st.fused == fused, (st.fused, st.l, st.m, st.n_resample_taps, st.n_lowpass_taps)
+    assert_bitexact(got, want, f"profile kernel {rate} {profile} sync={sync}")
+
+
+def test_profile_kernels_ragged_batched_pcm16_and_nonfinite(oracle):
+    """The same kernels over a call of ragged recordings, as PCM16 payloads, with NaN / Inf samples, and with
+    recordings that end around the tile boundaries."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    for profile, rate in (("slow", 48000), ("fast", 48000)):
+        s = apt.Settings.profile(profile)
+        os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                           "resample_cutout", "demodulation_atten")}
+        base = synth_apt(rate, 16, seed=5 + len(profile))
+        ns = [base.size, base.size - 1, base.size - 997, int(rate * 11.3), int(rate * 12.7) + 3, int(rate * 14.01)]
+        recs = [np.ascontiguousarray(base[:n]) for n in ns]
+        bad = recs[2].copy()
+        bad[rate * 3: rate * 3 + 40] = np.nan
+        bad[rate * 7] = np.inf
+        recs.append(bad)
+        wants = [oracle.decode(r, rate, True, settings=os_) for r in recs]
+        plan = apt.Plan(s, apt.Rate.hz(rate), True, max_samples=base.size, max_batch=len(recs))
+        cap = int(plan.info.max_rows)
+        d_in = [torch.from_numpy(r).to(dev) for r in recs]
+        d_out = [torch.empty(cap * 2080, dtype=torch.float32, device=dev) for _ in recs]
+        torch.cuda.synchronize()
+        for _ in range(2):
+            plan.decode_device([t.data_ptr() for t in d_in], [r.size for r in recs], [t.data_ptr() for t in d_out], [cap] * len(recs))
+        res = plan.results(len(recs))
+        for i, want in enumerate(wants):
+            assert res[i].status == 0
+            assert_bitexact(d_out[i][:res[i].n_out].cpu().numpy(), want, f"{profile} batched {i}")
+        # PCM16 payloads of the first four
+        pcm = [r.astype(np.int16) for r in recs[:4]]
+        wants16 = [oracle.decode(p.astype(np.float32), rate, True, settings=os_) for p in pcm]
+        d_pcm = [torch.from_numpy(p).to(dev) for p in pcm]
+        specs = [apt.WavSpec(1, 16, 2, 0, rate, 1, 0, 2 * p.size, p.size, p.size) for p in pcm]
+        torch.cuda.synchronize()
+        plan.decode_device_wav([t.data_ptr() for t in d_pcm], specs, [t.data_ptr() for t in d_out[:4]], [cap] * 4)
+        res = plan.results(4)
+        for i, want in enumerate(wants16):
+            assert_bitexact(d_out[i][:res[i].n_out].cpu().numpy(), want, f"{profile} pcm16 {i}")
         plan.close()
 
 
