@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -362,6 +363,9 @@ bool phase_geom(uint32_t threads, uint32_t l, uint32_t m, uint32_t t1, TableGeom
     g.jl_a = g.jlim / l;
     g.jl_b = g.jlim % l;
     g.perm_q = phase_lane_stride(l, m, stride, threads);
+    if (std::getenv("APTGPU_DEBUG_GEOM"))
+        std::fprintf(stderr, "aptgpu: phase geometry l %u m %u threads %u stride %u step_q %u off_x %u xt %u perm_q %u\n", l, m, threads,
+                     stride, g.step_q, g.off_x, g.xt, g.perm_q);
     if (geom) *geom = g;
     return true;
 }

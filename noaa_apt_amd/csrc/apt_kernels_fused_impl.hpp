@@ -579,28 +579,56 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             for (uint32_t q = tid; q < nt4; q += kFusedThreads) l4[q] = t4[q];
             for (uint32_t q = 4 * nt4 + tid; q < nt; q += kFusedThreads) T[q] = table[q];
         }
+        // the input tile: batches of four loads per thread in flight before anything is written to LDS (a loop that
+        // waited for each round's load paid one HBM round trip per 2048 / 8192 samples: eight of them per tile at
+        // 32 kHz, where the phase-resident stage 1 — all loads first — was 19 % faster for that reason alone)
         if constexpr (sizeof(XT) == 4) {
             const float *xf = reinterpret_cast<const float *>(x);
             if ((reinterpret_cast<uintptr_t>(xf) & 15u) == 0) {
-                for (uint32_t q = tid * 4; q < G.xt; q += kFusedThreads * 4) {
-                    const uint64_t i = xs0 + q;
-                    float4 v;
-                    if (i + 3 < n) {
-                        v = *reinterpret_cast<const float4 *>(xf + i);
-                    } else {
-                        v.x = i < n ? xf[i] : 0.f;
-                        v.y = i + 1 < n ? xf[i + 1] : 0.f;
-                        v.z = i + 2 < n ? xf[i + 2] : 0.f;
-                        v.w = i + 3 < n ? xf[i + 3] : 0.f;
+                constexpr uint32_t KB = 4;
+                for (uint32_t q0 = tid * 4; q0 < G.xt; q0 += KB * kFusedThreads * 4) {
+                    float4 v[KB];
+#pragma unroll
+                    for (uint32_t e = 0; e < KB; ++e) {
+                        const uint32_t q = q0 + e * kFusedThreads * 4;
+                        const uint64_t i = xs0 + q;
+                        v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (q < G.xt) {
+                            if (i + 3 < n) {
+                                v[e] = *reinterpret_cast<const float4 *>(xf + i);
+                            } else {
+                                v[e].x = i < n ? xf[i] : 0.f;
+                                v[e].y = i + 1 < n ? xf[i + 1] : 0.f;
+                                v[e].z = i + 2 < n ? xf[i + 2] : 0.f;
+                                v[e].w = i + 3 < n ? xf[i + 3] : 0.f;
+                            }
+                        }
                     }
-                    *reinterpret_cast<float4 *>(X + q) = v;
+#pragma unroll
+                    for (uint32_t e = 0; e < KB; ++e) {
+                        const uint32_t q = q0 + e * kFusedThreads * 4;
+                        if (q < G.xt) *reinterpret_cast<float4 *>(X + q) = v[e];
+                    }
                 }
             } else {
                 for (uint32_t q = tid; q < G.xt; q += kFusedThreads) X[q] = xs0 + q < n ? xf[xs0 + q] : 0.f;
             }
         } else {
             // mono PCM16 payload (wav.rs:37: `*x as f32`)
-            for (uint32_t q = tid; q < G.xt; q += kFusedThreads) X[q] = xs0 + q < n ? static_cast<float>(x[xs0 + q]) : 0.f;
+            constexpr uint32_t KB = 8;
+            for (uint32_t q0 = tid; q0 < G.xt; q0 += KB * kFusedThreads) {
+                float v[KB];
+#pragma unroll
+                for (uint32_t e = 0; e < KB; ++e) {
+                    const uint32_t q = q0 + e * kFusedThreads;
+                    v[e] = (q < G.xt && xs0 + q < n) ? static_cast<float>(x[xs0 + q]) : 0.f;
+                }
+#pragma unroll
+                for (uint32_t e = 0; e < KB; ++e) {
+                    const uint32_t q = q0 + e * kFusedThreads;
+                    if (q < G.xt) X[q] = v[e];
+                }
+            }
         }
         __syncthreads();
         if constexpr (APT_FUSED_STOP == 1) return;

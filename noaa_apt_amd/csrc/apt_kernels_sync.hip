@@ -190,7 +190,11 @@ __device__ __forceinline__ float nodes_eval_window(float *win, bool on, int lane
         }
         if (on) c = sync_corr_from_pulses([&](int k) { return win[lane + k * 2 * pw]; });
     } else {
-        if (on) c = sync_corr_strict(pw, [&](uint32_t j) { return win[lane + j]; });
+        if constexpr (PWC >= 4) {
+            if (on) c = sync_corr_strict_rolled(pw, [&](uint32_t j) { return win[lane + j]; });
+        } else {
+            if (on) c = sync_corr_strict(pw, [&](uint32_t j) { return win[lane + j]; });
+        }
     }
     return c;
 }

@@ -52,6 +52,34 @@ __device__ __forceinline__ float sync_corr_strict(uint32_t pw, At &&at)
     return c;
 }
 
+// the same chain with the seven (-, +) pulse pairs and the four tail pulses as loops that stay loops: with the pixel
+// width at compile time the form above unrolls to 38*pw additions whose LDS reads the compiler issues as early as its
+// register budget allows — 120 VGPRs and scratch in k_sync_words at pw = 4 / 5 (68 at pw = 3), four waves per SIMD
+// instead of seven for a latency-bound kernel.  Same additions in the same order: same bits.
+template <typename At>
+__device__ __forceinline__ float sync_corr_strict_rolled(uint32_t pw, At &&at)
+{
+#pragma clang fp contract(off)
+    const uint32_t pulse = 2 * pw;
+    float c = 0.f;
+    uint32_t j = 0;
+#pragma unroll
+    for (uint32_t e = 0; e < pulse; ++e, ++j) c = c - at(j);
+#pragma unroll 1
+    for (int rep = 0; rep < 7; ++rep) {
+#pragma unroll
+        for (uint32_t e = 0; e < pulse; ++e, ++j) c = c - at(j);
+#pragma unroll
+        for (uint32_t e = 0; e < pulse; ++e, ++j) c = c + at(j);
+    }
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (uint32_t e = 0; e < pulse; ++e, ++j) c = c - at(j);
+    }
+    return c;
+}
+
 // fast, step 1: pulse sum B[i]; at(j) returns F[i + j], j < 2*pw
 template <typename At>
 __device__ __forceinline__ float sync_pulse_sum(uint32_t pw, At &&at)

@@ -91,7 +91,7 @@ def test_fast_mode_tolerance(oracle, rate, seconds, kw):
     assert 0 < err <= PX_TOL  # it really is the reassociated arithmetic, and within tolerance
 
 
-@pytest.mark.parametrize("rate,seconds,profile,want_fused", [(48000, 14, "slow", 1), (48000, 14, "fast", 4), (96000, 12, "fast", 4)])
+@pytest.mark.parametrize("rate,seconds,profile,want_fused", [(48000, 14, "slow", 1), (48000, 14, "fast", 4), (16000, 30, "fast", 4)])
 def test_fast_mode_tolerance_on_the_other_profiles(oracle, rate, seconds, profile, want_fused):
     """APTGPU_MODE_FAST on the fast and slow settings profiles (round 4: their kernels have fast-mode instantiations)."""
     x = synth_apt(rate, seconds, seed=31)
