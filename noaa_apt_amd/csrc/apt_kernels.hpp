@@ -143,7 +143,6 @@ struct TableGeom {
     uint32_t off_x;            // LDS offset of the input tile in floats (the table sits at 0)
     uint32_t step_q, step_r;   // (NTHR*m) / l and % l: x0 / phase update between a thread's outputs
     uint32_t jl_a, jl_b;       // jlim / l and % l: taps of phase p = jl_a + (p < jl_b)
-    uint32_t perm_q;           // PHASE mode: thread t computes the outputs (t * perm_q) % step_r + j * step_r (1: t + j * step_r)
 };
 struct FusedParams {
     const float *hs;        // stage-1 table: tap pairs (fused_branch_taps), or the fp16 table

@@ -291,50 +291,6 @@ uint32_t phase_tpp(uint32_t l, uint32_t t1)
     const uint32_t jlim = 2 * ((t1 - 1) / 2) + 1;
     return ((jlim + l - 1) / l + 3u) & ~3u;
 }
-// Which of a stride's outputs the lanes of a wave take.  Thread t's window starts c(u) = ceil((rb + u*m) / l) entries
-// into its region of the paired tile (u = its output within the stride, rb = the tile's phase offset), and an 8-byte
-// LDS read is served 16 lanes at a time from 32 two-word slots: lanes whose starts are equal mod 32 collide.  With
-// u = t (consecutive lanes, consecutive outputs) the starts are m/l apart — 3.53 entries at 44 100 Hz, so lanes k and
-// k + 9 of every sixteen meet (31.8 entries apart): two-way conflicts on every read of stage 1, 41 % of its LDS
-// cycles (profiles/r04_sq_counters_phase.json).  With u = (t * q) mod stride for a suitable odd q the sixteen starts of
-// every group are distinct for every rb: found by search, 1 when nothing beats the identity.  (R goes back to LDS at
-// u + j*stride: lanes then q words apart, q odd — conflict-free as well.)
-uint32_t phase_lane_stride(uint32_t l, uint32_t m, uint32_t stride, uint32_t threads)
-{
-    const char *e = std::getenv("APTGPU_PHASE_PERM");  // A/B switch: 0 = identity
-    if (e && e[0] == '0') return 1;
-    auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
-    auto cost = [&](uint32_t q) -> uint64_t {
-        uint64_t tot = 0;
-        const uint32_t nrb = 16;
-        for (uint32_t r = 0; r < nrb; ++r) {
-            const uint32_t rb = static_cast<uint32_t>(static_cast<uint64_t>(r) * l / nrb);
-            for (uint32_t g0 = 0; g0 < threads; g0 += 16) {
-                uint32_t cnt[32] = {0};
-                uint32_t worst = 0;
-                for (uint32_t t = g0; t < g0 + 16 && t < stride; ++t) {
-                    const uint64_t u = (static_cast<uint64_t>(t) * q) % stride;
-                    const uint64_t c = (rb + u * m + l - 1) / l;
-                    worst = std::max(worst, ++cnt[c % 32]);
-                }
-                tot += worst;
-            }
-        }
-        return tot;
-    };
-    uint32_t best_q = 1;
-    uint64_t best = cost(1);
-    for (uint32_t q = 3; q < stride; q += 2) {
-        if (gcd(q, stride) != 1) continue;
-        const uint64_t c = cost(q);
-        if (c < best) {
-            best = c;
-            best_q = q;
-        }
-    }
-    return best_q;
-}
-
 // geometry for workgroups of `threads` (256: three per CU; 512: two per CU); the launcher recovers the thread
 // count from step_r (<= 256 <=> 256 threads: a stride above 256 needs l > 256, which phase_geom(256, ..) refuses)
 bool phase_geom(uint32_t threads, uint32_t l, uint32_t m, uint32_t t1, TableGeom *geom)
@@ -362,10 +318,6 @@ bool phase_geom(uint32_t threads, uint32_t l, uint32_t m, uint32_t t1, TableGeom
     if (g.xt > (threads == 256 ? 13600u : 20480u)) return false;
     g.jl_a = g.jlim / l;
     g.jl_b = g.jlim % l;
-    g.perm_q = phase_lane_stride(l, m, stride, threads);
-    if (std::getenv("APTGPU_DEBUG_GEOM"))
-        std::fprintf(stderr, "aptgpu: phase geometry l %u m %u threads %u stride %u step_q %u off_x %u xt %u perm_q %u\n", l, m, threads,
-                     stride, g.step_q, g.off_x, g.xt, g.perm_q);
     if (geom) *geom = g;
     return true;
 }

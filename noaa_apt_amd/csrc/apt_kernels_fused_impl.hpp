@@ -409,11 +409,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         const uint32_t xrel0 = static_cast<uint32_t>(X0 - xs0);       // -1 (wrapped) only when rb > 0, and then c >= 1
         // this thread's branch (the same for all its outputs: S*m is a multiple of l)
         const bool act = static_cast<uint32_t>(tid) < S;
-        // which output of the stride this thread takes: (tid * q) mod S — a permutation that makes the sixteen lanes of
-        // an LDS pass start their windows in sixteen different two-word slots (phase_lane_stride, apt_kernels_fused.hip)
-        const uint32_t pq = tp->tab.perm_q;
-        const uint32_t uo = (act && pq > 1) ? (static_cast<uint32_t>(tid) * pq) % S : static_cast<uint32_t>(tid);
-        const uint32_t v = rb + uo * gm_;
+        const uint32_t v = rb + static_cast<uint32_t>(tid) * gm_;
         const uint32_t c = (v + gl - 1) / gl;
         const uint32_t ph = c * gl - v;
         // The input tile in LDS, PAIRED: outputs 2jj and 2jj+1 of a thread read windows exactly dq samples
@@ -529,7 +525,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         if (act) {
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const int idx = static_cast<int>(uo) + j * static_cast<int>(S);
+                const int idx = tid + j * static_cast<int>(S);
                 const float val = (j & 1) ? acc[j / 2].y : acc[j / 2].x;
                 // (outputs before the recording or at / past its end: zero)
                 if (idx < Gm::TILE_K) P[idx] = (idx >= k_lo && idx < k_hi) ? val : 0.f;

@@ -257,7 +257,10 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         const char *phase_first = std::getenv("APTGPU_PHASE_FIRST");  // tests: phase-resident stage 1 wherever it exists
         if (eligible && gpu::fused_supported(plan->l, plan->m, t1, t2, plan->pw) && !no_spec)
             plan->fused = 1;
-        else if (eligible && !no_spec && phase_first && phase_first[0] == '1' &&
+        // (where both the table-driven and the phase-resident stage 1 exist: the latter when a work sample takes two or
+        // more input samples — 32 kHz: 1.28 against 1.57 ms per 16 recordings; the former below that — 8 / 12 / 16 kHz:
+        // 0.72 / 0.76 / 0.95 against 0.80 / 0.88 / 0.99; profiles/r04_sweeps.txt)
+        else if (eligible && !no_spec && ((phase_first && phase_first[0] == '1') || (!phase_first && plan->m >= 2 * plan->l)) &&
                  gpu::fused_phase_supported(plan->l, plan->m, t1, t2, plan->pw, &plan->table_geom))
             plan->fused = 4;
         else if (eligible && !no_spec && gpu::fused_table_supported(plan->l, plan->m, t1, t2, plan->pw, &plan->table_geom))

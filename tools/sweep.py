@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=600.0)
     ap.add_argument("--inputs", type=int, default=4)
     ap.add_argument("--pcm16", action="store_true")
+    ap.add_argument("--profile", default="standard", help="settings profile (default_settings.toml): standard, fast, slow")
     ap.add_argument("--no-sync", action="store_true", help="decode(sync=false): front end without stage 4, no picker")
     args = ap.parse_args()
 
@@ -59,7 +60,7 @@ def main():
         extra_env = dict(kv.split("=", 1) for kv in parts[3].split(";") if kv) if len(parts) > 3 else {}
         saved_env = {k_: os.environ.get(k_) for k_ in extra_env}
         os.environ.update(extra_env)
-        plan = apt.Plan(apt.Settings(), apt.Rate.hz(args.rate), not args.no_sync, max_samples=n, max_batch=B, mode=modes[mode_s])
+        plan = apt.Plan(apt.Settings.profile(args.profile), apt.Rate.hz(args.rate), not args.no_sync, max_samples=n, max_batch=B, mode=modes[mode_s])
         cap = int(plan.info.max_rows)
         # every call in flight needs its own output buffers
         outs = [[torch.empty(cap * 2080, dtype=torch.float32, device=dev) for _ in range(B)] for _ in range(S)]
