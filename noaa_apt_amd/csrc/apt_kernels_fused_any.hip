@@ -51,8 +51,8 @@ struct Candidate {
 // most resident waves per CU first (LDS permitting), then the larger tile
 constexpr Candidate kCandidates[] = {{256, 8}, {1024, 8}, {1024, 4}};
 
-bool make_geom(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, int nthr, int kpt, AnyGeom *out,
-               size_t *lds_bytes)
+bool make_geom(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, int nthr, int kpt, bool table_in_global,
+               AnyGeom *out, size_t *lds_bytes)
 {
     AnyGeom g{};
     g.l = l;
@@ -72,7 +72,11 @@ bool make_geom(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, in
     if (g.own == 0) return false;
     g.xt = (static_cast<uint32_t>((static_cast<uint64_t>(g.kt) * m + l - 1) / l) + per_phase + 8 + 3) & ~3u;
     const uint32_t slack = 64;
-    g.off_x = (l * g.tpp + 3u) & ~3u;
+    // (a table that does not fit LDS beside the tile — 44 100 Hz at the slow profile: 29 k taps, 116 KB — stays in
+    // HBM / L2 and stage 1 reads its rows from there: every thread 856 bytes per output, but fused: R, D and C still
+    // never leave the CU)
+    g.table_in_global = table_in_global ? 1u : 0u;
+    g.off_x = table_in_global ? 0u : ((l * g.tpp + 3u) & ~3u);
     const uint32_t ab_len = ((g.kt + slack) + (g.kt + slack) / static_cast<uint32_t>(kpt) + 8u) & ~3u;  // padded
     g.off_a = g.off_x + g.xt;
     g.off_b = g.off_a + ab_len;
@@ -91,8 +95,8 @@ bool make_geom(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, in
 }
 
 // picks the launch shape: maximise resident waves per CU, then tile size
-bool choose(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, Candidate *best, AnyGeom *geom,
-            size_t *lds)
+bool choose_with(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, bool in_global, Candidate *best, AnyGeom *geom,
+                 size_t *lds)
 {
     int best_score = 0;
     uint32_t best_kt = 0;
@@ -100,7 +104,7 @@ bool choose(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, Candi
     for (const Candidate &c : kCandidates) {
         AnyGeom g;
         size_t bytes;
-        if (!make_geom(l, m, t1, t2, pw, c.nthr, c.kpt, &g, &bytes)) continue;
+        if (!make_geom(l, m, t1, t2, pw, c.nthr, c.kpt, in_global, &g, &bytes)) continue;
         int wgs = static_cast<int>(kLdsLimit / bytes);
         int waves = wgs * (c.nthr / 64);
         if (waves > 32) waves = 32;  // 8 per SIMD is plenty
@@ -118,6 +122,11 @@ bool choose(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, Candi
     return found;
 }
 
+// the table in LDS where a launch shape exists for that; else in HBM / L2
+bool choose(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, Candidate *best, AnyGeom *geom, size_t *lds)
+{
+    return choose_with(l, m, t1, t2, pw, false, best, geom, lds) || choose_with(l, m, t1, t2, pw, true, best, geom, lds);
+}
 
 }  // namespace
 

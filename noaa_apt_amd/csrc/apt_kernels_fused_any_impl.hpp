@@ -90,7 +90,7 @@ k_fused_any(const CallArgs call, const SlotPtrs *__restrict__ slots, const float
     const uint32_t xrel0 = static_cast<uint32_t>(X0 - xs0);  // may wrap by -1..: used only with ceil >= 1 or rb == 0
 
     // ---- stage 0
-    {
+    if (!G.table_in_global) {
         // the table is 16-byte aligned in HBM and in LDS: 16-byte copies, several in flight
         const uint32_t nt = G.l * G.tpp, nt4 = nt / 4;
         const float4 *t4 = reinterpret_cast<const float4 *>(table);
@@ -151,7 +151,7 @@ k_fused_any(const CallArgs call, const SlotPtrs *__restrict__ slots, const float
                 }
                 if (k < static_cast<int64_t>(w)) {
                     const uint32_t cnt = G.jl_a + (p < G.jl_b ? 1u : 0u);
-                    const float *row = T + p * G.tpp;
+                    const float *row = (G.table_in_global ? table : T) + static_cast<size_t>(p) * G.tpp;
                     const float *xs = X + (xrel0 + c);
                     // batches of 8 taps: sixteen LDS reads in flight, then the eight MACs in tap order
                     uint32_t j = 0;

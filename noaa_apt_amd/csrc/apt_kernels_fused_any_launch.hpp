@@ -16,6 +16,7 @@ struct AnyGeom {
     uint32_t off_x, off_a, off_b;  // LDS offsets in floats (table at 0)
     uint32_t step_q, step_r;       // (NTHR*m) / l and % l: x0 / phase update between a thread's outputs
     uint32_t jl_a, jl_b;           // jlim / l and % l: taps of phase p = jl_a + (p < jl_b)
+    uint32_t table_in_global;      // the polyphase table does not fit LDS beside the tile: stage 1 reads its rows from HBM / L2
     uint64_t sign[4];              // bit j set <=> sync template[j] = +1 (decode.rs:188-198)
 };
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/install_profiles.sh [round]: copy the summaries tools/collect_profiles.sh left under gpurun_out/prof/ into
 # profiles/ under this round's names (what bench.py and the docs cite).
-R=${1:-r03}
+R=${1:-r04}
 P=gpurun_out/prof
 cd "$(dirname "$0")/.." || exit 1
 for MODE in strict fast; do
@@ -11,6 +11,13 @@ for MODE in strict fast; do
   [ -f $P/stats_${MODE}_streams1.kernel_stats.csv ] && cp $P/stats_${MODE}_streams1.kernel_stats.csv profiles/${R}_kernel_stats_${MODE}_streams1.csv
   [ -f $P/stats_${MODE}_bench.json ] && cp $P/stats_${MODE}_bench.json profiles/${R}_bench_${MODE}_under_rocprof.json
   [ -f $P/stats_${MODE}_streams1_bench.json ] && cp $P/stats_${MODE}_streams1_bench.json profiles/${R}_bench_${MODE}_streams1_under_rocprof.json
+done
+for f in $P/sq_*.json; do
+  [ -f "$f" ] && cp "$f" profiles/${R}_sq_counters_$(basename "$f" | sed -e 's/^sq_//')
+done
+for f in $P/hbm_*.json; do
+  case "$f" in *hbm_traffic_*) continue;; esac
+  [ -f "$f" ] && cp "$f" profiles/${R}_hbm_$(basename "$f" | sed -e 's/^hbm_//')
 done
 for f in $P/bench_*.json; do
   [ -f "$f" ] && cp "$f" profiles/${R}_$(basename "$f")
