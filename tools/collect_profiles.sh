@@ -56,18 +56,16 @@ done
 (cd $R && python bench.py --no-extras --mode fp16taps > $O/bench_fp16taps.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --batch 1 > $O/bench_strict_batch1.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --config4 > $O/bench_config4.json 2>> $O/bench_strict.err)
-(cd $R && python bench.py --no-extras --batch 8 > $O/bench_strict_batch8.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --rate 44100 > $O/bench_44100.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --rate 11025 > $O/bench_11025.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --rate 22050 > $O/bench_22050.json 2>> $O/bench_strict.err)
-(cd $R && python bench.py --no-extras --rate 32000 > $O/bench_32000.json 2>> $O/bench_strict.err)
 # the reference's other two stock profiles (default_settings.toml:120-140)
 (cd $R && python bench.py --no-extras --profile fast > $O/bench_profile_fast.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --profile slow > $O/bench_profile_slow.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --profile fast --mode fast > $O/bench_profile_fast_fastmode.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --profile slow --mode fast > $O/bench_profile_slow_fastmode.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --profile fast --rate 11025 > $O/bench_profile_fast_11025.json 2>> $O/bench_strict.err)
-(cd $R && python bench.py --no-extras --profile fast --rate 96000 > $O/bench_profile_fast_96000.json 2>> $O/bench_strict.err)
+(cd $R && python bench.py --no-extras --profile slow --rate 44100 --steps 60 > $O/bench_profile_slow_44100.json 2>> $O/bench_strict.err)
 (cd $R && python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras > $O/bench_torchrun_n1.json 2> $O/bench_torchrun.err)
 fi
 ls $O
