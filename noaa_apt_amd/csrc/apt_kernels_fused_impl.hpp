@@ -1147,12 +1147,24 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             float fl = 0.f;
 #pragma unroll
             for (int pp = 0; pp < Gm::NP; ++pp) fa[pp] = (f2){0.f, 0.f};
-            constexpr int CH3 = 7;
+            constexpr int CH3 = 8;
             static_for<0, (Gm::DW + CH3 - 1) / CH3>([&](auto cc) {
                 constexpr int hi = Gm::DW - 1 - decltype(cc)::value * CH3;  // walk qq downwards
                 float dv[CH3];
 #pragma unroll
                 for (int e = 0; e < CH3; ++e) dv[e] = (hi - e >= 0) ? lds[qofs + hi - e] : 0.f;
+                // The odd output (L - 1) has no partner: its products two samples at a time — one packed multiply of the
+                // tap pair (h2[ml], h2[ml + 1]) with the sample pair (d[qq], d[qq - 1]) — and the additions one after the
+                // other in tap order (strict modes; -18 instructions per thread at T2 = 37).
+                [[maybe_unused]] f2 plp[(CH3 + 1) / 2];
+                if constexpr ((L & 1) && !FAST) {
+                    static_for<0, CH3 / 2>([&](auto kk) {
+                        constexpr int k = decltype(kk)::value;
+                        constexpr int qa = hi - 2 * k, qb = qa - 1;
+                        constexpr int ma = (T2 - 1) + (L - 1) - qa;  // tap of sample qa; sample qb: ma + 1
+                        if constexpr (qb >= 0 && ma >= 0 && ma + 1 < T2) plp[k] = h2p[ma + 1] * (f2){dv[2 * k], dv[2 * k + 1]};
+                    });
+                }
                 static_for<0, CH3>([&](auto ee) {
                     constexpr int qq = hi - decltype(ee)::value;
                     if constexpr (qq >= 0) {
@@ -1186,7 +1198,12 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                         if constexpr (L & 1) {
                             constexpr int ml = (T2 - 1) + (L - 1) - qq;
                             if constexpr (ml >= 0 && ml < T2) {
+                                // (is this sample half of a packed pair?  its partner is the other sample of (2k, 2k + 1))
+                                constexpr int e_ = decltype(ee)::value, k_ = e_ / 2;
+                                constexpr int qa_ = hi - 2 * k_, ma_ = (T2 - 1) + (L - 1) - qa_;
+                                constexpr bool paired = k_ < CH3 / 2 && qa_ - 1 >= 0 && ma_ >= 0 && ma_ + 1 < T2;
                                 if constexpr (FAST) fl = __builtin_fmaf(h2[ml], d, fl);
+                                else if constexpr (paired) pl = (e_ & 1) ? plp[k_].y : plp[k_].x;
                                 else pl = h2[ml] * d;
                             }
                         }
