@@ -300,7 +300,7 @@ k_sync_words(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
     constexpr int kBatch = NL > 0 ? 4 : 1;
     constexpr int NLR = NL > 0 ? NL : 1;
     constexpr uint16_t kDeferred = 0x8000u;  // s_cand entry: to be settled in the second pass
-    float *wa = s_win + static_cast<size_t>(wave) * 2u * wlen;  // this wave's F window (room for two, interleaved: see below)
+    float *wa = s_win + static_cast<size_t>(wave) * wlen;  // this wave's F window
     const uint32_t wneed = GS + 38u * pw - 1u;  // samples of a window
     // F window of the group at `base` -> wa -> its correlation values
     auto eval_group = [&](uint64_t base, bool on) -> float {
@@ -439,35 +439,10 @@ k_sync_words(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t p
                 }
             }
         }
-        // Strict plans with the pixel width at compile time: the chains of the batch's candidates TWO AT A TIME — the two
-        // F windows interleaved in LDS, (F_a[j], F_b[j]) an 8-byte read, every template term one packed addition for
-        // both (sync_corr_strict2: each component accumulates exactly as the single chain does).  The chain is half of
-        // what a candidate costs this kernel, and what the kernel costs a pipelined step is its VALU instructions.
-        bool have_cv = false;
-        if constexpr (NL > 0 && PWC > 0) {
-            if (corr == nullptr && !fast) {
-                typedef float f2w __attribute__((ext_vector_type(2)));
-                f2w *wa2 = reinterpret_cast<f2w *>(wa);
-#pragma unroll
-                for (int e = 0; e < kBatch; e += 2) {
-                    if (qv[e] < 0) break;  // wave-uniform (candidates fill a batch from the front)
-#pragma unroll
-                    for (int t = 0; t < NL; ++t)
-                        if (lane + 64u * t < wlen) wa2[lane + 64 * t] = (f2w){fa[e][t], fa[e + 1][t]};
-                    __builtin_amdgcn_wave_barrier();
-                    f2w c2 = {kNegInf, kNegInf};
-                    if (inv[e] || inv[e + 1]) c2 = sync_corr_strict2<(PWC >= 4)>(pw, [&](uint32_t j) { return wa2[lane + j]; });
-                    __builtin_amdgcn_wave_barrier();  // the windows are dead from here on: wa is reused
-                    cv[e] = inv[e] ? c2.x : kNegInf;
-                    cv[e + 1] = inv[e + 1] ? c2.y : kNegInf;
-                }
-                have_cv = true;
-            }
-        }
 #pragma unroll
         for (int e = 0; e < kBatch; ++e) {
             if (qv[e] < 0) continue;  // wave-uniform
-            if (corr == nullptr && !have_cv) {
+            if (corr == nullptr) {
                 // F window of the candidate group -> LDS -> its 52 correlation values
                 if constexpr (NL > 0) {
 #pragma unroll
@@ -1011,8 +986,7 @@ void sync_nodes(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, ui
     const uint32_t ng = static_cast<uint32_t>((n_corr + GS - 1) / GS);
     const uint32_t chunks = (ng + kChunkGroups - 1) / kChunkGroups;
     const uint32_t r = md / GS;
-    // (two interleaved F windows per wave: the strict chains are evaluated two candidates at a time)
-    const size_t lds = words_win_ofs(r) + static_cast<size_t>(kNodesWaves) * 2u * nodes_window(pw) * sizeof(float);
+    const size_t lds = words_win_ofs(r) + static_cast<size_t>(kNodesWaves) * nodes_window(pw) * sizeof(float);
     const dim3 grid(chunks, call.count);
     const uint32_t wneed = GS + 38u * pw - 1u;
     const char *e_dpp = std::getenv("APTGPU_WORDS_DPP");  // A/B switch (read per launch: tools/sweep.py flips it between plans)

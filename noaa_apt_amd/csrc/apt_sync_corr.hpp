@@ -80,47 +80,6 @@ __device__ __forceinline__ float sync_corr_strict_rolled(uint32_t pw, At &&at)
     return c;
 }
 
-// The strict chain of TWO positions at once (k_sync_words: the same position of two candidate groups): at2(j) returns
-// (F_a[i + j], F_b[i + j]); every component accumulates exactly as sync_corr_strict does — packed additions with
-// negation modifiers, one instruction per template term for the two of them.  `rolled`: the pulse pairs as loops
-// (sync_corr_strict_rolled).
-typedef float sync_pair __attribute__((ext_vector_type(2)));
-template <bool ROLLED, typename At2>
-__device__ __forceinline__ sync_pair sync_corr_strict2(uint32_t pw, At2 &&at2)
-{
-#pragma clang fp contract(off)
-    const uint32_t pulse = 2 * pw;
-    sync_pair c = {0.f, 0.f};
-    uint32_t j = 0;
-#pragma unroll
-    for (uint32_t e = 0; e < pulse; ++e, ++j) c = c - at2(j);
-    if constexpr (ROLLED) {
-#pragma unroll 1
-        for (int rep = 0; rep < 7; ++rep) {
-#pragma unroll
-            for (uint32_t e = 0; e < pulse; ++e, ++j) c = c - at2(j);
-#pragma unroll
-            for (uint32_t e = 0; e < pulse; ++e, ++j) c = c + at2(j);
-        }
-#pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (uint32_t e = 0; e < pulse; ++e, ++j) c = c - at2(j);
-        }
-    } else {
-#pragma unroll
-        for (int rep = 0; rep < 7; ++rep) {
-#pragma unroll
-            for (uint32_t e = 0; e < pulse; ++e, ++j) c = c - at2(j);
-#pragma unroll
-            for (uint32_t e = 0; e < pulse; ++e, ++j) c = c + at2(j);
-        }
-#pragma unroll
-        for (uint32_t e = 0; e < 8 * pw; ++e, ++j) c = c - at2(j);
-    }
-    return c;
-}
-
 // fast, step 1: pulse sum B[i]; at(j) returns F[i + j], j < 2*pw
 template <typename At>
 __device__ __forceinline__ float sync_pulse_sum(uint32_t pw, At &&at)
