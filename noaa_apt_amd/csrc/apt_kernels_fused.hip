@@ -293,7 +293,7 @@ uint32_t phase_tpp(uint32_t l, uint32_t t1)
 }
 // geometry for workgroups of `threads` (256: three per CU; 512: two per CU); the launcher recovers the thread
 // count from step_r (<= 256 <=> 256 threads: a stride above 256 needs l > 256, which phase_geom(256, ..) refuses)
-bool phase_geom(uint32_t threads, uint32_t l, uint32_t m, uint32_t t1, TableGeom *geom)
+bool phase_geom(uint32_t threads, uint32_t l, uint32_t m, uint32_t t1, TableGeom *geom, uint32_t tap_regs = 0)
 {
     const uint32_t tile = threads * 13;
     if (l > threads) return false;
@@ -303,7 +303,7 @@ bool phase_geom(uint32_t threads, uint32_t l, uint32_t m, uint32_t t1, TableGeom
     g.m = m;
     g.jlim = 2 * ((t1 - 1) / 2) + 1;
     const uint32_t per_phase = (g.jlim + l - 1) / l;
-    if (per_phase > (threads == 256 ? 76u : 40u)) return false;  // taps a thread's registers hold (TPPM in k_fused)
+    if (per_phase > (tap_regs ? tap_regs : (threads == 256 ? 76u : 40u))) return false;  // taps a thread's registers hold (TPPM in k_fused)
     g.tpp = phase_tpp(l, t1);
     const uint32_t stride = l * (threads / l);  // outputs between a thread's consecutive outputs
     if ((tile + stride - 1) / stride > kPhaseOutputs) return false;
@@ -327,7 +327,7 @@ bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uin
 {
     if (l < 2 || m == 0 || t1 == 0) return false;
     // work-rate stages: the standard profile's (256- and 512-thread workgroups), the fast profile's (256)
-    if (t2 == 43 && pw == 4) return phase_geom(256, l, m, t1, geom);
+    if (t2 == 43 && pw == 4) return phase_geom(256, l, m, t1, geom, 28);  // (the fast profile's instantiations hold 28 taps per branch)
     if (t2 != 37 || pw != 3) return false;
     return phase_geom(256, l, m, t1, geom) || phase_geom(512, l, m, t1, geom);
 }

@@ -71,6 +71,7 @@ bool make_geom(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, in
     g.own = (g.kt - g.pre - (g.g - 1)) / kGS * kGS;
     if (g.own == 0) return false;
     g.xt = (static_cast<uint32_t>((static_cast<uint64_t>(g.kt) * m + l - 1) / l) + per_phase + 8 + 3) & ~3u;
+    if (g.xt < static_cast<uint32_t>(nthr)) g.xt = static_cast<uint32_t>(nthr);  // (stage 4 keeps one float per thread there)
     const uint32_t slack = 64;
     // (a table that does not fit LDS beside the tile — 44 100 Hz at the slow profile: 29 k taps, 116 KB — stays in
     // HBM / L2 and stage 1 reads its rows from there: every thread 856 bytes per output, but fused: R, D and C still

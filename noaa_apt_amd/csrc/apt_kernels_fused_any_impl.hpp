@@ -5,6 +5,7 @@
 
 #include "apt_kernels_fused_any_launch.hpp"
 #include "apt_envelope.hpp"
+#include "apt_sync_corr.hpp"
 
 #include <atomic>
 #include <type_traits>
@@ -60,7 +61,7 @@ template <int NTHR, int KPT, typename XT, int T2C, int PWC>
 __global__ void __launch_bounds__(NTHR)
 k_fused_any(const CallArgs call, const SlotPtrs *__restrict__ slots, const float *__restrict__ table /*[l][tpp]*/,
             const float *__restrict__ h2, const f2 *__restrict__ h2p /*[t2+1] (h2[k-1], h2[k])*/,
-            float cosphi2, float sinphi, float inv_sinphi, int want_gm, AnyGeom G)
+            float cosphi2, float sinphi, float inv_sinphi, int want_gm, float gm_slack, AnyGeom G)
 {
     const RecArgs rec = call.rec[blockIdx.y];
     const uint64_t w = rec.w;
@@ -296,112 +297,94 @@ k_fused_any(const CallArgs call, const SlotPtrs *__restrict__ slots, const float
     }
     if (gm_out == nullptr) return;  // no sync search wanted
 
-    // ---- stage 4: +-1 correlation, KPT consecutive outputs per thread
-    if constexpr (PWC > 0) {
-        // sample F[b0 + e] meets output u at template index j = e - u: the pair (u, u+1) adds it
-        // with the signs of T[j] and T[j-1] (neg modifiers); e ascending = j ascending
-        const int b0 = static_cast<int>(G.pre) + tid * KPT;
-        if (b0 < static_cast<int>(G.pre + G.own)) {
-            constexpr int NP = KPT / 2;
-            constexpr int GL = 38 * PWC;
-            constexpr int FW = KPT + GL - 1;
-            constexpr int CH = 8;
-            f2 ca[NP];
-#pragma unroll
-            for (int pp = 0; pp < NP; ++pp) ca[pp] = (f2){0.f, 0.f};
-            const float *src = A + P(b0);
-            static_for<0, (FW + CH - 1) / CH>([&](auto cc) {
-                constexpr int q0 = decltype(cc)::value * CH;
-                float fv[CH];
-                static_for<0, CH>([&](auto qq) {
-                    constexpr int q = decltype(qq)::value;
-                    if constexpr (q0 + q < FW) fv[q] = src[pad_ofs<KPT>(q0 + q)];
-                    else fv[q] = 0.f;
-                });
-                static_for<0, CH>([&](auto ee) {
-                    constexpr int e = q0 + decltype(ee)::value;
-                    if constexpr (e < FW) {
-                        const float v = fv[decltype(ee)::value];
-                        static_for<0, NP>([&](auto pc) {
-                            constexpr int pp = decltype(pc)::value;
-                            constexpr int jx = e - 2 * pp, jy = e - 2 * pp - 1;
-                            constexpr bool va = jx >= 0 && jx < GL;
-                            constexpr bool vb = jy >= 0 && jy < GL;
-                            if constexpr (va && vb) {
-                                ca[pp] = ca[pp] + (f2){sync_plus<PWC>(jx) ? v : -v, sync_plus<PWC>(jy) ? v : -v};
-                            } else if constexpr (va) {
-                                ca[pp].x = sync_plus<PWC>(jx) ? ca[pp].x + v : ca[pp].x - v;
-                            } else if constexpr (vb) {
-                                ca[pp].y = sync_plus<PWC>(jy) ? ca[pp].y + v : ca[pp].y - v;
-                            }
-                        });
-                    }
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-#pragma unroll
-            for (int pp = 0; pp < NP; ++pp) {
-                B[P(b0) + 2 * pp] = ca[pp].x;
-                B[P(b0) + 2 * pp + 1] = ca[pp].y;
-            }
-        }
-    } else
+    // ---- stage 4: bounds of the sync correlation's maximum per group of 52 positions (decode.rs:225-233).
+    // Until round 4 this kernel evaluated the reference's whole chain at every position (38 pw additions: 114 / 152 /
+    // 190) and handed the picker exact maxima.  Like the specialised kernels (apt_kernels_fused_impl.hpp, stage 4) it
+    // now evaluates the correlation from pulse sums — sync_pulse_sum, sync_corr_from_pulses: 2 pw + 21 additions per
+    // position whatever the pixel width — and widens the group's maximum by the rigorous rounding bound
+    // |pulse-sum value - sequential chain| <= gm_slack * sum|F| over the group's window: k_sync_words prunes with lo
+    // against hi and settles whatever the bounds leave open with the exact chain, so the picker's result does not
+    // depend on them (tests/test_gpu_bounds.py).  A window that holds a non-finite F gets [-inf, +inf].
+    const uint32_t pw = PWC > 0 ? static_cast<uint32_t>(PWC) : G.pulse / 2u;
+    const uint32_t pulse = 2u * pw;
+    float *AB = X;  // [NTHR] per-thread sums of |F| over the thread's KPT samples (the input tile is dead; xt >= NTHR)
     {
+        // 4a: pulse sums of the thread's KPT positions -> B (D is dead), |F| partial sums -> AB
+        const int b0 = static_cast<int>(G.pre) + tid * KPT;
+        if (b0 < static_cast<int>(G.pre + G.own + 36u * pw)) {
+            float bs[KPT];
+            if constexpr (PWC > 0) {
+                constexpr int NW = KPT + 2 * PWC - 1;
+                float wv[NW];
+                const float *src = A + P(b0);  // b0 is a multiple of KPT: element e sits at pad(e)
+#pragma unroll
+                for (int e = 0; e < NW; ++e) wv[e] = src[pad_ofs<KPT>(e)];
+#pragma unroll
+                for (int u = 0; u < KPT; ++u) bs[u] = sync_pulse_sum(pw, [&](uint32_t jj) { return wv[u + static_cast<int>(jj)]; });
+            } else {
+#pragma unroll
+                for (int u = 0; u < KPT; ++u)
+                    bs[u] = sync_pulse_sum(pw, [&](uint32_t jj) { return A[P(b0 + u + static_cast<int>(jj))]; });
+            }
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) B[P(b0) + u] = bs[u];
+        }
+        {
+            float a = 0.f;
+            const int s0 = static_cast<int>(G.pre) + tid * KPT;  // this thread's KPT samples of F (zero past the signal's end)
+            if (s0 < static_cast<int>(G.kt)) {
+#pragma unroll
+                for (int u = 0; u < KPT; ++u) a = a + __builtin_fabsf(A[P(s0) + u]);
+            }
+            AB[tid] = a;
+        }
+    }
+    __syncthreads();
+    {
+        // 4b: the correlation of the thread's owned positions from the pulse sums -> A (F is dead: it went to HBM above)
         const int b0 = static_cast<int>(G.pre) + tid * KPT;
         if (b0 < static_cast<int>(G.pre + G.own)) {
-            float acc[KPT];
+            float cvals[KPT];
 #pragma unroll
-            for (int u = 0; u < KPT; ++u) acc[u] = 0.f;
-            for (uint32_t j0 = 0; j0 < G.g; j0 += KPT) {
-                float win[2 * KPT];
-                const float *src = A + P(b0 + static_cast<int>(j0));
-#pragma unroll
-                for (int e = 0; e < 2 * KPT; ++e) win[e] = src[e + e / KPT];
-                const uint64_t signs = G.sign[j0 >> 6] >> (j0 & 63);  // KPT divides 64: no straddling
-#pragma unroll
-                for (int jj = 0; jj < KPT; ++jj) {
-                    const uint32_t j = j0 + jj;
-                    if (j < G.g) {
-                        const bool plus = (signs >> jj) & 1;  // wave-uniform
-                        if (plus) {
-#pragma unroll
-                            for (int u = 0; u < KPT; ++u) acc[u] = acc[u] + win[u + jj];
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < KPT; ++u) acc[u] = acc[u] - win[u + jj];
-                        }
-                    }
+            for (int u = 0; u < KPT; ++u) {
+                if constexpr (PWC > 0) {
+                    const float *src = B + P(b0);
+                    cvals[u] = sync_corr_from_pulses([&](int k) { return src[pad_ofs<KPT>(u + k * 2 * PWC)]; });
+                } else {
+                    cvals[u] = sync_corr_from_pulses([&](int k) { return B[P(b0 + u + k * static_cast<int>(pulse))]; });
                 }
             }
+            // (region A was last read in 4a, before the barrier above)
 #pragma unroll
-            for (int u = 0; u < KPT; ++u) B[P(b0) + u] = acc[u];
+            for (int u = 0; u < KPT; ++u) A[P(b0) + u] = cvals[u];
         }
     }
     __syncthreads();
 
-    // ---- stage 5b: group maxima (the correlation itself stays on the CU: k_sync_words evaluates
-    // it for the candidate groups).  NaNs are left out of the maximum and reported as [-inf, +inf] bounds.
+    // ---- stage 5b: the groups' records.  NaNs are left out of the maximum (they show in the sum of |F|).
     for (uint32_t g = tid; g < G.own / kGS; g += NTHR) {
         const uint64_t k = static_cast<uint64_t>(o0) + static_cast<uint64_t>(g) * kGS;
         if (k >= n_corr) break;
         const int base = static_cast<int>(G.pre + g * kGS);
         float cv[kGS];
 #pragma unroll
-        for (int o = 0; o < kGS; ++o) cv[o] = B[P(base + o)];  // all 52 reads in flight
+        for (int o = 0; o < kGS; ++o) cv[o] = A[P(base + o)];  // all 52 reads in flight
         float mx = kNegInfAny;
-        bool has_nan = false;
 #pragma unroll
         for (int o = 0; o < kGS; ++o) {
             float v = cv[o];
             if (k + o == 0 && !(v > 0.f)) v = 0.f;  // the picker starts from the peak (0, 0.)
-            if (k + o < n_corr) {
-                mx = fmaxf(mx, v);
-                has_nan = has_nan || (v != v);
-            }
+            if (k + o < n_corr) mx = fmaxf(mx, v);
         }
-        // exact values: lo = hi; a group with a NaN position must reach the picker's exact test
+        // |F| over the group's window [base, base + 52 + 38 pw - 1): the threads whose KPT samples touch it
+        const int t_lo = static_cast<int>(g * kGS) / KPT;
+        const int t_hi = (static_cast<int>(g * kGS) + kGS + static_cast<int>(G.g) - 2) / KPT;
+        float asum = 0.f;
+        for (int t = t_lo; t <= t_hi && t < NTHR; ++t) asum = asum + AB[t];
+        const float err = asum * gm_slack;
+        const bool open = !(err < __builtin_huge_valf());  // NaN or Inf somewhere in the window
         gm_out[static_cast<uint64_t>(o0) / kGS + g] =
-            has_nan ? GroupMax{__builtin_huge_valf(), -__builtin_huge_valf()} : GroupMax{mx, mx};
+            open ? GroupMax{__builtin_huge_valf(), -__builtin_huge_valf()} : GroupMax{mx + err, mx - err};
     }
 }
 
@@ -410,6 +393,7 @@ void launch_any(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, ui
                 const float *h2, const float *h2p, float cosphi2, float sinphi, float inv_sinphi, bool want_gm,
                 const AnyGeom &g, size_t lds)
 {
+    const float gm_slack = fused_gm_slack(g.pulse / 2u);
     auto kern = k_fused_any<NTHR, KPT, XT, T2C, PWC>;
     // (a per-device property of the function: plans on several devices / threads pass through here)
     constexpr int kMaxDevices = 64;
@@ -424,7 +408,7 @@ void launch_any(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, ui
     }
     const unsigned tiles = static_cast<unsigned>((max_w + g.own - 1) / g.own);
     hipLaunchKernelGGL(kern, dim3(tiles, call.count), dim3(NTHR), lds, s, call, d_slots, table, h2,
-                       reinterpret_cast<const f2 *>(h2p), cosphi2, sinphi, inv_sinphi, want_gm ? 1 : 0, g);
+                       reinterpret_cast<const f2 *>(h2p), cosphi2, sinphi, inv_sinphi, want_gm ? 1 : 0, gm_slack, g);
 }
 
 

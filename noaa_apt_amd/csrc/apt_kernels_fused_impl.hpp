@@ -239,7 +239,7 @@ __host__ __device__ constexpr bool sync_plus(int j)
 // that walked the tiles with a fixed grid and kept the NEXT tile's input in registers while the stages ran was measured
 // in rounds 2 and 3 and dropped: slower in every mode)
 template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
-__global__ void __launch_bounds__(NTHR, M == -1 ? ((NTHR > 256 ? 2 : 3) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs) or two 512-thread (<= 128) workgroups per CU */
+__global__ void __launch_bounds__(NTHR, M == -1 ? ((NTHR > 256 ? 2 : (T2 == 43 ? 4 : 3)) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs; the fast profile's: four, <= 128) or two 512-thread (<= 128) workgroups per CU */
                                      : M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
                                                /* specialised: as many workgroups as the CU's 160 KB of LDS hold (48 kHz SPLIT: 5, 96 kHz: 3) */
                                                : (FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), MODE == kModeF16Taps>::WGS_PER_CU * NTHR + 255) / 256)
@@ -389,7 +389,10 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         // ---- stages 0 + 1, taps of the thread's polyphase branch in registers (dsp.rs:252-263):
         // k*m - X0*l = v;  x0 - X0 = c = ceil(v / l);  phase p = c*l - v;  output k = sum_i h[p + i*l] * x[x0 + i]
         constexpr int NB = 16;     // outputs per thread (>= ceil(TILE_K / S): checked by fused_phase_supported)
-        constexpr int TPPM = NTHR > 256 ? 40 : 76;  // taps per branch the registers hold (>= tpp; 128 / 170 VGPRs)
+        // taps per branch the registers hold (>= tpp; 128 / 170 VGPRs).  The fast profile's filters are short (639 taps at
+        // 48 kHz: 25 per branch at every rate — its transition band is three times the standard profile's): 28 registers,
+        // so that its kernels fit four workgroups per CU
+        constexpr int TPPM = NTHR > 256 ? 40 : (T2 == 43 ? 28 : 76);
         typedef const FusedParams APT_CONST_AS *cprm_tab_ptr;
         const cprm_tab_ptr tp = (cprm_tab_ptr)(prm);
         const uint32_t gl = tp->tab.l, gm_ = tp->tab.m, tpp = tp->tab.tpp;
