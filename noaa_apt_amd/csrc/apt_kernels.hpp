@@ -36,9 +36,9 @@ struct ImageResult {
 // Per-group record the front ends hand to the picker: an interval [lo, hi] that holds the maximum of
 // the sync correlation over the group's positions, NaNs ignored (position 0 clamped to >= 0: the picker
 // starts from the peak (0, 0.), decode.rs:208).  lo == hi where the front end evaluated the very
-// arithmetic the picker re-evaluates (fast mode, the unfused kernels, k_fused_any); the strict
-// specialised front ends bound the reference's 114-term chain from pulse sums (apt_kernels_fused_impl.hpp,
-// stage 4).  k_sync_words prunes a group only when a later group's lo exceeds its hi, and settles every
+// arithmetic the picker re-evaluates (fast mode, the unfused kernels); the strict front ends — the
+// specialised kernels and, since round 4, k_fused_any — bound the reference's 38 pw-term chain from pulse
+// sums (apt_kernels_fused_impl.hpp stage 4, apt_kernels_fused_any_impl.hpp stage 4).  k_sync_words prunes a group only when a later group's lo exceeds its hi, and settles every
 // comparison the bounds leave open with the exact chain: the intervals only decide how much is
 // re-evaluated, never the result.
 // [-inf, +inf] marks a group that must reach the exact test whatever its neighbours hold: one with a NaN

@@ -19,8 +19,10 @@
 //   stage 2  D[k] = envelope(R[k-1], R[k])                (dsp.rs:369-377)
 //   stage 3  F[k] = sum_{j<T2} D[k-j] * h[j]              (dsp.rs:396-404), KPT consecutive
 //            outputs per thread: a sliding register window cuts LDS reads per tap to 1/KPT
-//   stage 4  C[k] = sum_{j<G} +-F[k+j]                    (decode.rs:225-233), same blocking
-//   stage 5  owned F and C -> HBM (coalesced), GM[g] = max of C over 52 positions
+//   stage 4  bounds of max C over groups of 52 positions, C[k] = sum_{j<G} +-F[k+j] (decode.rs:225-233): the
+//            correlation from pulse sums (apt_sync_corr.hpp) widened by the rounding bound slack * sum|F|; the
+//            picker evaluates the exact chain where it matters (apt_kernels_sync.hip)
+//   stage 5  owned F -> HBM (coalesced), GM[g] = [lo, hi]
 //
 // LDS layout of A and B: logical index i lives at i + i/KPT (one pad word after every KPT), so a
 // thread's block of KPT consecutive outputs starts at an ODD multiple-of-words stride from its

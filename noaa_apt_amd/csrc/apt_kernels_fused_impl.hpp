@@ -234,8 +234,8 @@ __host__ __device__ constexpr bool sync_plus(int j)
 // One workgroup per tile: blockIdx.y picks the recording, whose tiles are blockIdx.x < ceil(w / OWN_K).
 // The tile's input goes through registers (all loads issued before the first LDS write).  The specialised kernels
 // (M > 0, f32 taps) run stage 1 in the SPLIT form — two sub-tiles of 128 windows through the same LDS, each thread
-// half a window's branches (apt_kernels_fused_launch.hpp) — so that the work-rate stages' 28.5 KB, not the input
-// tile, set the LDS footprint at 48 kHz: five workgroups per CU (<= 96 VGPRs), three at 96 kHz.  (A persistent form
+// half a window's branches (apt_kernels_fused_launch.hpp) — so that the work-rate stages' 26.1 KB, not the input
+// tile, set the LDS footprint at 48 kHz: six workgroups per CU (<= 80 VGPRs; five until round 4), three at 96 kHz.  (A persistent form
 // that walked the tiles with a fixed grid and kept the NEXT tile's input in registers while the stages ran was measured
 // in rounds 2 and 3 and dropped: slower in every mode)
 template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>

@@ -23,7 +23,7 @@ constexpr int fused_chunk(int m, int mode)
 // at 96 kHz.  A 256-thread workgroup instead runs stage 1 over TWO sub-tiles of 128 windows, one after the other through
 // the same LDS; in each, thread (half h, window a) computes the branches [b0, b0 + nbr) of window a only — h = 0: the
 // first (l + 1) / 2 branches, h = 1: the rest.  All 256 threads then share a 26 KB (48 kHz) / 52 KB (96 kHz) tile:
-// five workgroups per CU at 48 kHz (the work-rate stages' 28.5 KB set the footprint), three at 96 kHz where the
+// six workgroups per CU at 48 kHz (the work-rate stages' 26.1 KB set the footprint; round 3: 28.5 KB, five), three at 96 kHz where the
 // 128-thread workgroups of rounds 1-3 reached 1.5 waves per SIMD.  The stages behind it see 256 threads x l outputs.  A half's taps: its own chunk-major table over
 // the window samples [w0, w0 + 4 nch) its branches use, w0 a multiple of 4 (16-byte LDS reads); a chunk is 4
 // samples x 3 branch pairs (24 dwords) followed by the odd branch's 4 taps (half 0 only): 28 = 16 + 8 + 4 dwords.
