@@ -227,6 +227,7 @@ def run_config4(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--no-power", action="store_true", help="do not sample amd-smi's power / clock metrics beside the timed region")
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--rate", type=int, default=48000)
@@ -334,6 +335,13 @@ def main():
                 counter[0] += 1
             plan.decode_device(sigs[j], nn, out, caps)
 
+        # (amd-smi is opened here, well before the timed region: its initialisation takes a while, and a pause between
+        # the warm-up steps and the timed steps would let the power manager's averages relax)
+        smu = None
+        if rank == 0 and not args.no_power:
+            from noaa_apt_amd.testing.smu import SmuSampler
+            smu = SmuSampler(pci_bus_id=getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None), device_index=local_rank)
+
         # ---- per-kernel measurement passes, BEFORE the warm-up steps (they are part of every run; placed
         # here they also bring the GPU out of the idle clocks it fell to while the host generated inputs)
         # (a) the dominant kernel with nothing else on the GPU — one step at a time, a host
@@ -373,6 +381,9 @@ def main():
         # timed region: HIP events bracket the dominant kernel of every 8th step (the markers
         # serialise the stream for ~6 us each; sampling keeps the measurement live but cheap)
         plan.enable_timing(0 if args.no_kernel_timing else 1)
+        # what the power manager does meanwhile (rank 0): the SMU's accumulators read before and after the timed region
+        # — no thread beside it — and a sampled loop of the same steps behind it
+        snap0 = smu.snapshot() if smu is not None else None
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -383,6 +394,27 @@ def main():
         t1 = time.perf_counter()
         dom_times = plan.collect_timing()
         plan.enable_timing(0)
+        power = None
+        if smu is not None:
+            power = {"source": "amd-smi gpu_metrics on rank 0: energy and throttler-residency accumulators read before / after the timed "
+                               "region; socket power and per-XCD gfx clocks sampled every 2 ms during the loop behind it",
+                     "timed_region": smu.between(snap0, smu.snapshot())}
+            if smu.available:
+                # the same loop again for ~0.4 s under the sampler, the first 0.1 s left out: what the pipeline looks like
+                # to the power manager once it has settled
+                k3 = max(args.steps, int(0.4 / max(1e-4, (t1 - t0) / args.steps)))
+                with smu:
+                    a3 = time.perf_counter()
+                    for _ in range(k3):
+                        step()
+                    torch.cuda.synchronize()
+                    b3 = time.perf_counter()
+                power["settled"] = smu.summary(skip_s=0.1)
+                if power["settled"] is not None:
+                    power["settled"]["steps"] = k3
+                    power["settled"]["ms_per_step"] = round(1e3 * (b3 - a3) / k3, 5)
+            else:
+                power["error"] = smu.error
         step(0)  # the recording that is compared with the oracle below
         res = plan.results(1)[0]
         ref_pos = plan.sync_positions(0) if not args.no_sync else np.zeros(0, np.uint64)
@@ -640,6 +672,12 @@ def main():
                 # `batch` recordings is that many times as long)
                 valu["issue_floor_us_per_launch"] = round(sq["issue_floor_us"] * max(1, args.batch), 2)
                 valu["achieved_frac_of_issue_floor"] = round(sq["issue_floor_us"] * max(1, args.batch) / (alone_ms * 1e3), 4)
+                # the floor above is priced at 2.4 GHz; in the pipelined loop the package is at its power limit and the
+                # SMU runs the XCDs slower (`power.settled`): the same floor at the clock the pipeline actually gets
+                clk = ((power or {}).get("settled") or {}).get("gfxclk_mhz", {}).get("mean_over_xcds")
+                if clk:
+                    valu["issue_floor_us_per_launch_at_settled_clock"] = round(valu["issue_floor_us_per_launch"] * 2400.0 / clk, 2)
+                    valu["settled_gfxclk_mhz"] = clk
         line = {
             "metric": "Msamples/sec WAV->APT-line decode",
             "value": round(value, 3),
@@ -709,6 +747,9 @@ def main():
                     "algorithmic_bytes_per_launch": b_alg / max(1, args.batch),
                     "frac": round(b_alg / max(1, args.batch) / (single_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             },
+            # the pipelined loop runs at the package power limit: socket power, the gfx clocks the SMU grants, the share
+            # of time the power throttler was active (None when amd-smi cannot be read)
+            "power": power,
             "pipeline": {
                 "achieved": round(pipe_achieved, 2),
                 "unit": "GB/s",

@@ -1,0 +1,42 @@
+"""noaa_apt_amd/testing/smu.py: the summary arithmetic on hand-made samples (no amd-smi, no GPU), and that a host
+without a readable SMU yields `available == False` / `summary() is None` instead of an exception."""
+from noaa_apt_amd.testing.smu import SmuSampler
+
+
+def _fake(samples, cap_w=1400.0, max_clk=2400):
+    s = SmuSampler.__new__(SmuSampler)
+    s.period_s, s.samples, s.available, s.error = 0.002, samples, True, None
+    s.cap_w, s.max_gfxclk = cap_w, max_clk
+    return s
+
+
+def test_summary_means_and_throttle_fractions():
+    samples = [
+        {"t": 0.00, "current_socket_power": 300, "gfxclks": [2400, 2400], "accumulation_counter": 0, "ppt_residency_acc": 0},
+        {"t": 0.10, "current_socket_power": 1300, "gfxclks": [2100, 1900], "current_uclk": 2000, "accumulation_counter": 100,
+         "ppt_residency_acc": 50, "temperature_hotspot": 50},
+        {"t": 0.20, "current_socket_power": 1400, "gfxclks": [2000, 2000], "current_uclk": 2000, "accumulation_counter": 200,
+         "ppt_residency_acc": 140, "temperature_hotspot": 55},
+    ]
+    full = _fake(samples).summary()
+    assert full["samples"] == 3 and full["socket_w"] == {"mean": 1000.0, "max": 1400}
+    assert full["throttled_frac"]["power_limit"] == 0.7
+    settled = _fake(samples).summary(skip_s=0.05)
+    assert settled["samples"] == 2
+    assert settled["socket_w"]["mean"] == 1350.0
+    assert settled["gfxclk_mhz"] == {"mean_over_xcds": 2000.0, "slowest_xcd": 1950.0, "fastest_xcd": 2050.0}
+    assert settled["throttled_frac"]["power_limit"] == 0.9
+    assert settled["cap_w"] == 1400.0 and settled["max_gfxclk_mhz"] == 2400 and settled["hbm_clk_mhz"] == 2000.0
+    assert settled["temperature_hotspot_c"] == 55
+
+
+def test_no_smu_is_not_an_error():
+    s = SmuSampler()
+    if s.available:  # a GPU box: the sampler works, nothing more to check here
+        with s:
+            pass
+        return
+    assert s.error
+    with s:
+        pass
+    assert s.summary() is None

@@ -3,8 +3,10 @@
 
 A sampler kernel (tools/ubench/clocks.hip -> libclockprobe.so: eight single-wave workgroups, one per XCD if the
 dispatcher spreads them) stays resident beside the work and records (s_memtime, s_memrealtime) pairs every ~10 us:
-shader-clock ticks against a constant 100 MHz.  The slope over the middle of the busy window is the clock the front
-end actually ran at.  One process per regime (the probe library latches APTGPU_DEBUG_SKIP on first use):
+what was taken for shader-clock ticks against a constant 100 MHz.  IT IS NOT: s_memtime (and the period of an s_sleep
+loop) tick at a constant rate on gfx950 whatever the gfx clock is — this tool reads 2.40 GHz in every regime while the
+SMU runs the XCDs at 2.0 GHz under the pipeline (tools/power_regimes.py, noaa_apt_amd/testing/smu.py: ask the SMU).
+Kept for the record and for the per-regime front-end durations it logs.  One process per regime (the probe library latches APTGPU_DEBUG_SKIP on first use):
 
     python tools/clock_regimes.py --regime isolated      # one call at a time, host synchronisation after each
     APTGPU_LIB=noaa_apt_amd/libaptgpu_probe.so APTGPU_DEBUG_SKIP=7 python tools/clock_regimes.py --regime back_to_back

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--inputs", type=int, default=4)
     ap.add_argument("--pcm16", action="store_true")
     ap.add_argument("--profile", default="standard", help="settings profile (default_settings.toml): standard, fast, slow")
+    ap.add_argument("--power", action="store_true", help="sample amd-smi beside the timed loop: socket power, gfx clocks, joules per call")
     ap.add_argument("--no-sync", action="store_true", help="decode(sync=false): front end without stage 4, no picker")
     args = ap.parse_args()
 
@@ -80,12 +81,27 @@ def main():
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
+        smu = None
+        if args.power:
+            from noaa_apt_amd.testing.smu import SmuSampler
+            smu = SmuSampler()
+            s0 = smu.snapshot()
+            smu.__enter__()
         a = time.perf_counter()
         for _ in range(args.steps):
             step()
         t_enq = time.perf_counter()
         torch.cuda.synchronize()
         b = time.perf_counter()
+        power = None
+        if smu is not None:
+            smu.__exit__(None, None, None)
+            power = smu.summary(skip_s=min(0.1, 0.25 * (b - a)))
+            bt = smu.between(s0, smu.snapshot())
+            if power is not None and bt and "socket_w_mean" in bt:
+                power["joules_per_call"] = round(bt["socket_w_mean"] * bt["window_s"] / args.steps, 4)
+                power["socket_w_mean_by_energy_counter"] = bt["socket_w_mean"]
+                power["power_limit_throttled_frac"] = bt.get("power_limit_throttled_frac")
         plan.enable_timing(2)
         for _ in range(8):
             step()
@@ -106,6 +122,7 @@ def main():
             "host_enqueue_ms_per_call": round(1e3 * (t_enq - a) / args.steps, 4),
             "status": [int(r.status) for r in res][:4], "rows": int(res[0].n_rows), "fused": int(plan.info.fused), "rows_checksum": chk,
             "alone_ms_per_call": {kk: round(v[0], 5) for kk, v in sorted(alone.items())},
+            **({"power": power} if args.power else {}),
         }), flush=True)
         plan.close()
         for k_, v_ in saved_env.items():

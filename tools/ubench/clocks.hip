@@ -1,8 +1,9 @@
 // tools/ubench/clocks.hip — shader-clock sampler (libclockprobe.so; not part of the product).
 //
 // k_clock_sampler: a few single-wave workgroups that stay resident while other work runs and record, every few
-// microseconds, the pair (s_memtime, s_memrealtime): the first ticks at the shader clock of the wave's XCD, the second
-// at a constant 100 MHz, so the slope between two samples is the effective shader clock over that interval.  One wave
+// microseconds, the pair (s_memtime, s_memrealtime): the second ticks at a constant 100 MHz and the first was expected
+// to tick at the shader clock of the wave's XCD.  It does not (measured: constant 2.40 GHz while the SMU reports 2.0 GHz
+// under load, and the s_sleep period below is constant too) — see tools/power_regimes.py for the real clocks.  One wave
 // per workgroup, ~10 VALU instructions per sample and an s_sleep in between: it takes a wave slot (and nothing else
 // worth mentioning) on the CUs it lands on.  tools/clock_regimes.py runs it beside the decode pipeline.
 #include <hip/hip_runtime.h>
