@@ -227,6 +227,9 @@ def run_config4(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--pre-steps", type=int, default=48, help="untimed steps before the per-kernel measurement passes")
+    ap.add_argument("--settle-steps", type=int, default=40,
+                    help="untimed pipelined steps between the per-kernel measurement passes and the W warm-up steps")
     ap.add_argument("--no-power", action="store_true", help="do not sample amd-smi's power / clock metrics beside the timed region")
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--warmup", type=int, default=30)
@@ -348,7 +351,7 @@ def main():
         # synchronisation after each, HIP events around every launch.  This per-launch duration
         # is what `roofline` uses (a launch in the timed region below shares the GPU with the
         # launches of the other calls in flight, so its duration there is not GPU time per launch).
-        for _ in range(48):  # (the host spent seconds generating inputs: bring the clocks up before timing anything)
+        for _ in range(args.pre_steps):  # (the host spent seconds generating inputs: wake the GPU before timing anything)
             step()
         torch.cuda.synchronize()
         plan.enable_timing(2)
@@ -366,12 +369,18 @@ def main():
                 torch.cuda.synchronize()
             single_ms = plan1.collect_timing().get("fused_front_end", (None, 0))[0]
             plan1.close()
-        # (c) pipelined, with events around every kernel, for the per-kernel breakdown
+        # (c) pipelined, with events around every kernel, for the per-kernel breakdown.  This pass is also what the
+        # power manager sees last before the warm-up steps: passes (a) and (b) leave the package 40 % idle, its power
+        # average relaxes, and a pipelined loop started then runs its first ~5 ms at up to 2.4 GHz, the next ~10 ms
+        # BELOW the settled clock (the controller overshoots) — `--settle-steps` pipelined steps (default 40: ~35 ms)
+        # put the loop into the state a long run is in before W and K are counted
         plan.enable_timing(2)
         for _ in range(10):
             step()
         ktimes = plan.collect_timing()
         plan.enable_timing(0)
+        for _ in range(args.settle_steps):
+            step()
 
         # ---- W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize
         for _ in range(args.warmup):

@@ -106,6 +106,10 @@ class SmuSampler:
         if not a or not b or b["t"] <= a["t"]:
             return None
         out = {"window_s": round(b["t"] - a["t"], 5)}
+        if b.get("accumulation_counter") == a.get("accumulation_counter"):
+            # the driver hands out a cached copy of the table now and then: the second read saw the first one's data
+            out["stale_table"] = True
+            return out
         if "energy_accumulator" in a and "energy_accumulator" in b:
             out["socket_w_mean"] = round((b["energy_accumulator"] - a["energy_accumulator"]) * 2.0 ** -16 / (b["t"] - a["t"]), 1)
         ticks = b.get("accumulation_counter", 0) - a.get("accumulation_counter", 0)

@@ -40,3 +40,12 @@ def test_no_smu_is_not_an_error():
     with s:
         pass
     assert s.summary() is None
+
+
+def test_between_snapshots():
+    a = {"t": 1.0, "energy_accumulator": 0, "accumulation_counter": 10, "ppt_residency_acc": 5}
+    b = {"t": 1.5, "energy_accumulator": 65536 * 600, "accumulation_counter": 510, "ppt_residency_acc": 405, "gfxclks": [2000, 2100]}
+    r = SmuSampler.between(a, b)
+    assert r["socket_w_mean"] == 1200.0 and r["power_limit_throttled_frac"] == 0.8 and r["gfxclk_mhz_at_end"] == 2050.0
+    assert SmuSampler.between(a, dict(a, t=2.0)) == {"window_s": 1.0, "stale_table": True}
+    assert SmuSampler.between(None, b) is None
