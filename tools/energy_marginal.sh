@@ -1,11 +1,9 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=$R/gpurun_out/r4e; mkdir -p $O
+# tools/energy_marginal.sh — joules ONE more launch of each chain kernel adds to a pipelined call (probe library), PCM16 input, config 3,
+# the fast / slow profiles.  One gpurun call; profiles/r04_energy_marginal.txt.
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=$R/gpurun_out/energy; mkdir -p $O
 P=$R/noaa_apt_amd/libaptgpu_probe.so
 python3 -c "import torch" 2>/dev/null
-run() { # name, env..., -- sweep args
-  name=$1; shift
-  env "$@" 2>/dev/null
-}
 echo "## base (probe library, nothing repeated)" > $O/energy_marginal.txt
 APTGPU_LIB=$P python3 tools/sweep.py --power --inputs 16 --steps 800 --warmup 50 --configs strict:16:3 >> $O/energy_marginal.txt 2>$O/e0
 for K in WORDS ORBIT GATHER; do

@@ -1,5 +1,7 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=$R/gpurun_out/r4q; mkdir -p $O
+# tools/energy_per_call.sh — bench lines with `power`, then joules per call (tools/sweep.py --power) of the whole pipeline, one call in
+# flight, the front ends alone and twice (probe library), 44.1 kHz.  One gpurun call; profiles/r04_energy_per_call.txt, r04_bench_power_*.json.
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=$R/gpurun_out/energy; mkdir -p $O
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_shape.json 2> $O/bench_driver_shape.err
 python3 bench.py --no-extras --no-cpu-baseline --no-single-launch > $O/bench_strict_600.json 2> $O/e1
 python3 bench.py --no-extras --no-cpu-baseline --no-single-launch --mode fast > $O/bench_fast_600.json 2> $O/e3
