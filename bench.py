@@ -637,14 +637,16 @@ def main():
             # (tools/collect_profiles.sh stamps them with tools/csrc_hash.py's hash of noaa_apt_amd/csrc)
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             try:
-                from csrc_hash import csrc_sha16
+                from csrc_hash import csrc_sha16, matches as stamp_matches
                 here = csrc_sha16(ROOT)
             except Exception:
                 here = None
+                stamp_matches = None
             try:
                 f = os.path.join(ROOT, "profiles", f"r04_hbm_traffic_{args.mode}.json")
                 d_t = json.load(open(f))
-                if here and d_t.get("csrc_sha16") == here:
+                # (the whole-tree stamp, or — profiles collected from round 5 on — the stamp of the front end's own sources)
+                if here and stamp_matches(d_t, "front_end", ROOT):
                     traffic = d_t["per_launch"]["k_fused"]["hbm_total_MB"] * 1e6
                     traffic_src = (f"profiles/r04_hbm_traffic_{args.mode}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                    f"collected on these kernel sources: csrc {here})")
@@ -655,7 +657,7 @@ def main():
                 traffic = None
             try:
                 d_s = json.load(open(os.path.join(ROOT, "profiles", f"r04_sq_counters_{args.mode}.json")))
-                sq = d_s if (here and d_s.get("csrc_sha16") == here) else None
+                sq = d_s if (here and stamp_matches(d_s, "front_end", ROOT)) else None
             except Exception:
                 sq = None
         # arithmetic the front end EXECUTES per work-rate sample: two flops per FIR tap, ~8 for the envelope,

@@ -28,10 +28,10 @@ for MODE in strict fast; do
   (cd $R && python - <<PY
 import json, sys
 sys.path.insert(0, "tools")
-from csrc_hash import csrc_sha16
+from csrc_hash import stamp
 for f in ("$O/hbm_traffic_$MODE.json", "$O/sq_$MODE/summary.json"):
     try:
-        d = json.load(open(f)); d["csrc_sha16"] = csrc_sha16(); json.dump(d, open(f, "w"), indent=1)
+        d = stamp(json.load(open(f))); json.dump(d, open(f, "w"), indent=1)
     except Exception as e:
         print("stamp failed", f, e)
 PY

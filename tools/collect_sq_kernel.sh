@@ -30,10 +30,10 @@ for LP in $(echo "$SPEC" | tr ',' ' '); do
   python - $FILES <<'PY'
 import json, sys
 sys.path.insert(0, "tools")
-from csrc_hash import csrc_sha16
+from csrc_hash import stamp
 for f in sys.argv[1:]:
     try:
-        d = json.load(open(f)); d["csrc_sha16"] = csrc_sha16(); json.dump(d, open(f, "w"), indent=1)
+        d = stamp(json.load(open(f))); json.dump(d, open(f, "w"), indent=1)
     except Exception as e:
         print("stamp failed", f, e)
 PY
