@@ -642,22 +642,37 @@ def main():
             except Exception:
                 here = None
                 stamp_matches = None
+            import glob
+
+            def newest_profile(stem):
+                """The latest round's profiles/rNN_<stem>.json whose stamp matches the sources here (else the latest one)."""
+                cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{stem}.json")), reverse=True)
+                first = None
+                for fpath in cands:
+                    try:
+                        d_ = json.load(open(fpath))
+                    except Exception:
+                        continue
+                    first = first or (fpath, d_)
+                    if here and stamp_matches(d_, "front_end", ROOT):
+                        return fpath, d_, True
+                return (first[0], first[1], False) if first else (None, None, False)
+
             try:
-                f = os.path.join(ROOT, "profiles", f"r04_hbm_traffic_{args.mode}.json")
-                d_t = json.load(open(f))
-                # (the whole-tree stamp, or — profiles collected from round 5 on — the stamp of the front end's own sources)
-                if here and stamp_matches(d_t, "front_end", ROOT):
+                f, d_t, ok_t = newest_profile(f"hbm_traffic_{args.mode}")
+                rel = os.path.relpath(f, ROOT) if f else None
+                if ok_t:
                     traffic = d_t["per_launch"]["k_fused"]["hbm_total_MB"] * 1e6
-                    traffic_src = (f"profiles/r04_hbm_traffic_{args.mode}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                   f"collected on these kernel sources: csrc {here})")
-                else:
-                    traffic_src = (f"profiles/r04_hbm_traffic_{args.mode}.json is stamped {d_t.get('csrc_sha16')}, the kernel "
+                    traffic_src = (f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                   f"collected on these kernel sources: csrc {d_t.get('csrc_sha16')})")
+                elif f:
+                    traffic_src = (f"{rel} is stamped {d_t.get('csrc_sha16')}, the kernel "
                                    f"sources here hash to {here}: not quoted")
             except Exception:
                 traffic = None
             try:
-                d_s = json.load(open(os.path.join(ROOT, "profiles", f"r04_sq_counters_{args.mode}.json")))
-                sq = d_s if (here and stamp_matches(d_s, "front_end", ROOT)) else None
+                _, d_s, ok_s = newest_profile(f"sq_counters_{args.mode}")
+                sq = d_s if ok_s else None
             except Exception:
                 sq = None
         # arithmetic the front end EXECUTES per work-rate sample: two flops per FIR tap, ~8 for the envelope,

@@ -1,25 +1,51 @@
 #!/bin/bash
-# tools/collect_all.sh — everything under profiles/ for this round in ONE call on the GPU box: the counter passes, their
-# summaries installed into profiles/ (so that bench.py finds them, stamped with the hash of the sources it runs), then
-# the bench lines of every configuration.  Afterwards, locally: tools/install_profiles.sh copies gpurun_out/prof/* into
-# profiles/ under the round's names.
+# tools/collect_all.sh [round] [stage...] — everything under profiles/ for a round in ONE call on the GPU box: the counter
+# passes, their summaries installed into profiles/ (so that bench.py finds them, stamped with the hashes of the sources
+# it runs), then the bench lines of every configuration.  Afterwards, locally: tools/install_profiles.sh copies
+# gpurun_out/prof/* into profiles/ under the round's names.
+# Stages (default: all of them, ~14 GPU-minutes; each logs its seconds to gpurun_out/prof/stage_seconds.txt):
+#   counters  front-end kernel stats, HBM traffic, SQ counters (strict + fast)        ~4 min   -> must precede `bench`
+#   bench     the bench line of every configuration                                   ~5 min
+#   chain     SQ counters of k_sync_words / slots / orbit / gather                    ~1.5 min
+#   others    SQ counters of the PHASE / TABLE / 96 kHz / profile / k_fused_any front ends  ~2 min
+#   power     socket power, clocks, joules per call (amd-smi)                         ~1.5 min
+#   pipeline  marginal cost of each kernel, shape variants, the LDS microbenchmark     ~1.5 min
+# An edit confined to one group of kernels (tools/csrc_hash.py --groups) needs only that group's stages again.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R || exit 1
-rm -rf gpurun_out/prof; mkdir -p gpurun_out/prof
-bash tools/collect_profiles.sh counters > gpurun_out/prof_counters.log 2>&1
-bash tools/install_profiles.sh ${1:-r04} > /dev/null 2>&1
-bash tools/collect_profiles.sh bench > gpurun_out/prof_bench.log 2>&1
-# counters of the other kernels: the chain behind the front end, the PHASE / TABLE / 96 kHz front ends, the fast / slow profiles
-bash tools/collect_sq_kernel.sh words:k_sync_words,slots:k_sync_slots,orbit:k_sync_orbit,gather:k_gather_rows 1 --inputs 16 --configs strict:16:1 > gpurun_out/prof_sq_kernels.log 2>&1
-bash tools/collect_sq_kernel.sh phase:k_fused 1 --rate 44100 --inputs 2 --configs strict:1:1 >> gpurun_out/prof_sq_kernels.log 2>&1
-bash tools/collect_sq_kernel.sh table:k_fused 1 --rate 11025 --inputs 2 --configs strict:1:1 >> gpurun_out/prof_sq_kernels.log 2>&1
-bash tools/collect_sq_kernel.sh 96k:k_fused 1 --rate 96000 --inputs 2 --configs strict:1:1 >> gpurun_out/prof_sq_kernels.log 2>&1
-bash tools/collect_sq_kernel.sh profile_fast:k_fused 0 --profile fast --inputs 2 --configs strict:1:1 >> gpurun_out/prof_sq_kernels.log 2>&1
-bash tools/collect_sq_kernel.sh profile_slow:k_fused 0 --profile slow --inputs 2 --configs strict:1:1 >> gpurun_out/prof_sq_kernels.log 2>&1
-bash tools/collect_sq_kernel.sh phase512:k_fused 0 --rate 22050 --inputs 2 --configs strict:1:1 >> gpurun_out/prof_sq_kernels.log 2>&1
-bash tools/collect_sq_kernel.sh any_fast_11025:k_fused_any 0 --profile fast --rate 11025 --inputs 2 --configs strict:1:1 >> gpurun_out/prof_sq_kernels.log 2>&1
-# the shader clock by regime, the pipeline's marginal costs and shape variants, the LDS microbenchmark
-for RG in idle isolated pipeline; do timeout 200 python tools/clock_regimes.py --regime $RG >> gpurun_out/prof/sclk_regimes.txt 2>> gpurun_out/prof/sclk.err; done
-APTGPU_LIB=$R/noaa_apt_amd/libaptgpu_probe.so APTGPU_DEBUG_SKIP=7 timeout 200 python tools/clock_regimes.py --regime back_to_back >> gpurun_out/prof/sclk_regimes.txt 2>> gpurun_out/prof/sclk.err
-bash tools/pipeline_costs.sh > gpurun_out/prof/pipeline_costs.txt 2> gpurun_out/prof/pipeline_costs.err
-./tools/ubench/lds_bw.bin > gpurun_out/prof/ubench_lds_bw.txt 2>&1
+ROUND=${1:-r05}; shift
+STAGES=${*:-counters bench chain others power pipeline}
+mkdir -p gpurun_out/prof
+has() { case " $STAGES " in *" $1 "*) return 0;; esac; return 1; }
+timed() { local t0=$SECONDS; "$@"; echo "$1 $2 $3: $((SECONDS - t0)) s" >> gpurun_out/prof/stage_seconds.txt; }
+stage_counters() {
+  bash tools/collect_profiles.sh counters > gpurun_out/prof_counters.log 2>&1
+  bash tools/install_profiles.sh $ROUND > /dev/null 2>&1
+}
+stage_bench() { bash tools/collect_profiles.sh bench > gpurun_out/prof_bench.log 2>&1; }
+stage_chain() {
+  bash tools/collect_sq_kernel.sh words:k_sync_words,slots:k_sync_slots,orbit:k_sync_orbit,gather:k_gather_rows 1 --inputs 16 --configs strict:16:1 > gpurun_out/prof_sq_kernels.log 2>&1
+}
+stage_others() {
+  bash tools/collect_sq_kernel.sh phase:k_fused 1 --rate 44100 --inputs 2 --configs strict:1:1 >> gpurun_out/prof_sq_kernels.log 2>&1
+  bash tools/collect_sq_kernel.sh table:k_fused 1 --rate 11025 --inputs 2 --configs strict:1:1 >> gpurun_out/prof_sq_kernels.log 2>&1
+  bash tools/collect_sq_kernel.sh 96k:k_fused 1 --rate 96000 --inputs 2 --configs strict:1:1 >> gpurun_out/prof_sq_kernels.log 2>&1
+  bash tools/collect_sq_kernel.sh profile_fast:k_fused 0 --profile fast --inputs 2 --configs strict:1:1 >> gpurun_out/prof_sq_kernels.log 2>&1
+  bash tools/collect_sq_kernel.sh profile_slow:k_fused 0 --profile slow --inputs 2 --configs strict:1:1 >> gpurun_out/prof_sq_kernels.log 2>&1
+  bash tools/collect_sq_kernel.sh phase512:k_fused 0 --rate 22050 --inputs 2 --configs strict:1:1 >> gpurun_out/prof_sq_kernels.log 2>&1
+  bash tools/collect_sq_kernel.sh any_fast_11025:k_fused_any 0 --profile fast --rate 11025 --inputs 2 --configs strict:1:1 >> gpurun_out/prof_sq_kernels.log 2>&1
+}
+stage_power() {
+  timeout 200 python tools/power_regimes.py > gpurun_out/prof/power_regimes.txt 2> gpurun_out/prof/power_regimes.err
+  timeout 100 python tools/rates_power.py > gpurun_out/prof/rates_power.txt 2> gpurun_out/prof/rates_power.err
+  bash tools/energy_per_call.sh > gpurun_out/prof/energy_per_call.log 2>&1
+  bash tools/energy_marginal.sh > gpurun_out/prof/energy_marginal.log 2>&1
+}
+stage_pipeline() {
+  bash tools/pipeline_costs.sh > gpurun_out/prof/pipeline_costs.txt 2> gpurun_out/prof/pipeline_costs.err
+  ./tools/ubench/lds_bw.bin > gpurun_out/prof/ubench_lds_bw.txt 2>&1
+}
+for S in counters bench chain others power pipeline; do
+  if has $S; then timed stage_$S; fi
+done
+cat gpurun_out/prof/stage_seconds.txt
