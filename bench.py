@@ -731,7 +731,7 @@ def main():
                 "input_resident_in_hbm": True,
                 "distinct_inputs_round_robin": n_inputs,
                 "picker": {"path": {0: "lds", 1: "sequential-walk", 2: "global"}.get(int(pflags[1]), "?"),
-                           "node_capacity": int(pflags[3]), "visited_nodes": int(pflags[4]), "orbit": {1: "direct", 2: "doubling (LDS)"}.get(int(pflags[6]), "doubling (L2)"),
+                           "node_capacity": int(pflags[3]), "visited_nodes": int(pflags[4]), "orbit": {1: "direct", 2: "doubling (LDS)", 3: "doubling over all nodes (LDS, no closure)"}.get(int(pflags[6]), "doubling (L2)"),
                            "cycle_stamps": [int(v) for v in pflags[8:11]]},
             },
             "roofline": {

@@ -662,7 +662,7 @@ __device__ __forceinline__ void gst(uint32_t *p, uint32_t v)
 template <int NT>
 __global__ void __launch_bounds__(NT, NT >= 1024 ? 8 : 2)
 k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t spr_in, uint32_t md_in,
-                    uint32_t pw, int force_walk, uint32_t lds_entries)
+                    uint32_t pw, int force_walk, uint32_t lds_entries, int alg)
 {
     const RecArgs rec = call.rec[blockIdx.x];
     const SlotPtrs sp = slots[rec.slot];
@@ -684,6 +684,8 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
     const uint32_t nt_cap = n_chunks * kSlotCap;  // node ids of slot entries: base_d + chunk*kSlotCap + k
     __shared__ uint32_t s_count, s_plen, s_conflict, s_endcell;
     __shared__ unsigned long long s_fit;
+    __shared__ uint32_t s_wtot[kOrbitThreadsMax / 64];
+    extern __shared__ uint16_t lds_orbit[];
     // this latency-bound workgroup shares its CU with VALU-saturated front-end waves of the next
     // recording: let its few instructions issue first
     __builtin_amdgcn_s_setprio(3);
@@ -764,9 +766,147 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         return sv;
     };
 
+    // ---- alg 1: NO closure.  The successor of EVERY possible start — the root, the grid nodes, md + 1 behind every
+    // node terminal of the recording — is one independent lookup in the (compacted, LDS-resident) node-terminal list;
+    // the root's orbit then follows by doubling the known prefix, path[m + 2^r] = J_r[path[m]], J_{r+1} = J_r o J_r,
+    // with 16-bit jump tables in LDS: log2(cells) rounds whatever the recording looks like (the breadth-first closure
+    // below takes one global round trip per level: 18 and 34 levels for 2 of the bench's 8 recordings).  Needs
+    // nodes < 65535 and (chunks + entries) * 4 + nodes * 2 + cells * 2 bytes of LDS; else the closure path runs.
+    bool all_done = false;
+    uint32_t n_all = 0;
+    if (!walk && alg == 1) {
+        const uint32_t lds_bytes = lds_entries * 2u;
+        uint32_t *s_pref = reinterpret_cast<uint32_t *>(lds_orbit);  // [n_chunks + 1] entries before chunk ch
+        bool ok = (n_chunks + 1u) * 4u <= lds_bytes;                 // (uniform)
+        uint32_t n_ent = 0;
+        if (ok) {
+            // exclusive scan of the chunks' entry counts: a contiguous run of chunks per thread
+            const uint32_t cpt = (n_chunks + NT - 1) / NT;
+            const uint32_t c0 = static_cast<uint32_t>(tid) * cpt;
+            uint32_t local = 0;
+            for (uint32_t j = 0; j < cpt; ++j) {
+                const uint32_t ch = c0 + j;
+                if (ch < n_chunks) {
+                    const uint32_t c = slot_cnt[ch];
+                    local += c < kSlotCap ? c : kSlotCap;
+                }
+            }
+            uint32_t incl = local;
+            const int ln = tid & 63;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if (ln >= d) incl += o;
+            }
+            if (ln == 63) s_wtot[wave] = incl;
+            __syncthreads();
+            uint32_t before = 0;
+            for (int wq = 0; wq < wave; ++wq) before += s_wtot[wq];
+            uint32_t run = before + incl - local;
+            for (uint32_t j = 0; j < cpt; ++j) {
+                const uint32_t ch = c0 + j;
+                if (ch < n_chunks) {
+                    s_pref[ch] = run;
+                    const uint32_t c = slot_cnt[ch];
+                    run += c < kSlotCap ? c : kSlotCap;
+                }
+            }
+            if (tid == NT - 1) s_pref[n_chunks] = run;  // the last thread's run ends at the total
+            __syncthreads();
+            n_ent = s_pref[n_chunks];
+        }
+        n_all = base_d + n_ent;
+        const uint32_t path_cap_a = kc + 2;
+        // LDS: s_pref | s_ent [n_ent] (uint32; the second jump table lies over it once the successors are known) |
+        // la [n_all + 1] | pth [path_cap]
+        const uint64_t need = 4ull * (n_chunks + 1u) + 4ull * n_ent + 2ull * (n_all + 2u) + 2ull * path_cap_a + 8u;
+        ok = ok && n_ent > 0 && n_all < 0xFFFFu && 2ull * (n_all + 2u) <= 4ull * n_ent && need <= lds_bytes;
+        if (ok) {
+            uint32_t *s_ent = s_pref + (n_chunks + 1);
+            uint16_t *la = reinterpret_cast<uint16_t *>(s_ent + n_ent);
+            uint16_t *pth = la + ((n_all + 2u) & ~1u);
+            uint16_t *lb = reinterpret_cast<uint16_t *>(s_ent);
+            const uint16_t ENDC = static_cast<uint16_t>(n_all);
+            // the node terminals of the whole recording, in order
+            for (uint32_t ch = tid; ch < n_chunks; ch += NT) {
+                const uint32_t c = slot_cnt[ch];
+                const uint32_t lim = c < kSlotCap ? c : kSlotCap;
+                const uint32_t at = s_pref[ch];
+                const uint4 *src = reinterpret_cast<const uint4 *>(slot_nt + static_cast<uint64_t>(ch) * kSlotCap);
+                for (uint32_t k4 = 0; 4 * k4 < lim; ++k4) {
+                    const uint4 v = src[k4];
+                    const uint32_t vals[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (4 * k4 + t < lim) s_ent[at + 4 * k4 + t] = vals[t];
+                }
+            }
+            __syncthreads();
+            // successor of every node (ids: 0 root, 1 .. n_grid grid cells 2 .. kc, base_d + list index)
+            for (uint32_t i = tid; i < n_all; i += NT) {
+                uint32_t cell, sv;
+                if (i == 0) { cell = 1; sv = 0; }
+                else if (i < base_d) { cell = i + 1; sv = cell * spr; }
+                else { sv = (s_ent[i - base_d] & kPosMask) + md + 1; cell = div_spr(sv); }
+                uint32_t nx = n_all;  // END
+                if (sv < nc32) {
+                    // first node terminal at or after sv (a tagged entry only matches its own position)
+                    uint32_t j = s_pref[sv / kChunkSpan];
+                    uint32_t u = nc32 - 1;
+                    for (; j < n_ent; ++j) {
+                        const uint32_t e = s_ent[j];
+                        const uint32_t pos = e & kPosMask;
+                        if (pos >= sv && (!(e & kNanStartTag) || pos == sv)) { u = pos; break; }
+                    }
+                    if (j >= n_ent) j = n_ent - 1;  // cannot happen (fact 3)
+                    const uint32_t a = u + md + 1;
+                    const uint32_t b = (cell + 1) * spr;
+                    const uint32_t s2 = a > b ? a : b;
+                    if (s2 < nc32) nx = (a >= b) ? base_d + j : cell;  // grid(cell+1) has id `cell`
+                }
+                la[i] = static_cast<uint16_t>(nx);
+            }
+            if (tid == 0) { la[n_all] = ENDC; pth[0] = 0; }
+            __syncthreads();
+            stamp(0);  // successors known
+            if (tid == 0) lb[n_all] = ENDC;  // (over s_ent: dead from here on)
+            for (uint32_t span = 1; span < path_cap_a; span <<= 1) {
+                for (uint32_t mI = tid; mI < span && mI + span < path_cap_a; mI += NT) pth[mI + span] = la[pth[mI]];
+                for (uint32_t i = tid; i < n_all; i += NT) lb[i] = la[la[i]];
+                __syncthreads();
+                uint16_t *t = la; la = lb; lb = t;
+            }
+            // the path in the kernel's node ids (base_d + chunk * kSlotCap + k for list entries), and the terminal
+            // each of its nodes reaches — what the peak-list code below reads
+            for (uint32_t k = tid; k < path_cap_a; k += NT) {
+                const uint32_t i = pth[k];
+                uint32_t v = END;
+                if (i != ENDC) {
+                    v = i;
+                    if (i >= base_d) {
+                        // chunk of list index q: the last ch with s_pref[ch] <= q
+                        const uint32_t q = i - base_d;
+                        uint32_t lo_c = 0, hi_c = n_chunks;  // s_pref[lo_c] <= q < s_pref[hi_c]
+                        while (hi_c - lo_c > 1) {
+                            const uint32_t mid = (lo_c + hi_c) >> 1;
+                            if (s_pref[mid] <= q) lo_c = mid; else hi_c = mid;
+                        }
+                        v = base_d + lo_c * kSlotCap + (q - s_pref[lo_c]);
+                    }
+                    uint32_t cell, u = 0;
+                    const uint32_t sv = node_start(v, &cell);
+                    if (sv < nc32) (void)first_node_terminal(sv, &u);
+                    gst(w_u + v, u);
+                }
+                gst(w_path + k, v);
+            }
+            __syncthreads();
+            all_done = true;
+        }
+    }
+
     // ---- reachable set by breadth-first marking from the root and every grid node
     uint32_t count = 0;
-    if (!walk) {
+    if (!walk && !all_done) {
         for (uint32_t wq = tid; wq < n_nodes / 32 + 1; wq += NT) gst(w_mark + wq, 0u);
         for (uint32_t c = tid; c < kc + 3; c += NT) gst(w_succ + c, 0xFFFFFFFFu);
         if (tid == 0) { s_count = base_d; s_conflict = 0; s_endcell = kc + 2; }
@@ -826,7 +966,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         count = hi;
         if (tid == 0) flags[12] = static_cast<uint32_t>(level);  // breadth-first levels (diagnostics)
     }
-    stamp(0);  // reachable set closed
+    if (!all_done) stamp(0);  // reachable set closed
 
     if (walk) {
         if (wave == 0) orbit_walk52(words, sp.nanw, gq, peaks, peaks_cap, res);
@@ -839,11 +979,11 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         }
         return;
     }
-    if (tid == 0) { gst(w_ja + END, END); gst(w_jb + END, END); gst(w_path, 0u); }
+    if (tid == 0 && !all_done) { gst(w_ja + END, END); gst(w_jb + END, END); gst(w_path, 0u); }
     __syncthreads();
 
     const uint32_t path_cap = kc + 2;  // root + at most one start per cell
-    const bool direct = s_conflict == 0;  // uniform (shared)
+    const bool direct = !all_done && s_conflict == 0;  // uniform (shared)
     if (direct) {
         // ---- confluent recording: the start in cell k+1 is the common successor of cell k, so the
         // orbit is read off without any pointer chasing: path[0] = root (acts as cell 1),
@@ -859,9 +999,8 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
     // (a) in LDS when the visited nodes fit (they do unless the recording is pathological): jump tables
     // over the nodes' indices in the visited list, 16 bits each — log2(cells) rounds of LDS reads and
     // barriers, ~10 us instead of the ~130 us the same rounds cost through L2
-    extern __shared__ uint16_t lds_orbit[];
     const uint32_t lds_cap = lds_entries;  // uint16 entries of dynamic LDS
-    const bool in_lds = !direct && path_cap + 2 * (count + 1) <= lds_cap && count < 0xFFFFu;
+    const bool in_lds = !all_done && !direct && path_cap + 2 * (count + 1) <= lds_cap && count < 0xFFFFu;
     if (in_lds) {
         uint16_t *pth = lds_orbit;              // [path_cap]
         uint16_t *la = pth + path_cap;          // [count + 1]
@@ -884,7 +1023,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         __syncthreads();
     }
     // (b) through global memory otherwise
-    if (!direct && !in_lds) {
+    if (!all_done && !direct && !in_lds) {
     constexpr int kKeep = 4;  // visited ids (and their current jump) kept in registers
     uint32_t vk[kKeep], jk[kKeep];
 #pragma unroll
@@ -957,8 +1096,10 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         flags[5] = 0u;
         flags[2] = nt_cap;
         flags[3] = n_nodes;
-        flags[4] = count;
-        flags[6] = direct ? 1u : (in_lds ? 2u : 0u);  // orbit: 1 read off directly, 2 doubling in LDS, 0 doubling through L2
+        flags[4] = all_done ? n_all : count;
+        // orbit: 1 read off directly, 2 doubling in LDS over the visited nodes, 0 the same through L2, 3 doubling over all nodes (alg 1)
+        flags[6] = all_done ? 3u : direct ? 1u : (in_lds ? 2u : 0u);
+        if (all_done) flags[12] = 0u;  // no breadth-first levels
         flags[11] = flags[7];  // candidates k_sync_words settled with exact window maxima; re-armed
         flags[7] = 0u;
     }
@@ -1037,12 +1178,23 @@ void sync_orbit(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, ui
     const char *e = std::getenv("APTGPU_ORBIT_LDS");
     const uint32_t kOrbitLdsEntries = (e && e[0] == '0') ? 0u : 12288u;
     const char *e_nt = std::getenv("APTGPU_ORBIT_THREADS");  // A/B switch (read per launch)
-    if (e_nt && std::atoi(e_nt) == 256)
+    // APTGPU_ORBIT_ALG=1: successors of all nodes + doubling from the root, no breadth-first closure; 128 KB of LDS
+    // (recordings whose tables do not fit take the closure path inside the same launch)
+    const char *e_alg = std::getenv("APTGPU_ORBIT_ALG");
+    const int alg = (e_alg && e_alg[0] == '1' && kOrbitLdsEntries != 0u) ? 1 : 0;
+    if (e_nt && std::atoi(e_nt) == 256) {
         hipLaunchKernelGGL(k_sync_orbit_global<256>, dim3(call.count), dim3(256), kOrbitLdsEntries * sizeof(uint16_t), s,
-                           call, d_slots, spr, md, pw, force == 1 ? 1 : 0, kOrbitLdsEntries);
-    else
+                           call, d_slots, spr, md, pw, force == 1 ? 1 : 0, kOrbitLdsEntries, 0);
+    } else if (alg == 1) {
+        constexpr uint32_t kAllEntries = 65536u;  // uint16 entries: 128 KB
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sync_orbit_global<kOrbitThreadsMax>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kAllEntries * sizeof(uint16_t)));
+        hipLaunchKernelGGL(k_sync_orbit_global<kOrbitThreadsMax>, dim3(call.count), dim3(kOrbitThreadsMax), kAllEntries * sizeof(uint16_t), s,
+                           call, d_slots, spr, md, pw, force == 1 ? 1 : 0, kAllEntries, 1);
+    } else {
         hipLaunchKernelGGL(k_sync_orbit_global<kOrbitThreadsMax>, dim3(call.count), dim3(kOrbitThreadsMax), kOrbitLdsEntries * sizeof(uint16_t), s,
-                           call, d_slots, spr, md, pw, force == 1 ? 1 : 0, kOrbitLdsEntries);
+                           call, d_slots, spr, md, pw, force == 1 ? 1 : 0, kOrbitLdsEntries, 0);
+    }
 }
 
 }  // namespace apt::gpu

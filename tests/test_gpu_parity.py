@@ -718,6 +718,37 @@ def test_picker_paths_direct_and_doubling(oracle, monkeypatch, lds):
     assert all(d == (2 if lds else 0) for d in doubling), seen
 
 
+def test_picker_all_nodes_doubling(oracle, monkeypatch):
+    """APTGPU_ORBIT_ALG=1: the successors of ALL possible starts and the root's orbit by doubling — no breadth-first
+    closure — on confluent and non-confluent recordings; bit-exact, and the path is the one that ran."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("APTGPU_ORBIT_ALG", "1")
+    dev = torch.device("cuda:0")
+    cases = [("apt", synth_apt(48000, 20, 5)), ("noise", synth_noise(48000, 20.0, 5, sigma=4000.0)),
+             ("noise-long", synth_noise(48000, 120.0, 6, sigma=3000.0)), ("apt-long", synth_apt(48000, 600, 2)),
+             ("nan", np.where(np.arange(48000 * 20) % 9001 == 17, np.float32("nan"), synth_apt(48000, 20, 11)).astype(f32)),
+             ("gaps", np.concatenate([synth_apt(48000, 8, 7), synth_noise(48000, 3.0, 8, sigma=500.0),
+                                      synth_apt(48000, 9, 9), np.zeros(48000, f32), synth_apt(48000, 7, 10)]))]
+    seen = {}
+    for name, x in cases:
+        plan = apt.Plan(apt.Settings(), apt.Rate.hz(48000), True, max_samples=x.size)
+        d_in = torch.from_numpy(x).to(dev)
+        cap = int(plan.info.max_rows)
+        d_out = torch.empty(cap * 2080, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(2):  # twice: the plan's scratch is reused
+            plan.decode_device([d_in.data_ptr()], [x.size], [d_out.data_ptr()], [cap])
+        res = plan.results(1)[0]
+        flags = plan.read_internal("picker_flags", np.uint32, 32)
+        want, st = oracle.decode(x, 48000, True, want_steps=True)
+        assert_bitexact(d_out[:res.n_out].cpu().numpy(), want, name)
+        assert plan.sync_positions(0).tolist() == st["sync_pos"].tolist(), name
+        seen[name] = (int(flags[1]), int(flags[6]))
+        plan.close()
+    assert seen["apt"] == (2, 3) and seen["apt-long"] == (2, 3) and seen["noise-long"] == (2, 3), seen
+    assert all(v == (2, 3) or v[0] == 1 for v in seen.values()), seen  # (1: the walk, when a chunk's node list overflowed)
+
+
 # ------------------------------------------------------------------ plans / batch
 def test_plan_device_resident_batch(ctx, oracle):
     torch = pytest.importorskip("torch")
