@@ -766,7 +766,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         return sv;
     };
 
-    // ---- alg 1: NO closure.  The successor of EVERY possible start — the root, the grid nodes, md + 1 behind every
+    // ---- alg 1 (the default): NO closure.  The successor of EVERY possible start — the root, the grid nodes, md + 1 behind every
     // node terminal of the recording — is one independent lookup in the (compacted, LDS-resident) node-terminal list;
     // the root's orbit then follows by doubling the known prefix, path[m + 2^r] = J_r[path[m]], J_{r+1} = J_r o J_r,
     // with 16-bit jump tables in LDS: log2(cells) rounds whatever the recording looks like (the breadth-first closure
@@ -1178,10 +1178,11 @@ void sync_orbit(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, ui
     const char *e = std::getenv("APTGPU_ORBIT_LDS");
     const uint32_t kOrbitLdsEntries = (e && e[0] == '0') ? 0u : 12288u;
     const char *e_nt = std::getenv("APTGPU_ORBIT_THREADS");  // A/B switch (read per launch)
-    // APTGPU_ORBIT_ALG=1: successors of all nodes + doubling from the root, no breadth-first closure; 128 KB of LDS
-    // (recordings whose tables do not fit take the closure path inside the same launch)
+    // the default: successors of all nodes + doubling from the root, no breadth-first closure; 128 KB of LDS
+    // (recordings whose tables do not fit take the closure path inside the same launch).  APTGPU_ORBIT_ALG=0 (A/B
+    // switch, tests) or APTGPU_ORBIT_LDS=0: the closure path for every recording
     const char *e_alg = std::getenv("APTGPU_ORBIT_ALG");
-    const int alg = (e_alg && e_alg[0] == '1' && kOrbitLdsEntries != 0u) ? 1 : 0;
+    const int alg = ((e_alg && e_alg[0] == '0') || kOrbitLdsEntries == 0u) ? 0 : 1;
     if (e_nt && std::atoi(e_nt) == 256) {
         hipLaunchKernelGGL(k_sync_orbit_global<256>, dim3(call.count), dim3(256), kOrbitLdsEntries * sizeof(uint16_t), s,
                            call, d_slots, spr, md, pw, force == 1 ? 1 : 0, kOrbitLdsEntries, 0);

@@ -685,10 +685,12 @@ def test_rows_cap_clamps_the_result_record(oracle):
 
 @pytest.mark.parametrize("lds", [True, False])
 def test_picker_paths_direct_and_doubling(oracle, monkeypatch, lds):
-    """The global-memory picker reads the orbit off directly on a confluent (continuous APT)
-    recording and extracts it by pointer doubling otherwise — with its jump tables in LDS, or (forced
-    here; else only for recordings whose visited nodes do not fit) through global memory; all bit-exact."""
+    """The closure form of the picker (APTGPU_ORBIT_ALG=0; what runs when a recording's tables do not fit the default
+    form's LDS): it reads the orbit off directly on a confluent (continuous APT) recording and extracts it by pointer
+    doubling otherwise — with its jump tables in LDS, or (forced here; else only for recordings whose visited nodes do
+    not fit) through global memory; all bit-exact."""
     torch = pytest.importorskip("torch")
+    monkeypatch.setenv("APTGPU_ORBIT_ALG", "0")
     if not lds:
         monkeypatch.setenv("APTGPU_ORBIT_LDS", "0")
     dev = torch.device("cuda:0")
@@ -719,10 +721,10 @@ def test_picker_paths_direct_and_doubling(oracle, monkeypatch, lds):
 
 
 def test_picker_all_nodes_doubling(oracle, monkeypatch):
-    """APTGPU_ORBIT_ALG=1: the successors of ALL possible starts and the root's orbit by doubling — no breadth-first
+    """The default picker: the successors of ALL possible starts and the root's orbit by doubling — no breadth-first
     closure — on confluent and non-confluent recordings; bit-exact, and the path is the one that ran."""
     torch = pytest.importorskip("torch")
-    monkeypatch.setenv("APTGPU_ORBIT_ALG", "1")
+    monkeypatch.delenv("APTGPU_ORBIT_ALG", raising=False)
     dev = torch.device("cuda:0")
     cases = [("apt", synth_apt(48000, 20, 5)), ("noise", synth_noise(48000, 20.0, 5, sigma=4000.0)),
              ("noise-long", synth_noise(48000, 120.0, 6, sigma=3000.0)), ("apt-long", synth_apt(48000, 600, 2)),
