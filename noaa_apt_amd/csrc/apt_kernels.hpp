@@ -143,6 +143,10 @@ struct TableGeom {
     uint32_t off_x;            // LDS offset of the input tile in floats (the table sits at 0)
     uint32_t step_q, step_r;   // (NTHR*m) / l and % l: x0 / phase update between a thread's outputs
     uint32_t jl_a, jl_b;       // jlim / l and % l: taps of phase p = jl_a + (p < jl_b)
+    // PHASE mode: the thread -> branch-slot assignment (fused_phase_table): `nperm` lists of `nthr` uint32 entries at
+    // float offset `perm_off` of the table buffer, list (tile % nperm) for a tile; an entry >= step_r marks an idle thread
+    uint32_t nthr, perm_off, nperm;
+    uint32_t nq;               // PHASE mode: branches per thread (1, 2, 4); step_r / nq threads of a workgroup have work
 };
 struct FusedParams {
     const float *hs;        // stage-1 table: tap pairs (fused_branch_taps), or the fp16 table
@@ -177,8 +181,9 @@ bool fused_table_front_end(hipStream_t s, const TableGeom &geom, int mode, bool 
 // TableGeom use: step_r = S, step_q = S*m/l, tpp = row stride of the table (multiple of 4), off_x = f2 entries
 // per region of the paired input tile, xt = floats of the whole tile.
 bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom);
-uint32_t fused_phase_table_floats(uint32_t l, uint32_t t1);
-void fused_phase_table(uint32_t l, const float *coeff, uint32_t t1, float *table);  // host: [l][tpp], rows 16-byte aligned
+uint32_t fused_phase_table_floats(const TableGeom &geom);
+// host: [l][tpp] taps, rows 16-byte aligned, then the thread assignment lists (geom.perm_off)
+void fused_phase_table(const TableGeom &geom, uint32_t t2, uint32_t pw, const float *coeff, uint32_t t1, float *table);
 bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, uint32_t t2, uint32_t pw, int mode, bool pcm16,
                            const CallArgs &call, const FusedParams *d_prm, uint64_t max_w);
 

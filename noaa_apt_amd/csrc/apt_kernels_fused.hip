@@ -27,7 +27,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <cstring>
 #include <type_traits>
+#include <vector>
 
 #pragma clang fp contract(off)
 
@@ -286,38 +289,75 @@ bool fused_table_front_end(hipStream_t s, const TableGeom &geom, int mode, bool 
 // ---- phase-resident stage 1 (k_fused in PHASE mode)
 namespace {
 constexpr uint32_t kPhaseOutputs = 16;
+constexpr uint32_t kPhaseMaxPerm = 8;
 uint32_t phase_tpp(uint32_t l, uint32_t t1)
 {
     const uint32_t jlim = 2 * ((t1 - 1) / 2) + 1;
     return ((jlim + l - 1) / l + 3u) & ~3u;
 }
-// geometry for workgroups of `threads` (256: three per CU; 512: two per CU); the launcher recovers the thread
-// count from step_r (<= 256 <=> 256 threads: a stride above 256 needs l > 256, which phase_geom(256, ..) refuses)
-bool phase_geom(uint32_t threads, uint32_t l, uint32_t m, uint32_t t1, TableGeom *geom, uint32_t tap_regs = 0)
+// the tile of a PHASE workgroup (FusedGeom with TABLE geometry: whole groups of four halo threads either side)
+struct PhaseTile {
+    uint32_t pre_k, own_k;
+};
+PhaseTile phase_tile(uint32_t threads, uint32_t t2, uint32_t pw)
+{
+    const uint32_t pre = ((t2 + 1 + 12) / 13 + 3) / 4 * 4, post = ((38 * pw - 1 + 12) / 13 + 3) / 4 * 4;
+    const uint32_t own = (threads - pre - post) / 4 * 4;
+    return PhaseTile{pre * 13, own * 13};
+}
+uint32_t gcd_u32(uint32_t a, uint32_t b)
+{
+    while (b) {
+        const uint32_t t = a % b;
+        a = b;
+        b = t;
+    }
+    return a;
+}
+// taps per branch a thread's registers hold (TPPM in k_fused)
+uint32_t phase_tap_regs(uint32_t threads, uint32_t t2, uint32_t nq)
+{
+    if (threads == 1024) return 24;
+    if (threads == 512) return 40;
+    if (t2 == 43) return 28;
+    return nq == 1 ? 76u : nq == 2 ? 36u : 20u;
+}
+// geometry for workgroups of `threads` (256: three per CU; 512: two; 1024: one) whose threads hold nq branches each
+bool phase_geom(uint32_t threads, uint32_t nq, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom)
 {
     const uint32_t tile = threads * 13;
-    if (l > threads) return false;
+    if (nq == 1 ? l > threads : (l % nq != 0 || l / nq > threads || l <= threads)) return false;
     if (static_cast<uint64_t>(tile + 4096) * m + l > 0x7fffffffull) return false;  // 32-bit in-tile index math
     TableGeom g{};
     g.l = l;
     g.m = m;
+    g.nq = nq;
     g.jlim = 2 * ((t1 - 1) / 2) + 1;
     const uint32_t per_phase = (g.jlim + l - 1) / l;
-    if (per_phase > (tap_regs ? tap_regs : (threads == 256 ? 76u : 40u))) return false;  // taps a thread's registers hold (TPPM in k_fused)
+    if (per_phase > phase_tap_regs(threads, t2, nq)) return false;
     g.tpp = phase_tpp(l, t1);
-    const uint32_t stride = l * (threads / l);  // outputs between a thread's consecutive outputs
-    if ((tile + stride - 1) / stride > kPhaseOutputs) return false;
+    // outputs between a branch's consecutive outputs: as many whole periods of l as the threads hold (nq = 1), or l
+    const uint32_t stride = nq == 1 ? l * (threads / l) : l;
+    if ((tile + stride - 1) / stride > kPhaseOutputs / nq) return false;
     g.step_r = stride;
     g.step_q = static_cast<uint32_t>(static_cast<uint64_t>(stride) * m / l);  // exact: l divides stride
-    // paired input tile: kPhaseOutputs / 2 regions of off_x f2 entries — a thread's window starts at most
+    // paired input tile: kPhaseOutputs / nq / 2 regions of off_x f2 entries — a branch's window starts at most
     // step_q + 4 entries into its region and is per_phase long
     g.off_x = g.step_q + per_phase + 8;
     if (g.off_x > 1024) return false;  // (the tile loader covers a region in 1024 / threads rounds)
-    g.xt = (kPhaseOutputs / 2) * 2 * g.off_x;
-    // LDS: three 256-thread workgroups (53 KB each) or two 512-thread ones (80 KB) per CU
-    if (g.xt > (threads == 256 ? 13600u : 20480u)) return false;
+    g.xt = (kPhaseOutputs / nq / 2) * 2 * g.off_x;
+    // LDS: three 256-thread workgroups (53 KB each), two 512-thread ones (80 KB) or one of 1024 threads per CU
+    if (g.xt > (threads == 256 ? 13600u : threads == 512 ? 20480u : 36000u)) return false;
     g.jl_a = g.jlim / l;
     g.jl_b = g.jlim % l;
+    // the thread assignment lists: one per distinct tile phase rb = ((tile * own_k - pre_k) * m) mod l
+    const PhaseTile pt = phase_tile(threads, t2, pw);
+    const uint32_t step = static_cast<uint32_t>((static_cast<uint64_t>(pt.own_k) * m) % l);
+    uint32_t nperm = step ? l / gcd_u32(l, step) : 1u;
+    if (nperm > kPhaseMaxPerm) nperm = 1;  // (then the list of tile 0 serves every tile: same results, more bank conflicts)
+    g.nthr = threads;
+    g.nperm = nperm;
+    g.perm_off = (l * g.tpp + 3u) & ~3u;
     if (geom) *geom = g;
     return true;
 }
@@ -326,23 +366,95 @@ bool phase_geom(uint32_t threads, uint32_t l, uint32_t m, uint32_t t1, TableGeom
 bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom)
 {
     if (l < 2 || m == 0 || t1 == 0) return false;
-    // work-rate stages: the standard profile's (256- and 512-thread workgroups), the fast profile's (256)
-    if (t2 == 43 && pw == 4) return phase_geom(256, l, m, t1, geom, 28);  // (the fast profile's instantiations hold 28 taps per branch)
+    // work-rate stages: the standard profile's (256 threads with one, two or four branches each; 512- and 1024-thread
+    // workgroups), the fast profile's (256 threads, one branch)
+    if (t2 == 43 && pw == 4) return phase_geom(256, 1, l, m, t1, t2, pw, geom);
     if (t2 != 37 || pw != 3) return false;
-    return phase_geom(256, l, m, t1, geom) || phase_geom(512, l, m, t1, geom);
+    const char *wide = std::getenv("APTGPU_PHASE_WIDE");  // A/B switch (plan creation): the 512- / 1024-thread forms first
+    if (wide && wide[0] == '1' && (phase_geom(512, 1, l, m, t1, t2, pw, geom) || phase_geom(1024, 1, l, m, t1, t2, pw, geom)))
+        return true;
+    return phase_geom(256, 1, l, m, t1, t2, pw, geom) || phase_geom(256, 2, l, m, t1, t2, pw, geom) ||
+           phase_geom(256, 4, l, m, t1, t2, pw, geom) || phase_geom(512, 1, l, m, t1, t2, pw, geom) ||
+           phase_geom(1024, 1, l, m, t1, t2, pw, geom);
 }
 
-uint32_t fused_phase_table_floats(uint32_t l, uint32_t t1) { return l * phase_tpp(l, t1); }
+uint32_t fused_phase_table_floats(const TableGeom &g) { return g.perm_off + g.nperm * g.nthr; }
 
-void fused_phase_table(uint32_t l, const float *coeff, uint32_t t1, float *table)
+// Thread -> branch-slot lists.  Thread t of a tile computes the outputs u, u + S, ... (S = step_r) for its slot u; the
+// window of slot u starts c(u) = ceil((rb + u m) / l) entries into a region of the paired input tile, and every
+// 8-byte LDS read of stage 1 is "entry c(u) + constant".  An 8-byte wave-read takes max(2, the largest number of its 64
+// lanes whose entries agree mod 32) cycles (tools/ubench/lds_bw.hip: consecutive entries and odd strides 2.17 cycles,
+// stride 2 / 4: 4.0 / 8.0); with slot = thread the starts advance m / l = 3.53 entries per lane at 44 100 Hz and up to
+// five lanes of a wave share a residue (3.9 cycles measured).  The lists below deal the slots of each residue class
+// out over the waves, at most two per wave where the class sizes allow it.  Which thread computes which slot changes
+// nothing else: the tile loader indexes by thread, the results go to R in LDS by slot.
+void fused_phase_table(const TableGeom &g, uint32_t t2, uint32_t pw, const float *coeff, uint32_t t1, float *table)
 {
-    const uint32_t jlim = 2 * ((t1 - 1) / 2) + 1;
-    const uint32_t tpp = phase_tpp(l, t1);
+    const uint32_t l = g.l, tpp = g.tpp;
     for (uint32_t p = 0; p < l; ++p)
         for (uint32_t i = 0; i < tpp; ++i) {
             const uint64_t j = p + static_cast<uint64_t>(i) * l;
-            table[static_cast<size_t>(p) * tpp + i] = j < jlim ? coeff[j] : 0.f;
+            table[static_cast<size_t>(p) * tpp + i] = j < g.jlim ? coeff[j] : 0.f;
         }
+    (void)t1;
+    const PhaseTile pt = phase_tile(g.nthr, t2, pw);
+    const uint32_t nq = g.nq ? g.nq : 1u;
+    const uint32_t S = g.step_r / nq;                  // slots: threads with work
+    const uint32_t NW = (S + 63) / 64;                 // waves with work (the others skip stage 1's arithmetic)
+    const char *ident = std::getenv("APTGPU_PHASE_IDENTITY");  // A/B switch: slot = thread, as until round 4
+    std::vector<uint32_t> list(g.nthr), ident_list(g.nthr);
+    for (uint32_t t = 0; t < g.nthr; ++t) ident_list[t] = t < S ? t : 0xFFFFFFFFu;
+    for (uint32_t r = 0; r < g.nperm; ++r) {
+        const int64_t k0 = static_cast<int64_t>(r) * pt.own_k - static_cast<int64_t>(pt.pre_k);
+        int64_t rb = (k0 * static_cast<int64_t>(g.m)) % static_cast<int64_t>(l);
+        if (rb < 0) rb += l;
+        // window start of slot u's branch q, mod the 32 entry positions of the LDS banks
+        auto res = [&](uint32_t u, uint32_t q) -> uint32_t {
+            return static_cast<uint32_t>((static_cast<uint64_t>(rb) + static_cast<uint64_t>(u + q * S) * g.m + l - 1) / l) & 31u;
+        };
+        // cycles of the wave-reads of one tap under a list: per wave and branch, max(2, largest residue class)
+        auto cost = [&](const std::vector<uint32_t> &ls) -> uint32_t {
+            uint32_t total = 0;
+            for (uint32_t w = 0; w < g.nthr / 64; ++w)
+                for (uint32_t q = 0; q < nq; ++q) {
+                    uint32_t cnt[32] = {0}, mx = 0;
+                    for (uint32_t e = 0; e < 64; ++e)
+                        if (ls[64 * w + e] < S) mx = std::max(mx, ++cnt[res(ls[64 * w + e], q)]);
+                    if (mx) total += std::max(mx, 2u);
+                }
+            return total;
+        };
+        std::vector<std::vector<uint32_t>> cls(32), wave(NW);
+        for (uint32_t u = 0; u < S; ++u) cls[res(u, 0)].push_back(u);
+        std::vector<uint32_t> order(32);
+        for (uint32_t q = 0; q < 32; ++q) order[q] = q;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cls[a].size() > cls[b].size(); });
+        std::vector<std::vector<uint32_t>> cnt(NW, std::vector<uint32_t>(32, 0));
+        std::vector<uint32_t> wmax(NW, 0);
+        for (uint32_t q : order)
+            for (uint32_t u : cls[q]) {
+                uint32_t best = 0;
+                uint64_t best_key = ~0ull;
+                for (uint32_t w = 0; w < NW; ++w) {
+                    if (wave[w].size() >= 64) continue;
+                    const uint32_t k = cnt[w][q], newmax = std::max(wmax[w], k + 1);
+                    const uint32_t harm = newmax > 2 ? newmax - std::max(wmax[w], 2u) : 0u;
+                    const uint64_t key = (static_cast<uint64_t>(harm) << 40) | (static_cast<uint64_t>(k) << 20) | wave[w].size();
+                    if (key < best_key) {
+                        best_key = key;
+                        best = w;
+                    }
+                }
+                wave[best].push_back(u);
+                ++cnt[best][q];
+                wmax[best] = std::max(wmax[best], cnt[best][q]);
+            }
+        for (uint32_t t = 0; t < g.nthr; ++t) list[t] = 0xFFFFFFFFu;
+        for (uint32_t w = 0; w < NW; ++w)
+            for (uint32_t e = 0; e < wave[w].size(); ++e) list[64 * w + e] = wave[w][e];
+        const bool use_ident = (ident && ident[0] == '1') || cost(ident_list) <= cost(list);
+        std::memcpy(table + g.perm_off + static_cast<size_t>(r) * g.nthr, (use_ident ? ident_list : list).data(), g.nthr * sizeof(uint32_t));
+    }
 }
 
 bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, uint32_t t2, uint32_t pw, int mode, bool pcm16,
@@ -353,19 +465,35 @@ bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, uint32_t t2, ui
         for (uint32_t i = 0; i < call.count; ++i)
             if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 1u) return false;
     const FusedLaunch a{s, &call, d_prm, max_w, static_cast<size_t>(geom.xt)};
-    const bool wide = geom.step_r > 256;  // 512-thread workgroups
+    const bool wide = geom.nthr == 512, huge = geom.nthr == 1024;
     if (t2 == 43 && pw == 4) {  // the fast profile's work-rate stages
-        if (wide) return false;
+        if (wide || huge) return false;
         if (mode == kModeFast) pcm16 ? fused_launch_phase_fastp_fast_i16(a) : fused_launch_phase_fastp_fast_f32(a);
         else if (mode == kModeStrict) pcm16 ? fused_launch_phase_fastp_i16(a) : fused_launch_phase_fastp_f32(a);
         else return false;
         return true;
     }
+    if (geom.nq == 2 || geom.nq == 4) {
+        if (wide || huge) return false;
+        const bool four = geom.nq == 4;
+        if (mode == kModeFast) {
+            if (four) pcm16 ? fused_launch_phase4_std_fast_i16(a) : fused_launch_phase4_std_fast_f32(a);
+            else pcm16 ? fused_launch_phase2_std_fast_i16(a) : fused_launch_phase2_std_fast_f32(a);
+        } else if (mode == kModeStrict) {
+            if (four) pcm16 ? fused_launch_phase4_std_i16(a) : fused_launch_phase4_std_f32(a);
+            else pcm16 ? fused_launch_phase2_std_i16(a) : fused_launch_phase2_std_f32(a);
+        } else {
+            return false;
+        }
+        return true;
+    }
     if (mode == kModeFast) {
-        if (wide) pcm16 ? fused_launch_phase512_std_fast_i16(a) : fused_launch_phase512_std_fast_f32(a);
+        if (huge) pcm16 ? fused_launch_phase1024_std_fast_i16(a) : fused_launch_phase1024_std_fast_f32(a);
+        else if (wide) pcm16 ? fused_launch_phase512_std_fast_i16(a) : fused_launch_phase512_std_fast_f32(a);
         else pcm16 ? fused_launch_phase_std_fast_i16(a) : fused_launch_phase_std_fast_f32(a);
     } else if (mode == kModeStrict) {
-        if (wide) pcm16 ? fused_launch_phase512_std_i16(a) : fused_launch_phase512_std_f32(a);
+        if (huge) pcm16 ? fused_launch_phase1024_std_i16(a) : fused_launch_phase1024_std_f32(a);
+        else if (wide) pcm16 ? fused_launch_phase512_std_i16(a) : fused_launch_phase512_std_f32(a);
         else pcm16 ? fused_launch_phase_std_i16(a) : fused_launch_phase_std_f32(a);
     }
     else

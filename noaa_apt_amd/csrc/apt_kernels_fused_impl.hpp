@@ -104,7 +104,7 @@ __host__ __device__ constexpr int branch_phase(int b)  // p_b = c_b*L - b*M
 template <int L, int M, int T1, int T2, int PW, int NTHR, int XB = 4, bool F16TAPS = false>
 struct FusedGeom {
     static constexpr bool TABLE = M <= 0;   // run-time resampling factors (table-driven or phase-resident stage 1)
-    static constexpr bool PHASE = M == -1;  // ... with the taps of a thread's polyphase branch in registers
+    static constexpr bool PHASE = M < 0;    // ... with the taps of a thread's -M polyphase branches in registers
     static constexpr int kFusedThreads = NTHR;
     // threads of L samples in front of / behind the owned ones: T2 + 1 samples of history, 38 PW - 1 of look-ahead;
     // whole groups of four threads where stage 1 is laid out for a tile that starts on a group boundary (TABLE, PHASE);
@@ -239,7 +239,7 @@ __host__ __device__ constexpr bool sync_plus(int j)
 // that walked the tiles with a fixed grid and kept the NEXT tile's input in registers while the stages ran was measured
 // in rounds 2 and 3 and dropped: slower in every mode)
 template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
-__global__ void __launch_bounds__(NTHR, M == -1 ? ((NTHR > 256 ? 2 : (T2 == 43 ? 4 : 3)) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs; the fast profile's: four, <= 128) or two 512-thread (<= 128) workgroups per CU */
+__global__ void __launch_bounds__(NTHR, M < 0 ? ((NTHR > 512 ? 1 : NTHR > 256 ? 2 : (T2 == 43 ? 4 : M == -4 ? 5 : M == -2 ? 4 : 3)) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs; the fast profile's and two branches per thread: four, <= 128; four branches: five, <= 96), two 512-thread or one 1024-thread (<= 128) workgroups per CU */
                                      : M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
                                                /* specialised: as many workgroups as the CU's 160 KB of LDS hold (48 kHz SPLIT: 5, 96 kHz: 3) */
                                                : (FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), MODE == kModeF16Taps>::WGS_PER_CU * NTHR + 255) / 256)
@@ -386,17 +386,26 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     APT_MARK("END tile_prologue");
     float r[L];
     if constexpr (Gm::PHASE) {
-        // ---- stages 0 + 1, taps of the thread's polyphase branch in registers (dsp.rs:252-263):
+        // ---- stages 0 + 1, taps of the thread's polyphase branches in registers (dsp.rs:252-263):
         // k*m - X0*l = v;  x0 - X0 = c = ceil(v / l);  phase p = c*l - v;  output k = sum_i h[p + i*l] * x[x0 + i]
-        constexpr int NB = 16;     // outputs per thread (>= ceil(TILE_K / S): checked by fused_phase_supported)
+        // A thread holds NQ = -M slots u + q S' (q < NQ, S' = S / NQ) of the S consecutive outputs after which the
+        // branches repeat, and computes the NB / NQ outputs (u + q S') + a S of each: NQ = 1 where S = l floor(NTHR / l)
+        // fits the workgroup (44 100 Hz: l = 208), NQ = 2 / 4 where l itself is two / four times too long for one slot
+        // per thread (22 050 Hz: l = 416, 11 025 Hz: l = 832 — until round 5 512- and 1024-thread workgroups at two / one
+        // per CU, and the table-driven stage 1): the same 256-thread kernel at three workgroups per CU for all of them.
+        constexpr int NB = 16;     // outputs per thread (NB / NQ >= ceil(TILE_K / S): checked by fused_phase_supported)
+        constexpr int NQ = -M;     // branches per thread
+        constexpr int NWIN = NB / NQ, NREG = NWIN / 2;  // outputs per branch; regions of the paired tile
+        static_assert(NQ == 1 || NQ == 2 || NQ == 4, "one, two or four branches per thread");
         // taps per branch the registers hold (>= tpp; 128 / 170 VGPRs).  The fast profile's filters are short (639 taps at
         // 48 kHz: 25 per branch at every rate — its transition band is three times the standard profile's): 28 registers,
         // so that its kernels fit four workgroups per CU
-        constexpr int TPPM = NTHR > 256 ? 40 : (T2 == 43 ? 28 : 76);
+        constexpr int TPPM = NTHR > 512 ? 24 : NTHR > 256 ? 40 : (T2 == 43 ? 28 : NQ == 1 ? 76 : NQ == 2 ? 36 : 20);  // (phase_tap_regs in apt_kernels_fused.hip)
         typedef const FusedParams APT_CONST_AS *cprm_tab_ptr;
         const cprm_tab_ptr tp = (cprm_tab_ptr)(prm);
         const uint32_t gl = tp->tab.l, gm_ = tp->tab.m, tpp = tp->tab.tpp;
-        const uint32_t S = tp->tab.step_r, dq = tp->tab.step_q;  // thread stride in outputs; S*m / l input samples
+        const uint32_t S = tp->tab.step_r, dq = tp->tab.step_q;  // stride of a branch's outputs; S*m / l input samples
+        const uint32_t SQ = NQ == 1 ? S : S / static_cast<uint32_t>(NQ);  // slots = threads with work
         const uint32_t ZR = tp->tab.off_x;                        // f2 entries per region of the paired tile
         const uint32_t jl_a = tp->tab.jl_a, jl_b = tp->tab.jl_b;
         const XT *__restrict__ x = static_cast<const XT *>(call.rec[ri].x);
@@ -410,16 +419,29 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         const int64_t xfirst = X0 + (rb ? 1 : 0);
         const int64_t xs0 = xfirst & ~static_cast<int64_t>(3);        // first input sample of the tile
         const uint32_t xrel0 = static_cast<uint32_t>(X0 - xs0);       // -1 (wrapped) only when rb > 0, and then c >= 1
-        // this thread's branch (the same for all its outputs: S*m is a multiple of l)
-        const bool act = static_cast<uint32_t>(tid) < S;
-        const uint32_t v = rb + static_cast<uint32_t>(tid) * gm_;
-        const uint32_t c = (v + gl - 1) / gl;
-        const uint32_t ph = c * gl - v;
-        // The input tile in LDS, PAIRED: outputs 2jj and 2jj+1 of a thread read windows exactly dq samples
+        // this thread's slot u (its branches are the same for all their outputs: S*m is a multiple of l).  Which thread
+        // takes which slot is the host's choice (fused_phase_table: the lists that keep the LDS reads below off each
+        // other's banks; one list per tile phase rb)
+        uint32_t u_slot;
+        {
+            const uint32_t nperm = tp->tab.nperm, perm_off = tp->tab.perm_off;
+            uint32_t r = 0;
+            if (nperm > 1) r = static_cast<uint32_t>(tile % static_cast<int64_t>(nperm));
+            u_slot = reinterpret_cast<const uint32_t *>(tp->table + perm_off)[r * static_cast<uint32_t>(kFusedThreads) + static_cast<uint32_t>(tid)];
+        }
+        const bool act = u_slot < SQ;
+        uint32_t cq[NQ], phq[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const uint32_t v = rb + ((act ? u_slot : 0u) + static_cast<uint32_t>(q) * SQ) * gm_;
+            cq[q] = (v + gl - 1) / gl;
+            phq[q] = cq[q] * gl - v;
+        }
+        // The input tile in LDS, PAIRED: outputs a = 2jj and 2jj+1 of a branch read windows exactly dq samples
         // apart, so region jj holds Z[jj][s] = (x[2jj*dq + s], x[(2jj+1)*dq + s]), s < ZR = dq + window + slack:
         // one 8-byte LDS read then delivers the two samples a packed multiply needs, already in a register
         // pair (two 4-byte reads would be merged by the compiler with their NEIGHBOURS in the window, and
-        // the pairs rebuilt with a v_mov per sample).  The windows' overlap (~10 %) is stored twice.
+        // the pairs rebuilt with a v_mov per sample).  The windows' overlap (~10 % at NQ = 1) is stored twice.
         f2 *Z = reinterpret_cast<f2 *>(lds);
         {
             // every load of the tile issued before the first LDS write (regions x rounds unrolled: a loop
@@ -427,9 +449,46 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             constexpr int ZROUNDS = 1024 / kFusedThreads;  // ceil(ZR / NTHR) at most (fused_phase_supported: ZR <= 1024)
             const XT *xt0 = x + xs0;    // only dereferenced inside [x_lo, x_hi)
             const int x_lo = rel(-xs0), x_hi = rel(n - xs0);
-            XT za[NB / 2][ZROUNDS], zb[NB / 2][ZROUNDS];
+            XT za[NREG][ZROUNDS], zb[NREG][ZROUNDS];
+            if (x_lo <= 0 && x_hi >= static_cast<int>((NWIN - 1) * dq + ZR)) {
+                // interior tile (wave-uniform): every sample exists.  A scalar base per region half, advanced in scalar
+                // registers (the empty asm keeps the steps from being folded into per-lane 64-bit adds, as in load_tile),
+                // plus the lane's 32-bit byte offset — the guarded form below spends ten VALU instructions per sample
+                // on index arithmetic and range tests, 700 per thread and tile at NQ = 1.
+                typedef const char __attribute__((address_space(1))) *gchar_ptr;
+                typedef const XT __attribute__((address_space(1))) *gx_ptr;
+                const uint32_t dqb = dq * static_cast<uint32_t>(sizeof(XT));
 #pragma unroll
-            for (int jj = 0; jj < NB / 2; ++jj) {
+                for (int rr = 0; rr < ZROUNDS; ++rr) {
+                    const uint32_t s_in = static_cast<uint32_t>(tid + rr * kFusedThreads);
+                    const uint32_t voff = s_in * static_cast<uint32_t>(sizeof(XT));
+#pragma unroll
+                    for (int jj = 0; jj < NREG; ++jj) {
+                        za[jj][rr] = XT(0);
+                        zb[jj][rr] = XT(0);
+                    }
+                    if (s_in < ZR) {
+                        // (xt0 is wave-uniform, but the 64-bit division behind it runs on the vector unit)
+                        const uint64_t xa = reinterpret_cast<uint64_t>(xt0);
+                        // (the builtin returns int: through uint32_t, or the low half is sign-extended over the high one)
+                        const uint32_t xa_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(xa))));
+                        const uint32_t xa_hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(xa >> 32))));
+                        const uint64_t xu = static_cast<uint64_t>(xa_lo) | (static_cast<uint64_t>(xa_hi) << 32);
+                        gchar_ptr sb = (gchar_ptr)(xu);
+#pragma unroll
+                        for (int jj = 0; jj < NREG; ++jj) {
+                            za[jj][rr] = *(gx_ptr)(sb + voff);
+                            sb += dqb;
+                            asm volatile("" : "+s"(sb));
+                            zb[jj][rr] = *(gx_ptr)(sb + voff);
+                            sb += dqb;
+                            asm volatile("" : "+s"(sb));
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+            for (int jj = 0; jj < NREG; ++jj) {
 #pragma unroll
                 for (int rr = 0; rr < ZROUNDS; ++rr) {
                     const uint32_t s_in = static_cast<uint32_t>(tid + rr * kFusedThreads);
@@ -439,8 +498,9 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                     zb[jj][rr] = (s_in < ZR && ib >= x_lo && ib < x_hi) ? xt0[ib] : XT(0);
                 }
             }
+            }
 #pragma unroll
-            for (int jj = 0; jj < NB / 2; ++jj) {
+            for (int jj = 0; jj < NREG; ++jj) {
 #pragma unroll
                 for (int rr = 0; rr < ZROUNDS; ++rr) {
                     const uint32_t s_in = static_cast<uint32_t>(tid + rr * kFusedThreads);
@@ -448,90 +508,101 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 }
             }
         }
-        // its taps -> registers (16-byte loads from the L2-resident table; in flight across the barrier)
+        // its taps -> registers (16-byte loads from the L2-resident table; in flight across the barrier).  The branches
+        // are worked through one after the other; with four of them the registers hold two at a time — the taps of
+        // branch q + 2 are requested when branch q is done (all four: 80 registers, three waves per SIMD).
         typedef float f4v __attribute__((ext_vector_type(4)));
-        f4v tq[TPPM / 4];
-        {
-            const f4v *row = reinterpret_cast<const f4v *>(tp->table) + static_cast<size_t>(act ? ph : 0u) * (tpp / 4);
+        constexpr int NTB = NQ > 2 ? 2 : NQ;
+        f4v tq[NTB][TPPM / 4];
+        auto load_taps = [&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            const f4v *row = reinterpret_cast<const f4v *>(tp->table) + static_cast<size_t>(act ? phq[q] : 0u) * (tpp / 4);
 #pragma unroll
             for (int e = 0; e < TPPM / 4; ++e)
-                tq[e] = (static_cast<uint32_t>(4 * e) < tpp) ? row[e] : (f4v){0.f, 0.f, 0.f, 0.f};
-        }
+                tq[q % NTB][e] = (static_cast<uint32_t>(4 * e) < tpp) ? row[e] : (f4v){0.f, 0.f, 0.f, 0.f};
+        };
+        static_for<0, NTB>(load_taps);
         __syncthreads();
         if constexpr (APT_FUSED_STOP == 1) return;
-        f2 acc[NB / 2];
+        f2 acc[NQ][NREG];  // branch q, output pair (2jj, 2jj+1)
 #pragma unroll
-        for (int jj = 0; jj < NB / 2; ++jj) acc[jj] = (f2){0.f, 0.f};
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int jj = 0; jj < NREG; ++jj) acc[q][jj] = (f2){0.f, 0.f};
         if (act) {
-            const f2 *zw[NB / 2];  // window of the output pair (2jj, 2jj+1)
+            static_for<0, NQ>([&](auto qq) {
+            constexpr int q = decltype(qq)::value;
+            const f2 *zw[NREG];  // window of the branch's output pair (2jj, 2jj+1)
 #pragma unroll
-            for (int jj = 0; jj < NB / 2; ++jj) zw[jj] = Z + jj * ZR + (xrel0 + c);
-            auto tap = [&](auto ii, float t) {
+            for (int jj = 0; jj < NREG; ++jj) zw[jj] = Z + jj * ZR + (xrel0 + cq[q]);
+            // Software pipeline over the taps: the 8-byte reads of tap i + 1 are issued before the arithmetic of tap i
+            // (until round 5 a chunk's reads were issued and waited for in place: one exposed LDS latency per two taps, at
+            // three waves per SIMD).  Two buffers of NREG pairs (NQ = 1: the same registers a two-tap chunk held).
+            f2 xb[2][NREG];
+            auto issue = [&](auto ii) {
                 constexpr int i = decltype(ii)::value;
-                f2 xp[NB / 2];
 #pragma unroll
-                for (int jj = 0; jj < NB / 2; ++jj) xp[jj] = zw[jj][i];
+                for (int jj = 0; jj < NREG; ++jj) xb[i & 1][jj] = zw[jj][i];
+            };
+            auto tap = [&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                const f4v q4 = tq[q % NTB][i / 4];
+                const float t = (i & 3) == 0 ? q4.x : (i & 3) == 1 ? q4.y : (i & 3) == 2 ? q4.z : q4.w;
                 if constexpr (FAST) {
 #pragma unroll
-                    for (int jj = 0; jj < NB / 2; ++jj) acc[jj] = __builtin_elementwise_fma((f2){t, t}, xp[jj], acc[jj]);
+                    for (int jj = 0; jj < NREG; ++jj) acc[q][jj] = __builtin_elementwise_fma((f2){t, t}, xb[i & 1][jj], acc[q][jj]);
                 } else {
-                    f2 pr[NB / 2];
+                    f2 pr[NREG];
 #pragma unroll
-                    for (int jj = 0; jj < NB / 2; ++jj) pr[jj] = (f2){t, t} * xp[jj];
+                    for (int jj = 0; jj < NREG; ++jj) pr[jj] = (f2){t, t} * xb[i & 1][jj];
 #pragma unroll
-                    for (int jj = 0; jj < NB / 2; ++jj) acc[jj] = acc[jj] + pr[jj];
+                    for (int jj = 0; jj < NREG; ++jj) acc[q][jj] = acc[q][jj] + pr[jj];
                 }
             };
             // taps 0 .. jl_a - 1 for every branch, tap jl_a for the branches p < jl_b (the reference's
-            // `p + i*l < jlim`): the tap count is wave-uniform up to that last, lane-predicated one.  Chunks of
-            // CHK taps under one uniform test, so that the LDS reads of a chunk's later taps are in flight under
-            // the arithmetic of its earlier ones.
-            const bool extra = ph < jl_b;
-            auto tap_of = [&](auto ii) -> float {
-                constexpr int i = decltype(ii)::value;
-                const f4v q4 = tq[i / 4];
-                return (i & 3) == 0 ? q4.x : (i & 3) == 1 ? q4.y : (i & 3) == 2 ? q4.z : q4.w;
-            };
-            constexpr int CHK = 2;
+            // `p + i*l < jlim`): the tap count is wave-uniform up to that last, lane-predicated one.
             bool go = true;  // (wave-uniform)
-            static_for<0, TPPM / CHK>([&](auto ee) {
-                constexpr int i0 = decltype(ee)::value * CHK;
-                go = go && static_cast<uint32_t>(i0 + CHK) <= jl_a;
+            issue(std::integral_constant<int, 0>{});
+            static_for<0, TPPM>([&](auto ee) {
+                constexpr int i0 = decltype(ee)::value;
+                go = go && static_cast<uint32_t>(i0 + 1) <= jl_a;
                 if (go) {
-                    static_for<0, CHK>([&](auto tt) {
-                        using I = std::integral_constant<int, i0 + decltype(tt)::value>;
-                        tap(I{}, tap_of(I{}));
-                    });
+                    // (a read past the branch's last tap stays inside its region's slack or the next region: never used)
+                    if constexpr (i0 + 1 < TPPM) issue(std::integral_constant<int, i0 + 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    tap(ee);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             });
-            // the last taps (fewer than CHK whole ones, then the predicated one): a run-time loop, its taps
-            // read from the table again
-            {
-                const float *rowf = tp->table + static_cast<size_t>(ph) * tpp;
-#pragma unroll 1
-                for (uint32_t i = jl_a - jl_a % CHK; i <= jl_a; ++i) {
-                    if (i < jl_a || extra) {
-                        const float t = rowf[i];
-                        f2 xp[NB / 2];
+            // the predicated last tap, read from the table again (a run-time index)
+            if (phq[q] < jl_b) {
+                const float t = tp->table[static_cast<size_t>(phq[q]) * tpp + jl_a];
+                f2 xp[NREG];
 #pragma unroll
-                        for (int jj = 0; jj < NB / 2; ++jj) xp[jj] = zw[jj][i];
+                for (int jj = 0; jj < NREG; ++jj) xp[jj] = zw[jj][jl_a];
 #pragma unroll
-                        for (int jj = 0; jj < NB / 2; ++jj) {
-                            if constexpr (FAST) acc[jj] = __builtin_elementwise_fma((f2){t, t}, xp[jj], acc[jj]);
-                            else acc[jj] = acc[jj] + (f2){t, t} * xp[jj];
-                        }
-                    }
+                for (int jj = 0; jj < NREG; ++jj) {
+                    if constexpr (FAST) acc[q][jj] = __builtin_elementwise_fma((f2){t, t}, xp[jj], acc[q][jj]);
+                    else acc[q][jj] = acc[q][jj] + (f2){t, t} * xp[jj];
                 }
             }
+            if constexpr (q + NTB < NQ) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_taps(std::integral_constant<int, q + NTB>{});
+            }
+            });
         }
         __syncthreads();  // everyone is done with the input tile: R may land on it
         if (act) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int idx = tid + j * static_cast<int>(S);
-                const float val = (j & 1) ? acc[j / 2].y : acc[j / 2].x;
-                // (outputs before the recording or at / past its end: zero)
-                if (idx < Gm::TILE_K) P[idx] = (idx >= k_lo && idx < k_hi) ? val : 0.f;
+            for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+                for (int a = 0; a < NWIN; ++a) {
+                    const int idx = static_cast<int>(u_slot + static_cast<uint32_t>(q) * SQ) + a * static_cast<int>(S);
+                    const float val = (a & 1) ? acc[q][a / 2].y : acc[q][a / 2].x;
+                    // (outputs before the recording or at / past its end: zero)
+                    if (idx < Gm::TILE_K) P[idx] = (idx >= k_lo && idx < k_hi) ? val : 0.f;
+                }
             }
         }
         __syncthreads();

@@ -96,6 +96,20 @@ void fused_launch_phase512_std_f32(const FusedLaunch &a);
 void fused_launch_phase512_std_i16(const FusedLaunch &a);
 void fused_launch_phase512_std_fast_f32(const FusedLaunch &a);
 void fused_launch_phase512_std_fast_i16(const FusedLaunch &a);
+// ... 256-thread workgroups whose threads hold two / four branches (256 < l <= 512: 22 050 Hz; 512 < l <= 1024: 11 025 Hz)
+void fused_launch_phase2_std_f32(const FusedLaunch &a);
+void fused_launch_phase2_std_i16(const FusedLaunch &a);
+void fused_launch_phase2_std_fast_f32(const FusedLaunch &a);
+void fused_launch_phase2_std_fast_i16(const FusedLaunch &a);
+void fused_launch_phase4_std_f32(const FusedLaunch &a);
+void fused_launch_phase4_std_i16(const FusedLaunch &a);
+void fused_launch_phase4_std_fast_f32(const FusedLaunch &a);
+void fused_launch_phase4_std_fast_i16(const FusedLaunch &a);
+// ... 1024-thread workgroups (512 < l <= 1024), one branch per thread
+void fused_launch_phase1024_std_f32(const FusedLaunch &a);
+void fused_launch_phase1024_std_i16(const FusedLaunch &a);
+void fused_launch_phase1024_std_fast_f32(const FusedLaunch &a);
+void fused_launch_phase1024_std_fast_i16(const FusedLaunch &a);
 #ifdef APT_WITH_PROBES
 // timing probes (make PROBES=1; APTGPU_PROBE_STOP=1..7; sources under tools/probes/): the fast 48 kHz f32
 // kernel cut off after a stage (1..5)

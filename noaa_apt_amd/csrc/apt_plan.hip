@@ -311,9 +311,11 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     }
     if (plan->fused == 2 || plan->fused == 3 || plan->fused == 4) {
         const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
-        Signal tab(static_cast<size_t>(plan->fused == 4 ? gpu::fused_phase_table_floats(plan->l, t1)
+        Signal tab(static_cast<size_t>(plan->fused == 4 ? gpu::fused_phase_table_floats(plan->table_geom)
                                                         : gpu::fused_any_table_floats(plan->l, t1)) + 16, 0.f);
-        if (plan->fused == 4) gpu::fused_phase_table(plan->l, plan->taps_resample.data(), t1, tab.data());
+        if (plan->fused == 4)
+            gpu::fused_phase_table(plan->table_geom, static_cast<uint32_t>(plan->taps_lowpass.size()), plan->pw,
+                                   plan->taps_resample.data(), t1, tab.data());
         else gpu::fused_any_table(plan->l, plan->taps_resample.data(), t1, tab.data());
         upload(plan->d_taps_any, tab);
         Signal h2p(2 * (plan->taps_lowpass.size() + 1) + 16, 0.f);

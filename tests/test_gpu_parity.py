@@ -294,6 +294,7 @@ def test_fused_specialisations_are_used(ctx):
     and the other rates whose tap table and input tile fit run the table-driven stage 1 in front of
     the specialised work-rate stages (3); 44 100 Hz the phase-resident stage 1 in front of the same stages
     (4); the rest the run-time fused kernel (2); l == 1 the unfused kernels (0)."""
+    apt.cache_clear()  # (a session another test built under an APTGPU_* switch would answer for its own kernel path)
     for rate, profile, want in ((48000, "standard", 1), (96000, "standard", 1), (44100, "standard", 4),
                                 (11025, "standard", 3), (8000, "standard", 3), (22050, "standard", 4),
                                 (48000, "fast", 4), (48000, "slow", 1), (96000, "fast", 2), (16000, "fast", 4),
@@ -362,6 +363,7 @@ def test_table_stage1_long_ragged_batched_and_pcm16(oracle):
 PHASE_CASES = [  # (rate, seconds): rates k_fused's phase-resident stage 1 (fused == 4) can serve
     (44100, 40), (44100, 11), (32000, 20), (20800, 15), (16000, 20), (24000, 15), (40000, 12), (15600, 20),
     (22050, 40), (22050, 11),  # l = 416: 512-thread workgroups
+    (11025, 40), (11025, 11),  # l = 832: 1024-thread workgroups
 ]
 
 
@@ -369,11 +371,31 @@ PHASE_CASES = [  # (rate, seconds): rates k_fused's phase-resident stage 1 (fuse
 @pytest.mark.parametrize("sync", [True, False])
 def test_phase_stage1_bitexact(oracle, monkeypatch, rate, seconds, sync):
     monkeypatch.setenv("APTGPU_PHASE_FIRST", "1")
+    apt.cache_clear()
     x = synth_apt(rate, seconds, seed=rate % 89 + seconds)
     want = oracle.decode(x, rate, sync)
     got, st = apt.decode(apt.Context(device=0), apt.Settings(), x, apt.Rate.hz(rate), sync, return_stats=True)
     assert st.fused == 4, (rate, st.l, st.m, st.n_resample_taps)
     assert_bitexact(got, want, f"phase stage 1 {rate} sync={sync}")
+
+
+@pytest.mark.parametrize("rate,seconds", [(22050, 40), (22050, 11), (11025, 40), (11025, 11)])
+@pytest.mark.parametrize("identity", [False, True])
+def test_phase_stage1_wide_workgroups_bitexact(oracle, monkeypatch, rate, seconds, identity):
+    """The 512- / 1024-thread forms of the phase-resident stage 1 (one branch per thread; APTGPU_PHASE_WIDE=1 — the
+    default for these rates is 256 threads with two / four branches each), with the host's thread assignment lists and
+    with slot = thread."""
+    monkeypatch.setenv("APTGPU_PHASE_FIRST", "1")
+    monkeypatch.setenv("APTGPU_PHASE_WIDE", "1")
+    if identity:
+        monkeypatch.setenv("APTGPU_PHASE_IDENTITY", "1")
+    apt.cache_clear()
+    x = synth_apt(rate, seconds, seed=rate % 89 + seconds)
+    want = oracle.decode(x, rate, True)
+    got, st = apt.decode(apt.Context(device=0), apt.Settings(), x, apt.Rate.hz(rate), True, return_stats=True)
+    apt.cache_clear()
+    assert st.fused == 4, (rate, st.l, st.m, st.n_resample_taps)
+    assert_bitexact(got, want, f"phase stage 1 (wide) {rate}")
 
 
 def test_phase_stage1_long_ragged_batched_and_pcm16(oracle):
