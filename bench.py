@@ -577,7 +577,7 @@ def main():
         fast_leg = None
         if args.mode == "strict" and not args.no_extras and not args.no_sync and rank == 0:
             planf = apt.Plan(settings, rate, True, max_samples=n, max_batch=B, device=local_rank, mode=apt.MODE_FAST)
-            if planf.info.fused in (1, 3):
+            if planf.info.fused in (1, 3, 4):
                 def fstep(j):
                     planf.decode_device(sigs[j % n_inputs], nn, out, caps)
                 for j in range(24):

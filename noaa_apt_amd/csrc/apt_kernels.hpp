@@ -147,6 +147,14 @@ struct TableGeom {
     // float offset `perm_off` of the table buffer, list (tile % nperm) for a tile; an entry >= step_r marks an idle thread
     uint32_t nthr, perm_off, nperm;
     uint32_t nq;               // PHASE mode: branches per thread (1, 2, 4); step_r / nq threads of a workgroup have work
+    // PHASE mode, exact != 0 (the tile phases repeat with a period nperm = 1 << perm_shift <= 8): list (tile % nperm) is
+    // built for that tile's phase, and everything a tile derives from its index by division is tabulated — per phase r the
+    // first input sample's quotient x0r[r] and remainder rbr[r] (tile = nperm t + r: X0 = x0r[r] + t xd), per thread the
+    // window start and polyphase branch of each of its nq slots, packed (c | p << 16) at float offset cp_off
+    // ([nperm][nthr][nq] uint32).  exact == 0: one list serves every tile and the kernel divides.
+    uint32_t exact, perm_shift, cp_off, xd;
+    int32_t x0r[8];
+    uint32_t rbr[8];
 };
 struct FusedParams {
     const float *hs;        // stage-1 table: tap pairs (fused_branch_taps), or the fp16 table

@@ -354,10 +354,23 @@ bool phase_geom(uint32_t threads, uint32_t nq, uint32_t l, uint32_t m, uint32_t 
     const PhaseTile pt = phase_tile(threads, t2, pw);
     const uint32_t step = static_cast<uint32_t>((static_cast<uint64_t>(pt.own_k) * m) % l);
     uint32_t nperm = step ? l / gcd_u32(l, step) : 1u;
-    if (nperm > kPhaseMaxPerm) nperm = 1;  // (then the list of tile 0 serves every tile: same results, more bank conflicts)
+    g.exact = (nperm <= kPhaseMaxPerm && (nperm & (nperm - 1)) == 0) ? 1u : 0u;
+    if (!g.exact) nperm = 1;  // (then the list of tile 0 serves every tile: same results, more bank conflicts, divisions in the kernel)
     g.nthr = threads;
     g.nperm = nperm;
     g.perm_off = (l * g.tpp + 3u) & ~3u;
+    g.cp_off = (g.perm_off + nperm * threads + 3u) & ~3u;
+    for (g.perm_shift = 0; (1u << g.perm_shift) < nperm; ++g.perm_shift) {}
+    if (g.exact) {
+        g.xd = static_cast<uint32_t>(static_cast<uint64_t>(nperm) * pt.own_k * m / l);  // exact: the period's definition
+        for (uint32_t r = 0; r < nperm; ++r) {
+            const int64_t km = (static_cast<int64_t>(r) * pt.own_k - static_cast<int64_t>(pt.pre_k)) * static_cast<int64_t>(m);
+            int64_t x0 = km / static_cast<int64_t>(l);
+            if (x0 * static_cast<int64_t>(l) > km) --x0;  // floor
+            g.x0r[r] = static_cast<int32_t>(x0);
+            g.rbr[r] = static_cast<uint32_t>(km - x0 * static_cast<int64_t>(l));
+        }
+    }
     if (geom) *geom = g;
     return true;
 }
@@ -378,15 +391,16 @@ bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uin
            phase_geom(1024, 1, l, m, t1, t2, pw, geom);
 }
 
-uint32_t fused_phase_table_floats(const TableGeom &g) { return g.perm_off + g.nperm * g.nthr; }
+uint32_t fused_phase_table_floats(const TableGeom &g) { return g.cp_off + g.nperm * g.nthr * (g.nq ? g.nq : 1u) + 80u; }  // (+ a row of slack: the tap loads are not bounded by tpp)
 
 // Thread -> branch-slot lists.  Thread t of a tile computes the outputs u, u + S, ... (S = step_r) for its slot u; the
 // window of slot u starts c(u) = ceil((rb + u m) / l) entries into a region of the paired input tile, and every
-// 8-byte LDS read of stage 1 is "entry c(u) + constant".  An 8-byte wave-read takes max(2, the largest number of its 64
-// lanes whose entries agree mod 32) cycles (tools/ubench/lds_bw.hip: consecutive entries and odd strides 2.17 cycles,
-// stride 2 / 4: 4.0 / 8.0); with slot = thread the starts advance m / l = 3.53 entries per lane at 44 100 Hz and up to
-// five lanes of a wave share a residue (3.9 cycles measured).  The lists below deal the slots of each residue class
-// out over the waves, at most two per wave where the class sizes allow it.  Which thread computes which slot changes
+// 8-byte LDS read of stage 1 is "entry c(u) + constant".  An 8-byte wave-read takes two cycles when the entries of each
+// of its half-waves (lanes 0-31, 32-63) are distinct mod 32 — in any order, at any multiple of 32 — and half a cycle
+// more per extra pass a half-wave needs (tools/ubench/lds_pat.hip, profiles/r05_ubench_lds_pat.txt: one pair 2.5, a pair
+// in both halves 3.0); with slot = thread the starts advance m / l = 3.53 entries per lane at 44 100 Hz and up to
+// four lanes of a half-wave share a residue (4.5 cycles measured).  The lists below deal the slots out over the
+// half-waves so that as few of them as the residue class sizes allow need extra passes, for all of a thread's branches.  Which thread computes which slot changes
 // nothing else: the tile loader indexes by thread, the results go to R in LDS by slot.
 void fused_phase_table(const TableGeom &g, uint32_t t2, uint32_t pw, const float *coeff, uint32_t t1, float *table)
 {
@@ -400,7 +414,7 @@ void fused_phase_table(const TableGeom &g, uint32_t t2, uint32_t pw, const float
     const PhaseTile pt = phase_tile(g.nthr, t2, pw);
     const uint32_t nq = g.nq ? g.nq : 1u;
     const uint32_t S = g.step_r / nq;                  // slots: threads with work
-    const uint32_t NW = (S + 63) / 64;                 // waves with work (the others skip stage 1's arithmetic)
+    const uint32_t NH = 2 * ((S + 63) / 64);           // half-waves of the waves with work (the other waves skip stage 1's arithmetic)
     const char *ident = std::getenv("APTGPU_PHASE_IDENTITY");  // A/B switch: slot = thread, as until round 4
     std::vector<uint32_t> list(g.nthr), ident_list(g.nthr);
     for (uint32_t t = 0; t < g.nthr; ++t) ident_list[t] = t < S ? t : 0xFFFFFFFFu;
@@ -408,52 +422,99 @@ void fused_phase_table(const TableGeom &g, uint32_t t2, uint32_t pw, const float
         const int64_t k0 = static_cast<int64_t>(r) * pt.own_k - static_cast<int64_t>(pt.pre_k);
         int64_t rb = (k0 * static_cast<int64_t>(g.m)) % static_cast<int64_t>(l);
         if (rb < 0) rb += l;
-        // window start of slot u's branch q, mod the 32 entry positions of the LDS banks
-        auto res = [&](uint32_t u, uint32_t q) -> uint32_t {
-            return static_cast<uint32_t>((static_cast<uint64_t>(rb) + static_cast<uint64_t>(u + q * S) * g.m + l - 1) / l) & 31u;
+        // window start of slot u's branch q: its entry in a region, and that mod the 32 entry positions of the LDS banks
+        auto ent = [&](uint32_t u, uint32_t q) -> uint32_t {
+            return static_cast<uint32_t>((static_cast<uint64_t>(rb) + static_cast<uint64_t>(u + q * S) * g.m + l - 1) / l);
         };
-        // cycles of the wave-reads of one tap under a list: per wave and branch, max(2, largest residue class)
+        auto res = [&](uint32_t u, uint32_t q) -> uint32_t { return ent(u, q) & 31u; };
+        // distinct entries among `have` (slots of one half-wave) that share the bank position of slot u's branch q and
+        // differ from it (lanes that read the SAME entry are served together)
+        auto rivals = [&](const std::vector<uint32_t> &have, uint32_t u, uint32_t q) -> uint32_t {
+            const uint32_t e = ent(u, q);
+            uint32_t n = 0;
+            for (size_t i = 0; i < have.size(); ++i) {
+                const uint32_t o = ent(have[i], q);
+                if (o == e) return 0;  // u rides along with that lane
+                if (((o ^ e) & 31u) != 0) continue;
+                bool seen = false;
+                for (size_t j = 0; j < i && !seen; ++j) seen = ent(have[j], q) == o;
+                n += seen ? 0 : 1;
+            }
+            return n;
+        };
+        // passes a half-wave's read of branch q takes beyond the first: (most distinct entries on one bank position) - 1
+        auto extra_of = [&](const std::vector<uint32_t> &have, uint32_t q) -> uint32_t {
+            uint32_t mx = 0;
+            for (uint32_t p = 0; p < 32; ++p) {
+                std::vector<uint32_t> es;
+                for (uint32_t u : have)
+                    if (res(u, q) == p && std::find(es.begin(), es.end(), ent(u, q)) == es.end()) es.push_back(ent(u, q));
+                mx = std::max<uint32_t>(mx, static_cast<uint32_t>(es.size()));
+            }
+            return mx ? mx - 1 : 0;
+        };
         auto cost = [&](const std::vector<uint32_t> &ls) -> uint32_t {
             uint32_t total = 0;
-            for (uint32_t w = 0; w < g.nthr / 64; ++w)
-                for (uint32_t q = 0; q < nq; ++q) {
-                    uint32_t cnt[32] = {0}, mx = 0;
-                    for (uint32_t e = 0; e < 64; ++e)
-                        if (ls[64 * w + e] < S) mx = std::max(mx, ++cnt[res(ls[64 * w + e], q)]);
-                    if (mx) total += std::max(mx, 2u);
-                }
+            for (uint32_t h = 0; h < g.nthr / 32; ++h) {
+                std::vector<uint32_t> have;
+                for (uint32_t e = 0; e < 32; ++e)
+                    if (ls[32 * h + e] < S) have.push_back(ls[32 * h + e]);
+                for (uint32_t q = 0; q < nq; ++q) total += extra_of(have, q);
+            }
             return total;
         };
-        std::vector<std::vector<uint32_t>> cls(32), wave(NW);
-        for (uint32_t u = 0; u < S; ++u) cls[res(u, 0)].push_back(u);
-        std::vector<uint32_t> order(32);
-        for (uint32_t q = 0; q < 32; ++q) order[q] = q;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cls[a].size() > cls[b].size(); });
-        std::vector<std::vector<uint32_t>> cnt(NW, std::vector<uint32_t>(32, 0));
-        std::vector<uint32_t> wmax(NW, 0);
-        for (uint32_t q : order)
-            for (uint32_t u : cls[q]) {
-                uint32_t best = 0;
-                uint64_t best_key = ~0ull;
-                for (uint32_t w = 0; w < NW; ++w) {
-                    if (wave[w].size() >= 64) continue;
-                    const uint32_t k = cnt[w][q], newmax = std::max(wmax[w], k + 1);
-                    const uint32_t harm = newmax > 2 ? newmax - std::max(wmax[w], 2u) : 0u;
-                    const uint64_t key = (static_cast<uint64_t>(harm) << 40) | (static_cast<uint64_t>(k) << 20) | wave[w].size();
-                    if (key < best_key) {
-                        best_key = key;
-                        best = w;
-                    }
+        // greedy: slots of the largest residue classes (of branch 0) first, each to the half-wave where it adds the
+        // fewest extra passes over all its branches; among equals, to the one where it meets the fewest rivals, then
+        // to the emptiest
+        std::vector<uint32_t> order(S);
+        std::vector<uint32_t> csize(32, 0);
+        for (uint32_t u = 0; u < S; ++u) ++csize[res(u, 0)];
+        for (uint32_t u = 0; u < S; ++u) order[u] = u;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return csize[res(a, 0)] > csize[res(b, 0)]; });
+        std::vector<std::vector<uint32_t>> half(NH);
+        std::vector<uint32_t> hextra(static_cast<size_t>(NH) * nq, 0);
+        for (uint32_t u : order) {
+            uint32_t best = 0;
+            uint64_t best_key = ~0ull;
+            for (uint32_t h = 0; h < NH; ++h) {
+                if (half[h].size() >= 32) continue;
+                uint32_t add = 0, mult = 0;
+                for (uint32_t q = 0; q < nq; ++q) {
+                    const uint32_t k = rivals(half[h], u, q);  // u would be entry number k + 1 on its bank position
+                    if (k > hextra[static_cast<size_t>(h) * nq + q]) add += k - hextra[static_cast<size_t>(h) * nq + q];
+                    mult += k;
                 }
-                wave[best].push_back(u);
-                ++cnt[best][q];
-                wmax[best] = std::max(wmax[best], cnt[best][q]);
+                const uint64_t key = (static_cast<uint64_t>(add) << 40) | (static_cast<uint64_t>(mult) << 20) | half[h].size();
+                if (key < best_key) {
+                    best_key = key;
+                    best = h;
+                }
             }
+            for (uint32_t q = 0; q < nq; ++q) {
+                uint32_t &hx = hextra[static_cast<size_t>(best) * nq + q];
+                hx = std::max(hx, rivals(half[best], u, q));
+            }
+            half[best].push_back(u);
+        }
         for (uint32_t t = 0; t < g.nthr; ++t) list[t] = 0xFFFFFFFFu;
-        for (uint32_t w = 0; w < NW; ++w)
-            for (uint32_t e = 0; e < wave[w].size(); ++e) list[64 * w + e] = wave[w][e];
+        for (uint32_t h = 0; h < NH; ++h)
+            for (uint32_t e = 0; e < half[h].size(); ++e) list[32 * h + e] = half[h][e];
         const bool use_ident = (ident && ident[0] == '1') || cost(ident_list) <= cost(list);
-        std::memcpy(table + g.perm_off + static_cast<size_t>(r) * g.nthr, (use_ident ? ident_list : list).data(), g.nthr * sizeof(uint32_t));
+        if (const char *dbg = std::getenv("APTGPU_PHASE_LIST_DEBUG"); dbg && dbg[0] == '1')
+            std::fprintf(stderr, "aptgpu: phase lists l=%u m=%u nq=%u threads=%u rb=%lld: extra passes per tap %u (slot = thread: %u)%s\n", l, g.m,
+                         nq, g.nthr, static_cast<long long>(rb), cost(list), cost(ident_list), use_ident ? " -> slot = thread" : "");
+        const std::vector<uint32_t> &chosen = use_ident ? ident_list : list;
+        std::memcpy(table + g.perm_off + static_cast<size_t>(r) * g.nthr, chosen.data(), g.nthr * sizeof(uint32_t));
+        // window start and branch of every slot of every thread (the kernel reads them when g.exact)
+        std::vector<uint32_t> cp(static_cast<size_t>(g.nthr) * nq, 0u);
+        for (uint32_t t = 0; t < g.nthr; ++t)
+            for (uint32_t q = 0; q < nq; ++q) {
+                const uint32_t u = chosen[t] < S ? chosen[t] : 0u;
+                const uint64_t v = static_cast<uint64_t>(rb) + static_cast<uint64_t>(u + q * S) * g.m;
+                const uint64_t c = (v + l - 1) / l, ph = c * l - v;
+                cp[static_cast<size_t>(t) * nq + q] = static_cast<uint32_t>(c) | (static_cast<uint32_t>(ph) << 16);
+            }
+        std::memcpy(table + g.cp_off + static_cast<size_t>(r) * g.nthr * nq, cp.data(), cp.size() * sizeof(uint32_t));
     }
 }
 

@@ -412,30 +412,56 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         const int64_t n = static_cast<int64_t>(call.rec[ri].n);
         // The tile starts at work sample k0, which is negative in tile 0: the samples before the recording
         // read as zero (like those at or past its end), the outputs before it are zeroed afterwards.
-        const int64_t kbm = k0 * static_cast<int64_t>(gm_);           // k0*m = X0*l + rb, 0 <= rb < l
-        int64_t X0 = kbm / static_cast<int64_t>(gl);
-        if (X0 * static_cast<int64_t>(gl) > kbm) --X0;                // floor
-        const uint32_t rb = static_cast<uint32_t>(kbm - X0 * static_cast<int64_t>(gl));
+        // k0*m = X0*l + rb, 0 <= rb < l: tabulated per tile phase where the phases repeat (TableGeom::exact — every rate
+        // recordings come in), a 64-bit division on the vector unit otherwise
+        const uint32_t exact = tp->tab.exact;
+        int64_t X0;
+        uint32_t rb, rsel = 0;
+        if (exact) {
+            const uint32_t sh = tp->tab.perm_shift;
+            rsel = static_cast<uint32_t>(tile) & ((1u << sh) - 1u);
+            const uint32_t t1 = static_cast<uint32_t>(tile) >> sh;
+            X0 = static_cast<int64_t>(tp->tab.x0r[rsel]) + static_cast<int64_t>(static_cast<uint64_t>(t1) * tp->tab.xd);
+            rb = tp->tab.rbr[rsel];
+        } else {
+            const int64_t kbm = k0 * static_cast<int64_t>(gm_);
+            X0 = kbm / static_cast<int64_t>(gl);
+            if (X0 * static_cast<int64_t>(gl) > kbm) --X0;                // floor
+            rb = static_cast<uint32_t>(kbm - X0 * static_cast<int64_t>(gl));
+        }
         const int64_t xfirst = X0 + (rb ? 1 : 0);
         const int64_t xs0 = xfirst & ~static_cast<int64_t>(3);        // first input sample of the tile
         const uint32_t xrel0 = static_cast<uint32_t>(X0 - xs0);       // -1 (wrapped) only when rb > 0, and then c >= 1
         // this thread's slot u (its branches are the same for all their outputs: S*m is a multiple of l).  Which thread
         // takes which slot is the host's choice (fused_phase_table: the lists that keep the LDS reads below off each
-        // other's banks; one list per tile phase rb)
-        uint32_t u_slot;
-        {
-            const uint32_t nperm = tp->tab.nperm, perm_off = tp->tab.perm_off;
-            uint32_t r = 0;
-            if (nperm > 1) r = static_cast<uint32_t>(tile % static_cast<int64_t>(nperm));
-            u_slot = reinterpret_cast<const uint32_t *>(tp->table + perm_off)[r * static_cast<uint32_t>(kFusedThreads) + static_cast<uint32_t>(tid)];
-        }
+        // other's banks; one list per tile phase rb), and where the lists are exact the window start c and the branch p
+        // of each of its slots come with it
+        const uint32_t lidx = rsel * static_cast<uint32_t>(kFusedThreads) + static_cast<uint32_t>(tid);
+        const uint32_t u_slot = reinterpret_cast<const uint32_t *>(tp->table + tp->tab.perm_off)[lidx];
         const bool act = u_slot < SQ;
         uint32_t cq[NQ], phq[NQ];
+        if (exact) {
+            typedef uint32_t uq __attribute__((ext_vector_type(NQ)));
+            uint32_t cpv[NQ];
+            if constexpr (NQ == 1) {
+                cpv[0] = reinterpret_cast<const uint32_t *>(tp->table + tp->tab.cp_off)[lidx];
+            } else {
+                const uq v = reinterpret_cast<const uq *>(tp->table + tp->tab.cp_off)[lidx];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const uint32_t v = rb + ((act ? u_slot : 0u) + static_cast<uint32_t>(q) * SQ) * gm_;
-            cq[q] = (v + gl - 1) / gl;
-            phq[q] = cq[q] * gl - v;
+                for (int q = 0; q < NQ; ++q) cpv[q] = v[q];
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                cq[q] = cpv[q] & 0xFFFFu;
+                phq[q] = cpv[q] >> 16;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const uint32_t v = rb + ((act ? u_slot : 0u) + static_cast<uint32_t>(q) * SQ) * gm_;
+                cq[q] = (v + gl - 1) / gl;
+                phq[q] = cq[q] * gl - v;
+            }
         }
         // The input tile in LDS, PAIRED: outputs a = 2jj and 2jj+1 of a branch read windows exactly dq samples
         // apart, so region jj holds Z[jj][s] = (x[2jj*dq + s], x[(2jj+1)*dq + s]), s < ZR = dq + window + slack:
@@ -517,9 +543,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         auto load_taps = [&](auto qq) {
             constexpr int q = decltype(qq)::value;
             const f4v *row = reinterpret_cast<const f4v *>(tp->table) + static_cast<size_t>(act ? phq[q] : 0u) * (tpp / 4);
+            // (quads past the row's end are never multiplied — the tap loop stops at jl_a <= tpp — and are not loaded: a
+            // wave-uniform test per quad; as a select per register it cost a v_cndmask per tap)
 #pragma unroll
             for (int e = 0; e < TPPM / 4; ++e)
-                tq[q % NTB][e] = (static_cast<uint32_t>(4 * e) < tpp) ? row[e] : (f4v){0.f, 0.f, 0.f, 0.f};
+                if (static_cast<uint32_t>(4 * e) < tpp) tq[q % NTB][e] = row[e];
         };
         static_for<0, NTB>(load_taps);
         __syncthreads();
@@ -600,8 +628,8 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 for (int a = 0; a < NWIN; ++a) {
                     const int idx = static_cast<int>(u_slot + static_cast<uint32_t>(q) * SQ) + a * static_cast<int>(S);
                     const float val = (a & 1) ? acc[q][a / 2].y : acc[q][a / 2].x;
-                    // (outputs before the recording or at / past its end: zero)
-                    if (idx < Gm::TILE_K) P[idx] = (idx >= k_lo && idx < k_hi) ? val : 0.f;
+                    // (outputs before the recording or at / past its end: zero; an interior tile has none)
+                    if (idx < Gm::TILE_K) P[idx] = (interior || (idx >= k_lo && idx < k_hi)) ? val : 0.f;
                 }
             }
         }

@@ -254,13 +254,14 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         const char *force_any = std::getenv("APTGPU_FUSED_ANY");  // tests: run-time kernel even if specialised
         plan->fused = 0;
         const bool no_spec = force_any && force_any[0] == '1';
-        const char *phase_first = std::getenv("APTGPU_PHASE_FIRST");  // tests: phase-resident stage 1 wherever it exists
+        const char *phase_first = std::getenv("APTGPU_PHASE_FIRST");  // tests: 0 = the table-driven stage 1 wherever it exists
         if (eligible && gpu::fused_supported(plan->l, plan->m, t1, t2, plan->pw) && !no_spec)
             plan->fused = 1;
-        // (where both the table-driven and the phase-resident stage 1 exist: the latter when a work sample takes two or
-        // more input samples — 32 kHz: 1.28 against 1.57 ms per 16 recordings; the former below that — 8 / 12 / 16 kHz:
-        // 0.72 / 0.76 / 0.95 against 0.80 / 0.88 / 0.99; profiles/r04_sweeps.txt)
-        else if (eligible && !no_spec && ((phase_first && phase_first[0] == '1') || (!phase_first && plan->m >= 2 * plan->l)) &&
+        // (where both the table-driven and the phase-resident stage 1 exist, the latter: since round 5 — thread assignment
+        // lists, interior tile loads, pipelined taps, two / four branches per thread — it is the faster one at every rate
+        // measured (8 / 11.025 / 16 / 32 kHz: 0.60 / 0.64 / 0.71 / 0.95 against 0.70 / 0.68 / 0.94 / 1.56 ms per 16 recordings,
+        // profiles/r05_sweeps.txt); APTGPU_PHASE_FIRST=0 (tests) puts the table-driven form first again)
+        else if (eligible && !no_spec && !(phase_first && phase_first[0] == '0') &&
                  gpu::fused_phase_supported(plan->l, plan->m, t1, t2, plan->pw, &plan->table_geom))
             plan->fused = 4;
         else if (eligible && !no_spec && gpu::fused_table_supported(plan->l, plan->m, t1, t2, plan->pw, &plan->table_geom))

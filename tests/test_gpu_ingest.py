@@ -106,8 +106,8 @@ def _pcm16(x):
     (96000, 12, dict(), 1),
     (48000, 20, dict(extra_chunks=[(b"junk", b"abc")]), 1),           # misaligned payload -> staging + fused f32
     (48000, 20, dict(channels=2), 1),                                 # stereo: first channel only
-    (11025, 30, dict(), 3),                                           # table-driven stage 1, int16 input
-    (11025, 30, dict(extra_chunks=[(b"junk", b"abc")]), 3),          # odd payload address -> staging + f32 table path
+    (11025, 30, dict(), 4),                                           # phase-resident stage 1 (four branches per thread), int16 input
+    (11025, 30, dict(extra_chunks=[(b"junk", b"abc")]), 4),          # odd payload address -> staging + the f32 kernel
     (48000, 20, dict(is_float=True), 1),
     (48000, 20, dict(bits=32), 1),
 ])

@@ -296,7 +296,7 @@ def test_fused_specialisations_are_used(ctx):
     (4); the rest the run-time fused kernel (2); l == 1 the unfused kernels (0)."""
     apt.cache_clear()  # (a session another test built under an APTGPU_* switch would answer for its own kernel path)
     for rate, profile, want in ((48000, "standard", 1), (96000, "standard", 1), (44100, "standard", 4),
-                                (11025, "standard", 3), (8000, "standard", 3), (22050, "standard", 4),
+                                (11025, "standard", 4), (8000, "standard", 4), (22050, "standard", 4),
                                 (48000, "fast", 4), (48000, "slow", 1), (96000, "fast", 2), (16000, "fast", 4),
                                 (11025, "fast", 2), (96000, "slow", 2), (24960, "standard", 0)):
         _, st = apt.decode(ctx, apt.Settings.profile(profile), synth_apt(rate, 11, 3), apt.Rate.hz(rate),
@@ -311,7 +311,9 @@ TABLE_CASES = [  # (rate, seconds): rates served by k_fused's table-driven stage
 
 @pytest.mark.parametrize("rate,seconds", TABLE_CASES)
 @pytest.mark.parametrize("sync", [True, False])
-def test_table_stage1_bitexact(ctx, oracle, rate, seconds, sync):
+def test_table_stage1_bitexact(ctx, oracle, monkeypatch, rate, seconds, sync):
+    monkeypatch.setenv("APTGPU_PHASE_FIRST", "0")  # (the phase-resident stage 1 is the default where both exist)
+    apt.cache_clear()
     x = synth_apt(rate, seconds, seed=rate % 97 + seconds)
     want = oracle.decode(x, rate, sync)
     got, st = apt.decode(ctx, apt.Settings(), x, apt.Rate.hz(rate), sync, return_stats=True)
@@ -319,9 +321,10 @@ def test_table_stage1_bitexact(ctx, oracle, rate, seconds, sync):
     assert_bitexact(got, want, f"table stage 1 {rate} sync={sync}")
 
 
-def test_table_stage1_long_ragged_batched_and_pcm16(oracle):
+def test_table_stage1_long_ragged_batched_and_pcm16(oracle, monkeypatch):
     """Many tiles, lengths that end mid-tile / mid-group, several recordings per call, PCM16 payloads at
     odd byte offsets, and the fast mode's tolerance — all at 11 025 Hz."""
+    monkeypatch.setenv("APTGPU_PHASE_FIRST", "0")
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda:0")
     recs = [synth_apt(11025, 900, seed=5), synth_apt(11025, 20, seed=6)[:11025 * 20 - 3],

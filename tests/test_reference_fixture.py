@@ -84,7 +84,7 @@ def test_gpu_decode_wav(oracle, ow, data, sync, mode):
 
 @pytest.mark.gpu
 def test_gpu_decode_wav_fast_mode_within_tolerance(oracle, ow, data):
-    """APTGPU_MODE_FAST on the fixture (11 025 Hz: table-driven stage 1 + the fast work-rate stages,
+    """APTGPU_MODE_FAST on the fixture (11 025 Hz: phase-resident stage 1 + the fast work-rate stages,
     PCM16 payload straight from the file image): the tolerance of SURVEY.md §8(d) — same rows, and (a
     moved sync position would move a whole row) every pixel within 1e-4 of full scale."""
     rows, st = apt.decode_wav(apt.Context(device=0, mode=apt.MODE_FAST), apt.Settings(), data, True,
@@ -92,7 +92,7 @@ def test_gpu_decode_wav_fast_mode_within_tolerance(oracle, ow, data):
     sig, spec = ow.load_wav(data)
     want = oracle.decode(sig, spec.sample_rate, True)
     g = GOLDEN["decode_sync_1"]
-    assert st.fused == 3 and st.n_sync == g["n_sync"] and rows.size == want.size == g["rows"] * 2080
+    assert st.fused == 4 and st.n_sync == g["n_sync"] and rows.size == want.size == g["rows"] * 2080
     err = float(np.max(np.abs(rows - want))) / float(np.max(np.abs(want)))
     assert 0 < err <= 1e-4, err
 
