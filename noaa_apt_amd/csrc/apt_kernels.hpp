@@ -146,13 +146,18 @@ struct TableGeom {
     // PHASE mode: the thread -> branch-slot assignment (fused_phase_table): `nperm` lists of `nthr` uint32 entries at
     // float offset `perm_off` of the table buffer, list (tile % nperm) for a tile; an entry >= step_r marks an idle thread
     uint32_t nthr, perm_off, nperm;
-    uint32_t nq;               // PHASE mode: branches per thread (1, 2, 4); step_r / nq threads of a workgroup have work
+    uint32_t nq;               // PHASE mode: branches per thread (1, 2, 4, 8); step_r / nq threads of a workgroup have work
+    uint32_t stream;           // PHASE mode: taps streamed from the table (filters too long for the registers), rows padded to 16
     // PHASE mode, exact != 0 (the tile phases repeat with a period nperm = 1 << perm_shift <= 8): list (tile % nperm) is
     // built for that tile's phase, and everything a tile derives from its index by division is tabulated — per phase r the
     // first input sample's quotient x0r[r] and remainder rbr[r] (tile = nperm t + r: X0 = x0r[r] + t xd), per thread the
     // window start and polyphase branch of each of its nq slots, packed (c | p << 16) at float offset cp_off
     // ([nperm][nthr][nq] uint32).  exact == 0: one list serves every tile and the kernel divides.
     uint32_t exact, perm_shift, cp_off, xd;
+    // ... and the taps once more in THREAD order at float offset tt_off: [nperm][nq][tpp / 4][nthr] quads — quad e of
+    // the branch of thread t's slot q — so that a wave's tap load is 1 KB of consecutive memory (from the phase-major
+    // table every lane reads a row of its own: 64 cache lines per load)
+    uint32_t tt_off;
     int32_t x0r[8];
     uint32_t rbr[8];
 };

@@ -290,10 +290,10 @@ bool fused_table_front_end(hipStream_t s, const TableGeom &geom, int mode, bool 
 namespace {
 constexpr uint32_t kPhaseOutputs = 16;
 constexpr uint32_t kPhaseMaxPerm = 8;
-uint32_t phase_tpp(uint32_t l, uint32_t t1)
+uint32_t phase_tpp(uint32_t l, uint32_t t1, bool stream = false)
 {
     const uint32_t jlim = 2 * ((t1 - 1) / 2) + 1;
-    return ((jlim + l - 1) / l + 3u) & ~3u;
+    return stream ? ((jlim + l - 1) / l + 15u) & ~15u : ((jlim + l - 1) / l + 3u) & ~3u;  // (streamed: whole chunks of 16)
 }
 // the tile of a PHASE workgroup (FusedGeom with TABLE geometry: whole groups of four halo threads either side)
 struct PhaseTile {
@@ -323,7 +323,8 @@ uint32_t phase_tap_regs(uint32_t threads, uint32_t t2, uint32_t nq)
     return nq == 1 ? 76u : nq == 2 ? 36u : 20u;
 }
 // geometry for workgroups of `threads` (256: three per CU; 512: two; 1024: one) whose threads hold nq branches each
-bool phase_geom(uint32_t threads, uint32_t nq, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom)
+bool phase_geom(uint32_t threads, uint32_t nq, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom,
+                bool stream = false)
 {
     const uint32_t tile = threads * 13;
     if (nq == 1 ? l > threads : (l % nq != 0 || l / nq > threads || l <= threads)) return false;
@@ -334,8 +335,9 @@ bool phase_geom(uint32_t threads, uint32_t nq, uint32_t l, uint32_t m, uint32_t 
     g.nq = nq;
     g.jlim = 2 * ((t1 - 1) / 2) + 1;
     const uint32_t per_phase = (g.jlim + l - 1) / l;
-    if (per_phase > phase_tap_regs(threads, t2, nq)) return false;
-    g.tpp = phase_tpp(l, t1);
+    if (!stream && per_phase > phase_tap_regs(threads, t2, nq)) return false;
+    g.stream = stream ? 1u : 0u;
+    g.tpp = phase_tpp(l, t1, stream);
     // outputs between a branch's consecutive outputs: as many whole periods of l as the threads hold (nq = 1), or l
     const uint32_t stride = nq == 1 ? l * (threads / l) : l;
     if ((tile + stride - 1) / stride > kPhaseOutputs / nq) return false;
@@ -344,7 +346,9 @@ bool phase_geom(uint32_t threads, uint32_t nq, uint32_t l, uint32_t m, uint32_t 
     // paired input tile: kPhaseOutputs / nq / 2 regions of off_x f2 entries — a branch's window starts at most
     // step_q + 4 entries into its region and is per_phase long
     g.off_x = g.step_q + per_phase + 8;
-    if (g.off_x > 1024) return false;  // (the tile loader covers a region in 1024 / threads rounds)
+    // (the tile loader covers a region in 1024 / threads rounds; the fast profile's forms with four / eight branches per
+    // thread — one or two regions only — in nine)
+    if (g.off_x > ((t2 == 43 && nq > 2) ? 2304u : 1024u)) return false;
     g.xt = (kPhaseOutputs / nq / 2) * 2 * g.off_x;
     // LDS: three 256-thread workgroups (53 KB each), two 512-thread ones (80 KB) or one of 1024 threads per CU
     if (g.xt > (threads == 256 ? 13600u : threads == 512 ? 20480u : 36000u)) return false;
@@ -360,6 +364,8 @@ bool phase_geom(uint32_t threads, uint32_t nq, uint32_t l, uint32_t m, uint32_t 
     g.nperm = nperm;
     g.perm_off = (l * g.tpp + 3u) & ~3u;
     g.cp_off = (g.perm_off + nperm * threads + 3u) & ~3u;
+    g.tt_off = (g.cp_off + nperm * threads * nq + 3u) & ~3u;
+    if (const char *e = std::getenv("APTGPU_PHASE_TT"); !g.exact || (e && e[0] == '0')) g.tt_off = 0;  // (A/B switch: 0 = phase-major rows only)
     for (g.perm_shift = 0; (1u << g.perm_shift) < nperm; ++g.perm_shift) {}
     if (g.exact) {
         g.xd = static_cast<uint32_t>(static_cast<uint64_t>(nperm) * pt.own_k * m / l);  // exact: the period's definition
@@ -381,7 +387,14 @@ bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uin
     if (l < 2 || m == 0 || t1 == 0) return false;
     // work-rate stages: the standard profile's (256 threads with one, two or four branches each; 512- and 1024-thread
     // workgroups), the fast profile's (256 threads, one branch)
-    if (t2 == 43 && pw == 4) return phase_geom(256, 1, l, m, t1, t2, pw, geom);
+    if (t2 == 43 && pw == 4)
+        return phase_geom(256, 1, l, m, t1, t2, pw, geom) || phase_geom(256, 4, l, m, t1, t2, pw, geom) ||
+               phase_geom(256, 8, l, m, t1, t2, pw, geom);
+    // the slow profile's (61-tap low-pass, pixel width 5): its resampling filters (197 taps per branch at the sound-card
+    // rates) do not fit the registers — the streamed form
+    if (t2 == 61 && pw == 5)
+        return phase_geom(256, 1, l, m, t1, t2, pw, geom, true) || phase_geom(256, 2, l, m, t1, t2, pw, geom, true) ||
+               phase_geom(256, 4, l, m, t1, t2, pw, geom, true);
     if (t2 != 37 || pw != 3) return false;
     const char *wide = std::getenv("APTGPU_PHASE_WIDE");  // A/B switch (plan creation): the 512- / 1024-thread forms first
     if (wide && wide[0] == '1' && (phase_geom(512, 1, l, m, t1, t2, pw, geom) || phase_geom(1024, 1, l, m, t1, t2, pw, geom)))
@@ -391,7 +404,12 @@ bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uin
            phase_geom(1024, 1, l, m, t1, t2, pw, geom);
 }
 
-uint32_t fused_phase_table_floats(const TableGeom &g) { return g.cp_off + g.nperm * g.nthr * (g.nq ? g.nq : 1u) + 80u; }  // (+ a row of slack: the tap loads are not bounded by tpp)
+uint32_t fused_phase_table_floats(const TableGeom &g)
+{
+    // (+ slack behind both tap tables: the streamed form prefetches one chunk past a row's end)
+    const uint32_t base = g.tt_off ? g.tt_off : ((g.cp_off + g.nperm * g.nthr * (g.nq ? g.nq : 1u) + 3u) & ~3u);
+    return base + (g.tt_off ? g.nperm * (g.nq ? g.nq : 1u) * g.tpp * g.nthr : 0u) + 64u * g.nthr / 4u + 80u;
+}
 
 // Thread -> branch-slot lists.  Thread t of a tile computes the outputs u, u + S, ... (S = step_r) for its slot u; the
 // window of slot u starts c(u) = ceil((rb + u m) / l) entries into a region of the paired input tile, and every
@@ -515,6 +533,16 @@ void fused_phase_table(const TableGeom &g, uint32_t t2, uint32_t pw, const float
                 cp[static_cast<size_t>(t) * nq + q] = static_cast<uint32_t>(c) | (static_cast<uint32_t>(ph) << 16);
             }
         std::memcpy(table + g.cp_off + static_cast<size_t>(r) * g.nthr * nq, cp.data(), cp.size() * sizeof(uint32_t));
+        if (g.tt_off) {
+            // the taps in thread order: [r][q][e][t][4]
+            for (uint32_t q = 0; q < nq; ++q)
+                for (uint32_t e = 0; e < tpp / 4; ++e)
+                    for (uint32_t t = 0; t < g.nthr; ++t) {
+                        const uint32_t ph = cp[static_cast<size_t>(t) * nq + q] >> 16;
+                        float *dst = table + g.tt_off + (((static_cast<size_t>(r) * nq + q) * (tpp / 4) + e) * g.nthr + t) * 4;
+                        for (uint32_t k = 0; k < 4; ++k) dst[k] = chosen[t] < S ? table[static_cast<size_t>(ph) * tpp + 4 * e + k] : 0.f;
+                    }
+        }
     }
 }
 
@@ -527,6 +555,21 @@ bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, uint32_t t2, ui
             if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 1u) return false;
     const FusedLaunch a{s, &call, d_prm, max_w, static_cast<size_t>(geom.xt)};
     const bool wide = geom.nthr == 512, huge = geom.nthr == 1024;
+    if (t2 == 61 && pw == 5) {  // the slow profile's work-rate stages, streamed taps (strict instantiations only: they serve fast mode too)
+        if (wide || huge || !geom.stream) return false;
+        if (geom.nq == 1) pcm16 ? fused_launch_phase_slowp_i16(a) : fused_launch_phase_slowp_f32(a);
+        else if (geom.nq == 2) pcm16 ? fused_launch_phase2_slowp_i16(a) : fused_launch_phase2_slowp_f32(a);
+        else if (geom.nq == 4) pcm16 ? fused_launch_phase4_slowp_i16(a) : fused_launch_phase4_slowp_f32(a);
+        else return false;
+        return true;
+    }
+    if (t2 == 43 && pw == 4 && geom.nq > 1) {  // the fast profile's, four / eight branches per thread (strict instantiations only)
+        if (wide || huge) return false;
+        if (geom.nq == 4) pcm16 ? fused_launch_phase4_fastp_i16(a) : fused_launch_phase4_fastp_f32(a);
+        else if (geom.nq == 8) pcm16 ? fused_launch_phase8_fastp_i16(a) : fused_launch_phase8_fastp_f32(a);
+        else return false;
+        return true;
+    }
     if (t2 == 43 && pw == 4) {  // the fast profile's work-rate stages
         if (wide || huge) return false;
         if (mode == kModeFast) pcm16 ? fused_launch_phase_fastp_fast_i16(a) : fused_launch_phase_fastp_fast_f32(a);

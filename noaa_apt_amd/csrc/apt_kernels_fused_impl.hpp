@@ -239,7 +239,7 @@ __host__ __device__ constexpr bool sync_plus(int j)
 // that walked the tiles with a fixed grid and kept the NEXT tile's input in registers while the stages ran was measured
 // in rounds 2 and 3 and dropped: slower in every mode)
 template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
-__global__ void __launch_bounds__(NTHR, M < 0 ? ((NTHR > 512 ? 1 : NTHR > 256 ? 2 : (T2 == 43 ? 4 : M == -4 ? 5 : M == -2 ? 4 : 3)) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs; the fast profile's and two branches per thread: four, <= 128; four branches: five, <= 96), two 512-thread or one 1024-thread (<= 128) workgroups per CU */
+__global__ void __launch_bounds__(NTHR, M < 0 ? ((NTHR > 512 ? 1 : NTHR > 256 ? 2 : (T1 == 1 ? (M == -1 ? 3 : 4) : T2 == 43 ? 4 : M == -4 ? 5 : M == -2 ? 4 : 3)) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs; the fast profile's and two branches per thread: four, <= 128; four branches: five, <= 96), two 512-thread or one 1024-thread (<= 128) workgroups per CU */
                                      : M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
                                                /* specialised: as many workgroups as the CU's 160 KB of LDS hold (48 kHz SPLIT: 5, 96 kHz: 3) */
                                                : (FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), MODE == kModeF16Taps>::WGS_PER_CU * NTHR + 255) / 256)
@@ -396,11 +396,15 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         constexpr int NB = 16;     // outputs per thread (NB / NQ >= ceil(TILE_K / S): checked by fused_phase_supported)
         constexpr int NQ = -M;     // branches per thread
         constexpr int NWIN = NB / NQ, NREG = NWIN / 2;  // outputs per branch; regions of the paired tile
-        static_assert(NQ == 1 || NQ == 2 || NQ == 4, "one, two or four branches per thread");
+        static_assert(NQ == 1 || NQ == 2 || NQ == 4 || NQ == 8, "one, two, four or eight branches per thread");
+        // T1 == 1 (unused otherwise in this mode): the STREAMED form for filters too long for the registers (the slow
+        // profile: 197 taps per branch) — a branch's taps are fetched from the table sixteen at a time while the previous
+        // sixteen are in use, instead of all of them before the first multiplication
+        constexpr bool STREAM = T1 == 1;
         // taps per branch the registers hold (>= tpp; 128 / 170 VGPRs).  The fast profile's filters are short (639 taps at
         // 48 kHz: 25 per branch at every rate — its transition band is three times the standard profile's): 28 registers,
         // so that its kernels fit four workgroups per CU
-        constexpr int TPPM = NTHR > 512 ? 24 : NTHR > 256 ? 40 : (T2 == 43 ? 28 : NQ == 1 ? 76 : NQ == 2 ? 36 : 20);  // (phase_tap_regs in apt_kernels_fused.hip)
+        constexpr int TPPM = STREAM ? 4 : NTHR > 512 ? 24 : NTHR > 256 ? 40 : (T2 == 43 ? 28 : NQ == 1 ? 76 : NQ == 2 ? 36 : 20);  // (phase_tap_regs in apt_kernels_fused.hip)
         typedef const FusedParams APT_CONST_AS *cprm_tab_ptr;
         const cprm_tab_ptr tp = (cprm_tab_ptr)(prm);
         const uint32_t gl = tp->tab.l, gm_ = tp->tab.m, tpp = tp->tab.tpp;
@@ -472,7 +476,9 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         {
             // every load of the tile issued before the first LDS write (regions x rounds unrolled: a loop
             // that waited for each round's loads cost 26 HBM latencies per tile)
-            constexpr int ZROUNDS = 1024 / kFusedThreads;  // ceil(ZR / NTHR) at most (fused_phase_supported: ZR <= 1024)
+            // ceil(ZR / NTHR) at most (phase_geom: ZR <= 1024; the fast profile's long periods — 44 100 Hz: m = 2205 — 2304,
+            // with one or two regions only)
+            constexpr int ZROUNDS = (T2 == 43 && NQ > 2) ? 9 : 1024 / kFusedThreads;
             const XT *xt0 = x + xs0;    // only dereferenced inside [x_lo, x_hi)
             const int x_lo = rel(-xs0), x_hi = rel(n - xs0);
             XT za[NREG][ZROUNDS], zb[NREG][ZROUNDS];
@@ -542,14 +548,20 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         f4v tq[NTB][TPPM / 4];
         auto load_taps = [&](auto qq) {
             constexpr int q = decltype(qq)::value;
-            const f4v *row = reinterpret_cast<const f4v *>(tp->table) + static_cast<size_t>(act ? phq[q] : 0u) * (tpp / 4);
+            // (exact lists: the thread-order copy — quad e of this thread's branch q is element e * NTHR + tid of its
+            // [tpp / 4][NTHR] block, a wave's load 1 KB of consecutive memory; else its row of the phase-major table)
+            const uint32_t tt_off = tp->tab.tt_off;  // (0: no such copy)
+            const f4v *row = tt_off ? reinterpret_cast<const f4v *>(tp->table + tt_off) +
+                                          (static_cast<size_t>(rsel) * NQ + q) * (tpp / 4) * kFusedThreads + tid
+                                    : reinterpret_cast<const f4v *>(tp->table) + static_cast<size_t>(act ? phq[q] : 0u) * (tpp / 4);
+            const uint32_t estep = tt_off ? static_cast<uint32_t>(kFusedThreads) : 1u;
             // (quads past the row's end are never multiplied — the tap loop stops at jl_a <= tpp — and are not loaded: a
             // wave-uniform test per quad; as a select per register it cost a v_cndmask per tap)
 #pragma unroll
             for (int e = 0; e < TPPM / 4; ++e)
-                if (static_cast<uint32_t>(4 * e) < tpp) tq[q % NTB][e] = row[e];
+                if (static_cast<uint32_t>(4 * e) < tpp) tq[q % NTB][e] = row[static_cast<size_t>(e) * estep];
         };
-        static_for<0, NTB>(load_taps);
+        if constexpr (!STREAM) static_for<0, NTB>(load_taps);
         __syncthreads();
         if constexpr (APT_FUSED_STOP == 1) return;
         f2 acc[NQ][NREG];  // branch q, output pair (2jj, 2jj+1)
@@ -567,6 +579,66 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             // (until round 5 a chunk's reads were issued and waited for in place: one exposed LDS latency per two taps, at
             // three waves per SIMD).  Two buffers of NREG pairs (NQ = 1: the same registers a two-tap chunk held).
             f2 xb[2][NREG];
+            if constexpr (STREAM) {
+                constexpr int TCH = 16;  // taps per chunk: four 16-byte loads of the branch's row (rows are padded to chunks)
+                const uint32_t tt_off = tp->tab.tt_off;
+                const f4v *row = tt_off ? reinterpret_cast<const f4v *>(tp->table + tt_off) +
+                                              (static_cast<size_t>(rsel) * NQ + q) * (tpp / 4) * kFusedThreads + tid
+                                        : reinterpret_cast<const f4v *>(tp->table) + static_cast<size_t>(phq[q]) * (tpp / 4);
+                const uint32_t estep = tt_off ? static_cast<uint32_t>(kFusedThreads) : 1u;
+                f4v tb[2][TCH / 4];
+                const f2 *zp[NREG];
+#pragma unroll
+                for (int jj = 0; jj < NREG; ++jj) zp[jj] = zw[jj];
+                auto fetch = [&](auto bb, uint32_t ch) {
+                    constexpr int b = decltype(bb)::value;
+#pragma unroll
+                    for (int e = 0; e < TCH / 4; ++e) tb[b][e] = row[static_cast<size_t>(ch * (TCH / 4) + e) * estep];
+                };
+                // one chunk: tap i0 + k against the pairs at zp[jj][k]; the reads of tap k + 1 issued before the arithmetic
+                // of tap k; a wave-uniform test per tap (all lanes run taps i < jl_a)
+                auto chunk = [&](auto bb, uint32_t i0) {
+                    constexpr int b = decltype(bb)::value;
+#pragma unroll
+                    for (int jj = 0; jj < NREG; ++jj) xb[0][jj] = zp[jj][0];
+                    static_for<0, TCH>([&](auto kk) {
+                        constexpr int k = decltype(kk)::value;
+                        if (i0 + static_cast<uint32_t>(k) < jl_a) {
+                            if constexpr (k + 1 < TCH) {
+#pragma unroll
+                                for (int jj = 0; jj < NREG; ++jj) xb[(k + 1) & 1][jj] = zp[jj][k + 1];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            const f4v q4 = tb[b][k / 4];
+                            const float t = (k & 3) == 0 ? q4.x : (k & 3) == 1 ? q4.y : (k & 3) == 2 ? q4.z : q4.w;
+                            if constexpr (FAST) {
+#pragma unroll
+                                for (int jj = 0; jj < NREG; ++jj) acc[q][jj] = __builtin_elementwise_fma((f2){t, t}, xb[k & 1][jj], acc[q][jj]);
+                            } else {
+                                f2 pr[NREG];
+#pragma unroll
+                                for (int jj = 0; jj < NREG; ++jj) pr[jj] = (f2){t, t} * xb[k & 1][jj];
+#pragma unroll
+                                for (int jj = 0; jj < NREG; ++jj) acc[q][jj] = acc[q][jj] + pr[jj];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
+#pragma unroll
+                    for (int jj = 0; jj < NREG; ++jj) zp[jj] += TCH;
+                };
+                const uint32_t nch = (jl_a + TCH - 1) / TCH;
+                fetch(std::integral_constant<int, 0>{}, 0);
+#pragma unroll 1
+                for (uint32_t ch = 0; ch < nch; ch += 2) {
+                    fetch(std::integral_constant<int, 1>{}, ch + 1);  // (past the row's last chunk: the next row or the table's slack, never used)
+                    chunk(std::integral_constant<int, 0>{}, ch * TCH);
+                    if (ch + 1 < nch) {
+                        fetch(std::integral_constant<int, 0>{}, ch + 2);
+                        chunk(std::integral_constant<int, 1>{}, (ch + 1) * TCH);
+                    }
+                }
+            }
             auto issue = [&](auto ii) {
                 constexpr int i = decltype(ii)::value;
 #pragma unroll
@@ -589,9 +661,9 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             };
             // taps 0 .. jl_a - 1 for every branch, tap jl_a for the branches p < jl_b (the reference's
             // `p + i*l < jlim`): the tap count is wave-uniform up to that last, lane-predicated one.
-            bool go = true;  // (wave-uniform)
-            issue(std::integral_constant<int, 0>{});
-            static_for<0, TPPM>([&](auto ee) {
+            bool go = !STREAM;  // (wave-uniform)
+            if constexpr (!STREAM) issue(std::integral_constant<int, 0>{});
+            static_for<0, STREAM ? 0 : TPPM>([&](auto ee) {
                 constexpr int i0 = decltype(ee)::value;
                 go = go && static_cast<uint32_t>(i0 + 1) <= jl_a;
                 if (go) {
@@ -614,7 +686,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                     else acc[q][jj] = acc[q][jj] + (f2){t, t} * xp[jj];
                 }
             }
-            if constexpr (q + NTB < NQ) {
+            if constexpr (!STREAM && q + NTB < NQ) {
                 __builtin_amdgcn_sched_barrier(0);
                 load_taps(std::integral_constant<int, q + NTB>{});
             }

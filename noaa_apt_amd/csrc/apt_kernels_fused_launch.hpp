@@ -105,6 +105,19 @@ void fused_launch_phase4_std_f32(const FusedLaunch &a);
 void fused_launch_phase4_std_i16(const FusedLaunch &a);
 void fused_launch_phase4_std_fast_f32(const FusedLaunch &a);
 void fused_launch_phase4_std_fast_i16(const FusedLaunch &a);
+// ... the fast profile's work-rate stages with four / eight branches per thread (44 100 Hz: l = 832; 22 050 Hz: l = 1664)
+void fused_launch_phase4_fastp_f32(const FusedLaunch &a);
+void fused_launch_phase4_fastp_i16(const FusedLaunch &a);
+void fused_launch_phase8_fastp_f32(const FusedLaunch &a);
+void fused_launch_phase8_fastp_i16(const FusedLaunch &a);
+// ... the slow profile's work-rate stages (61-tap low-pass, pixel width 5), taps streamed from the table (197 per branch at
+// 44 100 / 22 050 / 11 025 Hz: l = 208 / 416 / 832, m = 441)
+void fused_launch_phase_slowp_f32(const FusedLaunch &a);
+void fused_launch_phase_slowp_i16(const FusedLaunch &a);
+void fused_launch_phase2_slowp_f32(const FusedLaunch &a);
+void fused_launch_phase2_slowp_i16(const FusedLaunch &a);
+void fused_launch_phase4_slowp_f32(const FusedLaunch &a);
+void fused_launch_phase4_slowp_i16(const FusedLaunch &a);
 // ... 1024-thread workgroups (512 < l <= 1024), one branch per thread
 void fused_launch_phase1024_std_f32(const FusedLaunch &a);
 void fused_launch_phase1024_std_i16(const FusedLaunch &a);

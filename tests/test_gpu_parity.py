@@ -451,6 +451,10 @@ PROFILE_CASES = [  # (rate, seconds, profile, fused): the fast and slow profiles
     (48000, 14, "fast", 4),    # phase-resident stage 1 (l = 26) + the fast profile's work-rate stages (43 taps, pw 4)
     (96000, 12, "fast", 2),    # l = 13, m = 75: the paired tile of the phase-resident stage 1 would not fit — run-time kernel
     (16000, 30, "fast", 4), (32000, 16, "fast", 4), (8000, 50, "fast", 4), (12000, 40, "fast", 4), (24000, 20, "fast", 4),
+    # round 5: four / eight branches per thread in front of the fast profile's stages (l = 832 / 1664)
+    (44100, 14, "fast", 4), (22050, 20, "fast", 4),
+    # round 5: the slow profile at the sound-card rates — 197 taps per branch streamed from the table (l = 208 / 416 / 832)
+    (44100, 14, "slow", 4), (22050, 20, "slow", 4), (11025, 30, "slow", 4), (44100, 41, "slow", 4),
 ]
 
 
@@ -474,7 +478,7 @@ def test_profile_kernels_ragged_batched_pcm16_and_nonfinite(oracle):
     recordings that end around the tile boundaries."""
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda:0")
-    for profile, rate in (("slow", 48000), ("fast", 48000)):
+    for profile, rate in (("slow", 48000), ("fast", 48000), ("slow", 44100), ("fast", 44100), ("slow", 11025), ("fast", 22050)):
         s = apt.Settings.profile(profile)
         os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
                                            "resample_cutout", "demodulation_atten")}
