@@ -74,7 +74,7 @@ CASES = [
     (96000, 12, dict(seed=3)),
     (48000, 20, dict(seed=8, noise_sigma=6000.0)),   # heavy noise: many near-tie maxima
     (48000, 20, dict(seed=9, amplitude=2000.0)),     # weak signal
-    (11025, 30, dict(seed=6)),                       # table-driven stage 1 (k_fused TABLE mode), fast work-rate stages
+    (11025, 30, dict(seed=6)),                       # phase-resident stage 1, four branches per thread, fast work-rate stages
     (8000, 30, dict(seed=7)),
     (44100, 14, dict(seed=5)),                       # phase-resident stage 1 (k_fused PHASE mode)
     (22050, 20, dict(seed=4)),
@@ -86,7 +86,7 @@ def test_fast_mode_tolerance(oracle, rate, seconds, kw):
     x = synth_apt(rate, seconds, **kw)
     want, st = oracle.decode(x, rate, True, want_steps=True)
     rows, pos, res, fused = decode_on_plan(x, rate, apt.MODE_FAST)
-    assert fused == {48000: 1, 96000: 1, 44100: 4, 22050: 4}.get(rate, 3) and res.status == 0
+    assert fused == {48000: 1, 96000: 1}.get(rate, 4) and res.status == 0
     frac, err = check_tolerance(rows, pos, want, st["sync_pos"], f"{rate} {kw}")
     assert 0 < err <= PX_TOL  # it really is the reassociated arithmetic, and within tolerance
 
@@ -103,6 +103,22 @@ def test_fast_mode_tolerance_on_the_other_profiles(oracle, rate, seconds, profil
     assert fused == want_fused and res.status == 0
     frac, err = check_tolerance(rows, pos, want, st["sync_pos"], f"{rate} {profile}")
     assert 0 < err <= PX_TOL
+
+
+@pytest.mark.parametrize("rate,seconds,profile", [(44100, 14, "fast"), (22050, 20, "fast"), (44100, 14, "slow"), (11025, 30, "slow")])
+def test_fast_mode_served_by_strict_kernels(oracle, rate, seconds, profile):
+    """APTGPU_MODE_FAST where the kernel path has strict instantiations only (round 5: the fast profile with four / eight
+    branches per thread, the slow profile's streamed taps): the strict kernel serves the call, with the unverified
+    reciprocal of sin(phi) — inside the tolerance, usually bit-identical."""
+    x = synth_apt(rate, seconds, seed=37)
+    s = apt.Settings.profile(profile)
+    os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                       "resample_cutout", "demodulation_atten")}
+    want, st = oracle.decode(x, rate, True, settings=os_, want_steps=True)
+    rows, pos, res, fused = decode_on_plan(x, rate, apt.MODE_FAST, settings=s)
+    assert fused == 4 and res.status == 0
+    frac, err = check_tolerance(rows, pos, want, st["sync_pos"], f"{rate} {profile}")
+    assert err <= PX_TOL
 
 
 def test_fast_mode_pure_noise(oracle):
