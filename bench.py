@@ -87,7 +87,7 @@ def sustained_front_end(args, batch):
     probe = os.path.join(ROOT, "noaa_apt_amd", "libaptgpu_probe.so")
     if not os.path.exists(probe) or args.profile != "standard" or args.mode not in ("strict", "fast"):
         return None
-    env = dict(os.environ, APTGPU_LIB=probe, APTGPU_DEBUG_SKIP="7")
+    env = dict(os.environ, APTGPU_PROBE_LIB=probe, APTGPU_DEBUG_SKIP="7")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "tools", "sweep.py"), "--configs", f"{args.mode}:{batch}:3", "--steps", "80",
@@ -341,7 +341,7 @@ def main():
         # (amd-smi is opened here, well before the timed region: its initialisation takes a while, and a pause between
         # the warm-up steps and the timed steps would let the power manager's averages relax)
         smu = None
-        if rank == 0 and not args.no_power:
+        if not args.no_power:  # (every rank watches its own device: the first 8-GPU run should explain itself)
             from noaa_apt_amd.testing.smu import SmuSampler
             smu = SmuSampler(pci_bus_id=getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None), device_index=local_rank)
 
@@ -399,6 +399,7 @@ def main():
             step()
         t_enq = time.perf_counter()  # host finished enqueueing (informational)
         torch.cuda.synchronize()
+        t_local = time.perf_counter()  # this rank's own K steps (the job's time is taken behind the barrier)
         job_barrier()
         t1 = time.perf_counter()
         dom_times = plan.collect_timing()
@@ -610,6 +611,25 @@ def main():
     from noaa_apt_amd import shard
     # whole-job figures: MAX elapsed over ranks, SUM of samples over ranks (no other collective)
     elapsed, total_samples_per_step = shard.reduce_job(t1 - t0, float(n) * max(1, args.batch), device=dev)
+    # what each rank saw (bookkeeping, outside the timed region): its own K steps, its device's power and clocks in the
+    # settled loop, joules per call, and where its process and device sit
+    try:
+        aff = dict(zip(("pci", "numa_node", "cpulist"), apt.host_affinity(local_rank)))
+    except Exception as e:  # noqa: BLE001
+        aff = {"error": str(e)}
+    settled = (power or {}).get("settled") or {}
+    timed = (power or {}).get("timed_region") or {}
+    mine = {"rank": rank, "device": local_rank, "ms_per_step": round(1e3 * (t_local - t0) / args.steps, 5),
+            "socket_w": (settled.get("socket_w") or {}).get("mean"),
+            "gfxclk_mhz": (settled.get("gfxclk_mhz") or {}).get("mean_over_xcds"),
+            "joules_per_call": (round(timed["socket_w_mean"] * timed["window_s"] / args.steps, 4)
+                                if timed.get("socket_w_mean") and timed.get("window_s") else None),
+            "pci": aff.get("pci"), "numa_node": aff.get("numa_node"),
+            "cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    per_rank = [mine]
+    if dist is not None and world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine, group=cpu_group) if cpu_group is not None else dist.all_gather_object(per_rank, mine)
 
     if res.status != 0:
         raise SystemExit(f"decode failed on rank {rank}: status {res.status} reason {res.reason}")
@@ -712,6 +732,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5),
+            "joules_per_call": mine["joules_per_call"],  # socket energy accumulator over the timed region / K (rank 0's device)
+            "per_rank": per_rank,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

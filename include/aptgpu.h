@@ -275,7 +275,12 @@ int aptgpu_plan_read_internal(aptgpu_plan *plan, int i, const char *name, void *
  * Returns APTGPU_OK when every worker ran (per-recording failures are in status[]), else the first
  * worker-level error (HIP failure, bad argument).  Host buffers may be pageable; pinned ones
  * (aptgpu_host_alloc) are DMA'd directly. */
+/* ABI note (0.2.0): `struct_size` is the caller's sizeof(aptgpu_batch_stats), set BEFORE the call; the library fills
+ * at most that many bytes, so a caller built against this header keeps working when fields are appended (0 is read
+ * as "this header's size").  The struct had no such field in 0.1.0 and grew twice: check aptgpu_abi_version(). */
 typedef struct aptgpu_batch_stats {
+    uint32_t struct_size;  /* in: sizeof(aptgpu_batch_stats) as the caller was compiled              */
+    uint32_t reserved;
     double seconds;        /* wall time of the whole call                                   */
     uint64_t samples;      /* input samples of the recordings that were handed to a worker  */
     uint64_t h2d_bytes, d2h_bytes;
@@ -492,6 +497,9 @@ int aptgpu_resample_wav_file(const aptgpu_context *ctx, const char *input_path,
 /* 6. misc                                                                 */
 /* ====================================================================== */
 const char *aptgpu_version(void);
+/* Incremented whenever a struct of this header changes layout or a function its signature (0.2.0: 2). */
+int aptgpu_abi_version(void);
+#define APTGPU_ABI_VERSION 2
 int aptgpu_device_count(void);
 
 #ifdef __cplusplus

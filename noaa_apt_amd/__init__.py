@@ -31,6 +31,6 @@ from .api import (  # noqa: F401
     Contrast, Rotate, Telemetry, ImageResult,
     get_min, get_max, percent, map_signal_u8, read_telemetry, process,
     Plan, PlanInfo, Result, KernelTime, decode_batch, BatchStats, host_alloc_f32, host_free,
-    lib, lib_path, build, device_count, version, cache_clear, cache_info, host_affinity, host_affinity_from_sysfs,
+    lib, lib_path, use_library, build, device_count, version, abi_version, cache_clear, cache_info, host_affinity, host_affinity_from_sysfs,
     MODE_STRICT, MODE_GENERIC, MODE_FP16_TAPS, MODE_FAST,
 )

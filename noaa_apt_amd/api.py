@@ -1,6 +1,7 @@
 """ctypes binding of include/aptgpu.h with the reference's names (see package docstring)."""
 import ctypes as C
 import os
+import sys
 import subprocess
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence
@@ -17,8 +18,9 @@ MODE_FP16_TAPS = 2
 MODE_FAST = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (APTGPU_LIB: tools/ only — the probe build of `make -C noaa_apt_amd/csrc probe-lib` for timing experiments)
-_LIB = os.environ.get("APTGPU_LIB") or os.path.join(_HERE, "libaptgpu.so")
+# The product library, in-tree.  No environment variable redirects this module to another shared object; timing tools
+# that want the probe build (`make -C noaa_apt_amd/csrc probe-lib`) say so in code, through use_library().
+_LIB = os.path.join(_HERE, "libaptgpu.so")
 _f32p = C.POINTER(C.c_float)
 _u64p = C.POINTER(C.c_uint64)
 _i8p = C.POINTER(C.c_int8)
@@ -129,7 +131,8 @@ class WavSpec(C.Structure):
 
 class BatchStats(C.Structure):
     """aptgpu_batch_stats: what a host-fed batch moved and how long it took."""
-    _fields_ = [("seconds", C.c_double), ("samples", C.c_uint64), ("h2d_bytes", C.c_uint64),
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32),
+                ("seconds", C.c_double), ("samples", C.c_uint64), ("h2d_bytes", C.c_uint64),
                 ("d2h_bytes", C.c_uint64), ("h2d_seconds", C.c_double), ("d2h_seconds", C.c_double),
                 ("workers", C.c_int32), ("recordings_per_call", C.c_int32),
                 ("gate_wait_seconds", C.c_double), ("setup_seconds", C.c_double),
@@ -146,6 +149,17 @@ _lib = None
 
 def lib_path():
     return _LIB
+
+
+def use_library(path):
+    """tools/ only: load `path` (the probe build, libaptgpu_probe.so — same ABI, APTGPU_DEBUG_* switches that leave
+    kernels out, so its rows can be garbage) instead of the product library.  Must be called before the first lib();
+    says so on stderr."""
+    global _LIB
+    if _lib is not None:
+        raise RuntimeError("use_library() after the library was loaded")
+    _LIB = os.path.abspath(path)
+    sys.stderr.write(f"aptgpu: loading {_LIB} instead of the product library (timing experiments only)\n")
 
 
 def build():
@@ -181,6 +195,7 @@ def lib():
     L = C.CDLL(_LIB)
     vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
     L.aptgpu_version.restype = C.c_char_p
+    L.aptgpu_abi_version.restype = C.c_int
     L.aptgpu_device_count.restype = i32
     L.aptgpu_free.argtypes = [vp]
     L.aptgpu_free.restype = None
@@ -262,6 +277,10 @@ def lib():
 
 def version():
     return lib().aptgpu_version().decode()
+
+
+def abi_version():
+    return int(lib().aptgpu_abi_version())
 
 
 def device_count():
@@ -752,6 +771,7 @@ def decode_batch(context: Optional[Context], settings: Settings, inputs, input_r
     status = (C.c_int32 * max(k, 1))()
     results = (Result * max(k, 1))()
     stats = BatchStats()
+    stats.struct_size = C.sizeof(BatchStats)
     err = C.create_string_buffer(_ERRCAP)
     fn = lib().aptgpu_decode_batch_wav if wav else lib().aptgpu_decode_batch
     rc = fn(C.byref(cctx), C.byref(cs), input_rate.get_hz(), int(sync), k, ptrs, sizes, devs, len(devices),

@@ -41,7 +41,8 @@ aptgpu_context default_ctx()
 
 extern "C" {
 
-const char *aptgpu_version(void) { return "aptgpu 0.1.0 (gfx950)"; }
+const char *aptgpu_version(void) { return "aptgpu 0.2.0 (gfx950)"; }
+int aptgpu_abi_version(void) { return APTGPU_ABI_VERSION; }
 
 int aptgpu_device_count(void)
 {
@@ -721,8 +722,9 @@ int aptgpu_find_sync(const aptgpu_context *ctx, const float *signal, size_t n,
             call.rec[0].rows_cap = 0;
             call.rec[0].slot = 0;
             apt::gpu::group_max(sc.stream, d_c.ptr, n_corr, d_gm.ptr);
-            apt::gpu::sync_nodes(sc.stream, call, d_sp.ptr, n, pw, spr, md, false, true);
-            apt::gpu::sync_orbit(sc.stream, call, d_sp.ptr, spr, md, pw, (fw && fw[0] == '1') ? 1 : 0);
+            const apt::gpu::LaunchSwitches sw = apt::gpu::read_launch_switches();  // (once per API call)
+            apt::gpu::sync_nodes(sc.stream, call, d_sp.ptr, n, pw, spr, md, false, true, sw);
+            apt::gpu::sync_orbit(sc.stream, call, d_sp.ptr, spr, md, pw, (fw && fw[0] == '1') ? 1 : 0, sw);
             apt::hip_check(hipGetLastError(), "kernel launch (find_sync)");
             apt::hip_check(hipStreamSynchronize(sc.stream), "hipStreamSynchronize");
         }

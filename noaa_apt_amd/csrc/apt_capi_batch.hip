@@ -95,7 +95,7 @@ void Session::ensure_set(int k, uint64_t in_bytes, uint64_t out_cap)
             buf.alloc(count);
         } catch (const Error &e) {
             buf.count = 0;
-            if (e.kind != ErrorKind::Hip || e.message.find("out of memory") == std::string::npos) throw;
+            if (e.kind != ErrorKind::Hip || e.hip_code != static_cast<int>(hipErrorOutOfMemory)) throw;  // (the status itself, not its wording)
             (void)hipGetLastError();
             session_cache_clear();
             try {
@@ -136,6 +136,8 @@ float *staging_rows(IoSet &s, size_t per_call)
                        "hipHostMalloc");
     return s.h_rows;
 }
+
+static_assert(sizeof(aptgpu_batch_stats) == 88, "aptgpu_batch_stats: layout of include/aptgpu.h (api.py mirrors it)");
 
 namespace {
 
@@ -221,7 +223,7 @@ SessionLease session_acquire(const SessionKey &key, uint64_t max_n)
         return SessionLease(build());
     } catch (const Error &e) {
         // out of device memory while idle sessions hold some: drop them and try once more
-        if (e.kind != ErrorKind::Hip || e.message.find("out of memory") == std::string::npos) throw;
+        if (e.kind != ErrorKind::Hip || e.hip_code != static_cast<int>(hipErrorOutOfMemory)) throw;  // (the status itself, not its wording)
         (void)hipGetLastError();
         session_cache_clear();
         return SessionLease(build());
@@ -766,18 +768,23 @@ int decode_batch_impl(const aptgpu_context *ctx, const aptgpu_settings *settings
             if (!share[k].empty()) threads.emplace_back(worker, std::ref(sh), static_cast<int>(devs[k]), std::move(share[k]));
         for (auto &t : threads) t.join();
         if (stats) {
-            stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            stats->samples = total_samples;
-            stats->h2d_bytes = sh.h2d_bytes;
-            stats->d2h_bytes = sh.d2h_bytes;
-            stats->h2d_seconds = sh.h2d_seconds;
-            stats->d2h_seconds = sh.d2h_seconds;
-            stats->workers = static_cast<int32_t>(threads.size());
-            stats->recordings_per_call = sh.per_call;
-            stats->gate_wait_seconds = sh.gate_wait_seconds;
-            stats->setup_seconds = sh.setup_seconds;
-            stats->sessions_created = sh.sessions_created;
-            stats->workers_pinned = sh.workers_pinned;
+            // (filled in a local copy, then at most the caller's struct_size bytes go out: include/aptgpu.h)
+            aptgpu_batch_stats full{};
+            const uint32_t want = stats->struct_size ? stats->struct_size : static_cast<uint32_t>(sizeof full);
+            full.struct_size = want;
+            full.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            full.samples = total_samples;
+            full.h2d_bytes = sh.h2d_bytes;
+            full.d2h_bytes = sh.d2h_bytes;
+            full.h2d_seconds = sh.h2d_seconds;
+            full.d2h_seconds = sh.d2h_seconds;
+            full.workers = static_cast<int32_t>(threads.size());
+            full.recordings_per_call = sh.per_call;
+            full.gate_wait_seconds = sh.gate_wait_seconds;
+            full.setup_seconds = sh.setup_seconds;
+            full.sessions_created = sh.sessions_created;
+            full.workers_pinned = sh.workers_pinned;
+            std::memcpy(stats, &full, std::min<size_t>(want, sizeof full));
         }
         if (sh.first_error_code != APTGPU_OK) {
             put_err(err, err_cap, sh.first_error);

@@ -34,6 +34,7 @@ enum class ErrorKind { Internal = 1, RateOverflow = 2, Hip = 3, Invalid = 4, Uns
 struct Error {
     ErrorKind kind;
     std::string message;
+    int hip_code = 0;  // ErrorKind::Hip: the hipError_t behind it (0 where the error is not a runtime status)
 };
 
 // Sample rate in Hz (frequency.rs:98-117).

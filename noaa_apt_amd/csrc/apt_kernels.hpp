@@ -49,6 +49,20 @@ struct GroupMax {
     float lo;
 };
 
+// A/B switches of the launch wrappers (APTGPU_* environment variables of tools/ and tests/): read ONCE, when a plan
+// is created (read_launch_switches), and carried by the plan to every launch — not per launch: getenv is not safe
+// against a concurrent setenv of another thread, and a plan must not change kernels in mid-life.
+struct LaunchSwitches {
+    int gather_iters = 1;        // APTGPU_GATHER_ITERS: quads per thread of k_gather_rows_flat (0: the eight-rows form)
+    bool words_dpp = true;       // APTGPU_WORDS_DPP=0: k_sync_words without the DPP scans
+    bool orbit_lds = true;       // APTGPU_ORBIT_LDS=0: the orbit kernel's tables in global memory
+    int orbit_threads = 0;       // APTGPU_ORBIT_THREADS=256: the 256-thread orbit kernel
+    int orbit_alg = 1;           // APTGPU_ORBIT_ALG=0: the breadth-first closure form
+    float gm_slack_scale = 1.f;  // APTGPU_GM_SLACK_SCALE (tests): widens the strict front ends' bounds
+    int fused_lds_pad = 0;       // APTGPU_FUSED_LDS_PAD: extra dynamic LDS bytes per front-end workgroup
+};
+LaunchSwitches read_launch_switches();
+
 // ---- one decode_device call = one launch per stage over all its recordings -----------
 // Per-recording arguments travel BY VALUE in the kernel-argument segment (no H2D copy, no pinned
 // staging, nothing for the host to wait on); blockIdx.y (front end, k_sync_words, k_sync_slots, k_gather_rows) or
@@ -111,7 +125,7 @@ void gather_rows(hipStream_t s, const float *f, const uint32_t *peaks, Result *r
                  uint32_t spr, uint32_t pw, bool raw, float *rows, uint32_t rows_cap);
 // the same for the recordings of one call: rows / rows_cap from the call, F / peaks / res from the slots
 void gather_rows_call(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint32_t spr, uint32_t pw,
-                      uint32_t max_rows_cap);
+                      uint32_t max_rows_cap, const LaunchSwitches &sw = LaunchSwitches{});
 
 // ---- fused specialised front end (apt_kernels_fused.hip) --------------------------
 // true when a <L, M, T1, T2, PW> specialisation exists
@@ -129,7 +143,7 @@ uint32_t fused_f16_table_dwords(uint32_t l, uint32_t m, uint32_t t1);
 float fused_f16_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, uint32_t *table);
 bool fused_f16_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
 // strict front ends: |pulse-sum correlation - sequential chain| <= fused_gm_slack(pw) * sum|F| (see stage 4)
-float fused_gm_slack(uint32_t pw);
+float fused_gm_slack(uint32_t pw, float scale = 1.f);
 // fast mode (APTGPU_MODE_FAST): availability (same tables as strict)
 bool fused_fast_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
 // Per-plan parameters of the specialised front end, resident in HBM (the kernel fetches each when
@@ -179,7 +193,7 @@ struct FusedParams {
 // Inputs are f32 Signals, or (pcm16) mono int16 samples at 4-byte aligned addresses.
 // mode: 0 strict, 1 fp16 taps, 2 fast.
 bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, int mode,
-                     bool pcm16, const CallArgs &call, const FusedParams *d_prm, uint64_t max_w);
+                     bool pcm16, const CallArgs &call, const FusedParams *d_prm, uint64_t max_w, int lds_pad = 0);
 // Table-driven stage 1 + the specialised work-rate stages (k_fused in TABLE mode): any (l, m, taps) whose
 // phase-major table and input tile fit two 512-thread workgroups per CU, standard-profile work-rate
 // stages (37-tap low-pass, pw = 3).  11 025 Hz (l = 832) is the rate this exists for.
@@ -210,7 +224,7 @@ void fused_any_table(uint32_t l, const float *coeff, uint32_t t1, float *table);
 bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, bool pcm16,
                          const CallArgs &call, const SlotPtrs *d_slots, uint64_t max_w, const float *table,
                          const float *h2, const float *h2p /* fused_lowpass_pairs */, float cosphi2, float sinphi,
-                         float inv_sinphi, bool want_gm);
+                         float inv_sinphi, bool want_gm, float gm_slack_scale = 1.f);
 
 // ---- parallel peak picker (apt_kernels_sync.hip) ------------------------------------
 // Each launch covers the recordings of one call (CallArgs by value, slot table in HBM).
@@ -224,12 +238,12 @@ void group_max(hipStream_t s, const float *corr, uint64_t n_corr, GroupMax *gm);
 // re-evaluated from F — strictly (the reference's chain) or, `fast`, from pulse sums, exactly as the
 // front end of that mode did.
 void sync_nodes(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint64_t max_w, uint32_t pw,
-                uint32_t spr, uint32_t md, bool fast, bool use_corr);
+                uint32_t spr, uint32_t md, bool fast, bool use_corr, const LaunchSwitches &sw = LaunchSwitches{});
 // orbit of the picker (direct / pointer doubling, or the sequential walk as fallback): peak
 // list + result record of every recording
 size_t sync_orbit_ws_words(uint64_t w, uint32_t spr);  // uint32 words of scratch it needs
 void sync_orbit(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint32_t spr, uint32_t md,
-                uint32_t pw, int force /* 0 parallel picker, 1 sequential walk */);
+                uint32_t pw, int force /* 0 parallel picker, 1 sequential walk */, const LaunchSwitches &sw = LaunchSwitches{});
 
 // ---- consumers of the pixel rows (apt_kernels_image.hip) ------
 // All take the pixel count from `res` (device) when it is non-null, else `n`; `cap` bounds it

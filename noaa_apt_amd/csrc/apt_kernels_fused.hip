@@ -156,16 +156,11 @@ bool fused_f16_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint3
 // Bound on |a - c| / sum|F| for a = the pulse-sum evaluation and c = the reference's sequential chain of
 // the 38*pw-term sync correlation: gamma(38 pw - 1) + gamma(pw + 18) with gamma(k) = k u / (1 - k u),
 // u = 2^-24, plus 3 % for the rounding of the bound's own arithmetic (the sum of |F|, the product, the
-// two additions that form lo and hi: < 40 u relative).  APTGPU_GM_SLACK_SCALE (tests) widens it so that
-// the picker's exact settlement of open comparisons is exercised on ordinary inputs.
-float fused_gm_slack(uint32_t pw)
+// two additions that form lo and hi: < 40 u relative).  `scale` (APTGPU_GM_SLACK_SCALE, tests; read at plan creation —
+// LaunchSwitches) widens it so that the picker's exact settlement of open comparisons is exercised on ordinary inputs.
+float fused_gm_slack(uint32_t pw, float scale)
 {
-    float scale = 1.f;
-    if (const char *e = std::getenv("APTGPU_GM_SLACK_SCALE")) {
-        const float v = std::strtof(e, nullptr);
-        if (v >= 1.f) scale = v;
-    }
-    return static_cast<float>(38u * pw - 1u + pw + 18u) * 1.03f * 0x1p-24f * 1.0001f * scale;
+    return static_cast<float>(38u * pw - 1u + pw + 18u) * 1.03f * 0x1p-24f * 1.0001f * (scale >= 1.f ? scale : 1.f);
 }
 
 bool fused_fast_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
@@ -174,13 +169,13 @@ bool fused_fast_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint
 }
 
 bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, int mode,
-                     bool pcm16, const CallArgs &call, const FusedParams *d_prm, uint64_t max_w)
+                     bool pcm16, const CallArgs &call, const FusedParams *d_prm, uint64_t max_w, int lds_pad)
 {
     if (call.count == 0 || call.count > static_cast<uint32_t>(kMaxCall)) return false;
     if (pcm16)  // dword loads of sample pairs
         for (uint32_t i = 0; i < call.count; ++i)
             if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 3u) return false;
-    const FusedLaunch a{s, &call, d_prm, max_w, 0};
+    const FusedLaunch a{s, &call, d_prm, max_w, 0, lds_pad};
     if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
         if (mode == kModeF16Taps)  // fp16-tap stage 1: hb is the half2 table of fused_f16_branch_taps
             pcm16 ? fused_launch_48k_f16taps_i16(a) : fused_launch_48k_f16taps_f32(a);

@@ -164,13 +164,15 @@ void fused_any_table(uint32_t l, const float *coeff, uint32_t t1, float *table)
 
 bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, bool pcm16,
                          const CallArgs &call, const SlotPtrs *d_slots, uint64_t max_w, const float *table,
-                         const float *h2, const float *h2p, float cosphi2, float sinphi, float inv_sinphi, bool want_gm)
+                         const float *h2, const float *h2p, float cosphi2, float sinphi, float inv_sinphi, bool want_gm,
+                         float gm_slack_scale)
 {
     Candidate c;
     AnyGeom g;
     size_t lds;
     if (call.count == 0) return true;
     if (!choose(l, m, t1, t2, pw, &c, &g, &lds)) return false;
+    g.gm_slack_scale = gm_slack_scale;
     if (pcm16)
         for (uint32_t i = 0; i < call.count; ++i)
             if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 1u) return false;

@@ -393,7 +393,7 @@ void launch_any(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, ui
                 const float *h2, const float *h2p, float cosphi2, float sinphi, float inv_sinphi, bool want_gm,
                 const AnyGeom &g, size_t lds)
 {
-    const float gm_slack = fused_gm_slack(g.pulse / 2u);
+    const float gm_slack = fused_gm_slack(g.pulse / 2u, g.gm_slack_scale);
     auto kern = k_fused_any<NTHR, KPT, XT, T2C, PWC>;
     // (a per-device property of the function: plans on several devices / threads pass through here)
     constexpr int kMaxDevices = 64;

@@ -18,6 +18,7 @@ struct AnyGeom {
     uint32_t jl_a, jl_b;           // jlim / l and % l: taps of phase p = jl_a + (p < jl_b)
     uint32_t table_in_global;      // the polyphase table does not fit LDS beside the tile: stage 1 reads its rows from HBM / L2
     uint64_t sign[4];              // bit j set <=> sync template[j] = +1 (decode.rs:188-198)
+    float gm_slack_scale;          // APTGPU_GM_SLACK_SCALE as the plan read it (LaunchSwitches), host side only
 };
 
 #define APT_ANY_SHAPE_ARGS                                                                                          \

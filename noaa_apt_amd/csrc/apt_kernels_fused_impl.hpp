@@ -1802,9 +1802,9 @@ void launch_fused_args(const FusedLaunch &a)
     using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), MODE == kModeF16Taps>;
     size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
     if constexpr (Gm::TABLE) lds = std::max<size_t>(a.table_lds_floats, Gm::W_LDS_FLOATS) * sizeof(float);
-    // APTGPU_FUSED_LDS_PAD=bytes (A/B switch, read per launch): more dynamic LDS than the kernel uses = fewer workgroups
+    // APTGPU_FUSED_LDS_PAD=bytes (A/B switch, read at plan creation): more dynamic LDS than the kernel uses = fewer workgroups
     // per CU (2048 takes the 48 kHz kernels from six back to five)
-    if (const char *e = std::getenv("APTGPU_FUSED_LDS_PAD")) lds += static_cast<size_t>(std::max(0, std::atoi(e)));
+    lds += static_cast<size_t>(a.lds_pad > 0 ? a.lds_pad : 0);
     constexpr auto kern = k_fused<L, M, T1, T2, PW, NTHR, XT, MODE>;
     ensure_dynamic_lds<kern>(lds);
     const unsigned tiles = static_cast<unsigned>((a.max_w + Gm::OWN_K - 1) / Gm::OWN_K);

@@ -57,6 +57,7 @@ struct FusedLaunch {
     const FusedParams *prm;    // device-resident parameters of the plan
     uint64_t max_w;            // longest recording of the call, work samples (sizes grid.x)
     size_t table_lds_floats;   // TABLE mode: floats of LDS the table and the input tile take
+    int lds_pad = 0;           // APTGPU_FUSED_LDS_PAD (A/B switch, read at plan creation): more dynamic LDS than the kernel uses
 };
 
 // one function per instantiation, each in its own translation unit

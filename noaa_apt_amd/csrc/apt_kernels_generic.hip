@@ -548,17 +548,32 @@ void orbit_walk(hipStream_t s, const uint64_t *bits, const float *corr, uint64_t
                        peaks, peaks_cap, res);
 }
 
+LaunchSwitches read_launch_switches()
+{
+    LaunchSwitches sw;
+    if (const char *e = std::getenv("APTGPU_GATHER_ITERS")) sw.gather_iters = std::atoi(e);
+    if (const char *e = std::getenv("APTGPU_WORDS_DPP")) sw.words_dpp = e[0] != '0';
+    if (const char *e = std::getenv("APTGPU_ORBIT_LDS")) sw.orbit_lds = e[0] != '0';
+    if (const char *e = std::getenv("APTGPU_ORBIT_THREADS")) sw.orbit_threads = std::atoi(e);
+    if (const char *e = std::getenv("APTGPU_ORBIT_ALG")) sw.orbit_alg = e[0] == '0' ? 0 : 1;
+    if (const char *e = std::getenv("APTGPU_GM_SLACK_SCALE")) {
+        const float v = std::strtof(e, nullptr);
+        if (v >= 1.f) sw.gm_slack_scale = v;
+    }
+    if (const char *e = std::getenv("APTGPU_FUSED_LDS_PAD")) sw.fused_lds_pad = std::max(0, std::atoi(e));
+    return sw;
+}
+
 void gather_rows_call(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint32_t spr, uint32_t pw,
-                      uint32_t max_rows_cap)
+                      uint32_t max_rows_cap, const LaunchSwitches &sw)
 {
     if (call.count == 0) return;
     // The flat form wherever a row is 520 quads (every work rate that is a multiple of 4160 Hz) and the rows buffers are
     // 16-byte aligned: ONE quad per thread measured best beside the front end (pipelined step, 16 recordings per call:
     // 0.843 ms against 0.853 / 0.847 / 0.855 with 2 / 4 / 8 quads per thread and 0.869 with the form below;
-    // profiles/r04_sweeps.txt).  APTGPU_GATHER_ITERS=n (A/B switch, read per launch): n quads per thread, 0 = the form below.
+    // profiles/r04_sweeps.txt).  APTGPU_GATHER_ITERS=n (A/B switch, read at plan creation): n quads per thread, 0 = the form below.
     {
-        const char *e = std::getenv("APTGPU_GATHER_ITERS");
-        const int iters = e ? std::atoi(e) : 1;
+        const int iters = sw.gather_iters;
         bool aligned = true;
         for (uint32_t i = 0; i < call.count; ++i) aligned = aligned && (reinterpret_cast<uintptr_t>(call.rec[i].rows) & 15u) == 0;
         if (iters > 0 && spr / pw == 2080u && spr % pw == 0 && aligned && max_rows_cap > 0) {

@@ -55,6 +55,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cstdlib>
 #include <type_traits>
 
@@ -1120,7 +1122,7 @@ void group_max(hipStream_t s, const float *corr, uint64_t n_corr, GroupMax *gm)
 }
 
 void sync_nodes(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint64_t max_w, uint32_t pw,
-                uint32_t spr, uint32_t md, bool fast, bool use_corr)
+                uint32_t spr, uint32_t md, bool fast, bool use_corr, const LaunchSwitches &sw)
 {
     if (call.count == 0 || max_w <= 38ull * pw) return;
     const uint64_t n_corr = max_w - 38ull * pw;
@@ -1130,8 +1132,7 @@ void sync_nodes(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, ui
     const size_t lds = words_win_ofs(r) + static_cast<size_t>(kNodesWaves) * nodes_window(pw) * sizeof(float);
     const dim3 grid(chunks, call.count);
     const uint32_t wneed = GS + 38u * pw - 1u;
-    const char *e_dpp = std::getenv("APTGPU_WORDS_DPP");  // A/B switch (read per launch: tools/sweep.py flips it between plans)
-    const bool dpp = !(e_dpp && e_dpp[0] == '0');
+    const bool dpp = sw.words_dpp;  // (APTGPU_WORDS_DPP, read at plan creation)
 #define APT_WORDS_LAUNCH(NL, PWC)                                                                                       \
     do {                                                                                                                \
         if (dpp)                                                                                                        \
@@ -1167,29 +1168,49 @@ size_t sync_orbit_ws_words(uint64_t w, uint32_t spr)
     return 4 * node_cap + (node_cap / 32 + 1) + (kc + 2) + (kc + 3) + 64;
 }
 
+// can this device give a workgroup the 128 KB of dynamic LDS the closure-free orbit kernel wants?  Asked once per device
+// (the attribute is a per-device property of the function); where it cannot — an ARCH override, a smaller part — the
+// 24 KB closure form serves every recording
+static bool orbit_all_nodes_available(uint32_t bytes)
+{
+    constexpr int kMaxDevices = 64;
+    static std::atomic<int> state[kMaxDevices];  // 0 unknown, 1 yes, 2 no
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) dev = 0;
+    int st = state[dev].load(std::memory_order_acquire);
+    if (st == 0) {
+        int max_lds = 0;
+        const bool ok = hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess &&
+                        max_lds >= static_cast<int>(bytes) &&
+                        hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sync_orbit_global<kOrbitThreadsMax>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)) == hipSuccess;
+        (void)hipGetLastError();
+        st = ok ? 1 : 2;
+        state[dev].store(st, std::memory_order_release);
+    }
+    return st == 1;
+}
+
 void sync_orbit(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint32_t spr, uint32_t md,
-                uint32_t pw, int force)
+                uint32_t pw, int force, const LaunchSwitches &sw)
 {
     if (call.count == 0) return;
     // force: 0 = parallel picker, 1 = sequential walk over the terminal words
     // 24 KB of LDS for the doubling path's jump tables: a recording's visited nodes (about one per image row plus
     // the seeds) fit unless it is hours long; the kernel falls back to tables in global memory when they do not
     // (APTGPU_ORBIT_LDS=0, tests: always through global memory)
-    const char *e = std::getenv("APTGPU_ORBIT_LDS");
-    const uint32_t kOrbitLdsEntries = (e && e[0] == '0') ? 0u : 12288u;
-    const char *e_nt = std::getenv("APTGPU_ORBIT_THREADS");  // A/B switch (read per launch)
+    const uint32_t kOrbitLdsEntries = sw.orbit_lds ? 12288u : 0u;
     // the default: successors of all nodes + doubling from the root, no breadth-first closure; 128 KB of LDS
     // (recordings whose tables do not fit take the closure path inside the same launch).  APTGPU_ORBIT_ALG=0 (A/B
-    // switch, tests) or APTGPU_ORBIT_LDS=0: the closure path for every recording
-    const char *e_alg = std::getenv("APTGPU_ORBIT_ALG");
-    const int alg = ((e_alg && e_alg[0] == '0') || kOrbitLdsEntries == 0u) ? 0 : 1;
-    if (e_nt && std::atoi(e_nt) == 256) {
+    // switch, tests), APTGPU_ORBIT_LDS=0, or a device without 128 KB of LDS per workgroup: the closure path for every
+    // recording.  (All switches are read at plan creation: LaunchSwitches.)
+    constexpr uint32_t kAllEntries = 65536u;  // uint16 entries: 128 KB
+    const int alg = (sw.orbit_alg == 0 || kOrbitLdsEntries == 0u || !orbit_all_nodes_available(kAllEntries * sizeof(uint16_t))) ? 0 : 1;
+    if (sw.orbit_threads == 256) {
         hipLaunchKernelGGL(k_sync_orbit_global<256>, dim3(call.count), dim3(256), kOrbitLdsEntries * sizeof(uint16_t), s,
                            call, d_slots, spr, md, pw, force == 1 ? 1 : 0, kOrbitLdsEntries, 0);
     } else if (alg == 1) {
-        constexpr uint32_t kAllEntries = 65536u;  // uint16 entries: 128 KB
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sync_orbit_global<kOrbitThreadsMax>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kAllEntries * sizeof(uint16_t)));
         hipLaunchKernelGGL(k_sync_orbit_global<kOrbitThreadsMax>, dim3(call.count), dim3(kOrbitThreadsMax), kAllEntries * sizeof(uint16_t), s,
                            call, d_slots, spr, md, pw, force == 1 ? 1 : 0, kAllEntries, 1);
     } else {

@@ -13,7 +13,7 @@ namespace apt {
 void hip_check(hipError_t e, const char *what)
 {
     if (e != hipSuccess) {
-        throw Error{ErrorKind::Hip, std::string(what) + ": " + hipGetErrorString(e)};
+        throw Error{ErrorKind::Hip, std::string(what) + ": " + hipGetErrorString(e), static_cast<int>(e)};
     }
 }
 
@@ -104,6 +104,7 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     plan->sync = sync;
     plan->max_samples = max_samples;
     plan->max_batch = max_batch;
+    plan->sw = gpu::read_launch_switches();
     if (const char *e = std::getenv("APTGPU_FORCE_WALK")) plan->picker_force = e[0] == '1' ? 1 : 0;
     if (const char *e = std::getenv("APTGPU_PICKER_LDS")) if (e[0] == '1') plan->picker_force = 4;
 
@@ -416,7 +417,7 @@ void aptgpu_plan::upload_slot_table()
         prm.inv_sinphi = inv_sinphi;
         prm.f16_unscale = fused_f16 ? f16_unscale : 0.f;
         prm.want_gm = (sync && work_is_multiple) ? 1 : 0;
-        prm.gm_slack = apt::gpu::fused_gm_slack(pw);
+        prm.gm_slack = apt::gpu::fused_gm_slack(pw, sw.gm_slack_scale);
         if (!d_fused_params.ptr) d_fused_params.alloc(1);
         apt::hip_check(hipMemcpyAsync(d_fused_params.ptr, &prm, sizeof prm, hipMemcpyHostToDevice, stream),
                        "hipMemcpy fused params");
@@ -584,7 +585,7 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
                                   : fused == 3 ? fused_table_front_end(fs, table_geom, kmode, kind == 1, c,
                                                                        d_fused_params.ptr, max_w)
                                                : fused_front_end(fs, l, m, t1, t2, pw, kmode, kind == 1, c,
-                                                                 d_fused_params.ptr, max_w);
+                                                                 d_fused_params.ptr, max_w, sw.fused_lds_pad);
                     if (!ok)
                         throw apt::Error{apt::ErrorKind::Internal, "fused front end: no kernel for this geometry"};
                 });
@@ -606,7 +607,7 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
                 timed("fused_front_end", [&] {
                     if (!fused_any_front_end(cur, l, m, t1, t2, pw, kind == 1, c, d_slots.ptr, max_w, d_taps_any.ptr,
                                              d_taps_lowpass.ptr, d_taps_lowpass_pairs.ptr, cosphi2, sinphi, inv_sinphi,
-                                             want_sync))
+                                             want_sync, sw.gm_slack_scale))
                         throw apt::Error{apt::ErrorKind::Internal, "fused front end: no kernel for this geometry"};
                 });
             });
@@ -694,10 +695,10 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
             for_chunks(live, [&](const CallArgs &c, uint64_t max_w, uint32_t) {
                 if (!(skip & 1))
                     for (int r = 0; r < rep_w; ++r)
-                        timed("sync_nodes", [&] { sync_nodes(cur, c, d_slots.ptr, max_w, pw, spr, md, use_fused && fused_fast, !use_fused); });
+                        timed("sync_nodes", [&] { sync_nodes(cur, c, d_slots.ptr, max_w, pw, spr, md, use_fused && fused_fast, !use_fused, sw); });
                 if (!(skip & 2))
                     for (int r = 0; r < rep_o; ++r)
-                        timed("sync_orbit", [&] { sync_orbit(cur, c, d_slots.ptr, spr, md, pw, picker_force); });
+                        timed("sync_orbit", [&] { sync_orbit(cur, c, d_slots.ptr, spr, md, pw, picker_force, sw); });
             });
             gather_wanted = !(skip & 4);
         }
@@ -705,7 +706,7 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
         if (gather_wanted)
             for (int r = 0; r < gather_reps; ++r)
                 for_chunks(live, [&](const CallArgs &c, uint64_t, uint32_t max_cap) {
-                    timed("gather_rows", [&] { gather_rows_call(cur, c, d_slots.ptr, spr, pw, max_cap); });
+                    timed("gather_rows", [&] { gather_rows_call(cur, c, d_slots.ptr, spr, pw, max_cap, sw); });
                 });
     } else {
         // decode.rs:135-159 — crop to whole rows, resample_with_filter(NoFilter)

@@ -147,6 +147,7 @@ struct aptgpu_plan {
     // 3 k_fused with the table-driven stage 1 (run-time l / m / taps, specialised work-rate stages)
     int fused = 0;
     apt::gpu::TableGeom table_geom{};
+    apt::gpu::LaunchSwitches sw{};  // the A/B switches of the launch wrappers as the environment had them at plan creation
     int picker_force = 0;  // 0 parallel picker; APTGPU_FORCE_WALK=1 -> 1 (the sequential fallback)
 
     apt::DeviceBuffer<float> d_taps_resample, d_taps_lowpass, d_one, d_taps_branch, d_taps_lowpass_pairs, d_taps_any;

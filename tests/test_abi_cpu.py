@@ -32,6 +32,8 @@ def test_every_declared_symbol_is_exported(L):
 
 def test_version_and_device_count(L):
     assert apt.version().startswith("aptgpu")
+    hdr = open(os.path.join(ROOT, "include", "aptgpu.h")).read()
+    assert apt.abi_version() == int(re.search(r"#define APTGPU_ABI_VERSION (\d+)", hdr).group(1))
     assert apt.device_count() >= 0
 
 
@@ -39,6 +41,18 @@ def test_struct_layouts_match_header(L):
     # sizes the C side static_asserts / relies on
     assert ctypes.sizeof(apt.Result) == 32
     assert ctypes.sizeof(apt.KernelTime) == 64
+    # aptgpu_batch_stats: struct_size + reserved in front of the 0.1.0 fields (include/aptgpu.h)
+    assert ctypes.sizeof(apt.BatchStats) == 88 and apt.BatchStats.struct_size.offset == 0 and apt.BatchStats.seconds.offset == 8
+
+
+def test_no_environment_variable_redirects_the_loader(L, monkeypatch):
+    """the shipped module loads the in-tree product library, whatever APTGPU_LIB says; the probe build is
+    selected in code (use_library), before the first load, and announced on stderr."""
+    monkeypatch.setenv("APTGPU_LIB", "/nonexistent/libevil.so")
+    import importlib
+    assert apt.lib_path().endswith(os.path.join("noaa_apt_amd", "libaptgpu.so"))
+    with pytest.raises(RuntimeError):
+        apt.use_library("/tmp/other.so")  # the library is loaded already (fixture L)
 
 
 @pytest.mark.parametrize("kind,cut,atten,dw", [

@@ -237,3 +237,60 @@ def test_worker_affinity_lookup_on_this_host():
     bdf, node, cpus = apt.host_affinity(0)
     assert len(bdf.split(":")) == 3, bdf
     assert (node < 0 and cpus == "") or (node >= 0 and cpus != "")
+
+
+def _rank_decode(rank, world, port, recs, out_dir):
+    """One rank of a two-process job on ONE GPU (the torchrun shape minus the second device): its shard of the
+    recordings through aptgpu_decode_batch with two worker entries on device 0, its own process, HIP context and
+    session cache; rows to files, bookkeeping over gloo."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from noaa_apt_amd import shard
+        mine = shard.my_shard([r.size for r in recs], rank, world)
+        dist.barrier()
+        got, results, stats = apt.decode_batch(apt.Context(device=0), apt.Settings(), [recs[i] for i in mine],
+                                               apt.Rate.hz(48000), True, devices=(0, 0), recordings_per_call=2,
+                                               return_stats=True)
+        for i, g in zip(mine, got):
+            assert not isinstance(g, Exception), (rank, i, g)
+            np.save(os.path.join(out_dir, f"rows_{i}.npy"), g)
+        elapsed, total = shard.reduce_job(1.0 + rank, float(stats.samples))
+        counts = shard.gather_counts(len(mine))
+        info = apt.cache_info()
+        np.save(os.path.join(out_dir, f"meta_{rank}.npy"),
+                np.array([elapsed, total, counts[0], counts[1], stats.workers, stats.sessions_created, len(mine)], np.float64))
+        del info
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_share_one_gpu(oracle, tmp_path):
+    """SURVEY.md §8(e) on a one-GPU box: two spawned ranks, each a process with its own HIP context and session cache,
+    decode disjoint shards on the same device at the same time; every recording's rows bit-identical to the oracle's."""
+    import socket
+    import torch.multiprocessing as mp
+    recs = [synth_apt(48000, 11 + (5 * i) % 6, 700 + i, ppm=5.0 * i - 10.0) for i in range(7)]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rank_decode, args=(r, 2, port, recs, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    metas = [np.load(tmp_path / f"meta_{r}.npy") for r in range(2)]
+    for m in metas:
+        assert m[0] == 2.0                                   # MAX over ranks of (1.0, 2.0)
+        assert m[1] == float(sum(r.size for r in recs))      # whole-job samples
+        assert m[2] + m[3] == len(recs) and m[4] == 2        # both shards counted; two workers per rank
+    for i, x in enumerate(recs):
+        got = np.load(tmp_path / f"rows_{i}.npy")
+        assert _same(got, oracle.decode(x, 48000, True)), f"recording {i}"

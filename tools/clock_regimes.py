@@ -9,7 +9,7 @@ SMU runs the XCDs at 2.0 GHz under the pipeline (tools/power_regimes.py, noaa_ap
 Kept for the record and for the per-regime front-end durations it logs.  One process per regime (the probe library latches APTGPU_DEBUG_SKIP on first use):
 
     python tools/clock_regimes.py --regime isolated      # one call at a time, host synchronisation after each
-    APTGPU_LIB=noaa_apt_amd/libaptgpu_probe.so APTGPU_DEBUG_SKIP=7 python tools/clock_regimes.py --regime back_to_back
+    APTGPU_PROBE_LIB=noaa_apt_amd/libaptgpu_probe.so APTGPU_DEBUG_SKIP=7 python tools/clock_regimes.py --regime back_to_back
     python tools/clock_regimes.py --regime pipeline      # the bench's timed region: three calls in flight
     python tools/clock_regimes.py --regime idle          # the sampler alone
 
@@ -41,6 +41,8 @@ def main():
 
     import torch
     import noaa_apt_amd as apt
+    if os.environ.get("APTGPU_PROBE_LIB"):  # (the probe build: APTGPU_DEBUG_* switches; timing only)
+        apt.use_library(os.environ["APTGPU_PROBE_LIB"])
     from noaa_apt_amd.testing.synth import synth_apt
 
     probe = C.CDLL(os.path.join(ROOT, "tools", "ubench", "libclockprobe.so"))

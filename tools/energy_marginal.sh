@@ -5,10 +5,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; O=$R/gpurun_out/energy; mkdir -p $O
 P=$R/noaa_apt_amd/libaptgpu_probe.so
 python3 -c "import torch" 2>/dev/null
 echo "## base (probe library, nothing repeated)" > $O/energy_marginal.txt
-APTGPU_LIB=$P python3 tools/sweep.py --power --inputs 16 --steps 800 --warmup 50 --configs strict:16:3 >> $O/energy_marginal.txt 2>$O/e0
+APTGPU_PROBE_LIB=$P python3 tools/sweep.py --power --inputs 16 --steps 800 --warmup 50 --configs strict:16:3 >> $O/energy_marginal.txt 2>$O/e0
 for K in WORDS ORBIT GATHER; do
 echo "## APTGPU_DEBUG_REPEAT_$K=2" >> $O/energy_marginal.txt
-env APTGPU_LIB=$P APTGPU_DEBUG_REPEAT_$K=2 python3 tools/sweep.py --power --inputs 16 --steps 800 --warmup 50 --configs strict:16:3 >> $O/energy_marginal.txt 2>>$O/e0
+env APTGPU_PROBE_LIB=$P APTGPU_DEBUG_REPEAT_$K=2 python3 tools/sweep.py --power --inputs 16 --steps 800 --warmup 50 --configs strict:16:3 >> $O/energy_marginal.txt 2>>$O/e0
 done
 echo "## PCM16 payloads as input (product library)" >> $O/energy_marginal.txt
 python3 tools/sweep.py --power --pcm16 --inputs 16 --steps 800 --warmup 50 --configs strict:16:3 >> $O/energy_marginal.txt 2>>$O/e0

@@ -7,8 +7,8 @@ python3 bench.py --no-extras --no-cpu-baseline --no-single-launch > $O/bench_str
 python3 bench.py --no-extras --no-cpu-baseline --no-single-launch --mode fast > $O/bench_fast_600.json 2> $O/e3
 # energy per call by what runs: the whole pipeline, one call at a time, the front ends alone, the chain alone
 python3 tools/sweep.py --power --inputs 16 --steps 1200 --warmup 50 --configs "strict:16:3,strict:16:1,fast:16:3" > $O/sweep_power.txt 2> $O/e4
-APTGPU_LIB=$R/noaa_apt_amd/libaptgpu_probe.so APTGPU_DEBUG_SKIP=7 python3 tools/sweep.py --power --inputs 16 --steps 1200 --warmup 50 --configs "strict:16:3,fast:16:3" > $O/sweep_power_front_only.txt 2> $O/e5
-APTGPU_LIB=$R/noaa_apt_amd/libaptgpu_probe.so APTGPU_DEBUG_REPEAT_FRONT=2 python3 tools/sweep.py --power --inputs 16 --steps 800 --warmup 50 --configs "strict:16:3" > $O/sweep_power_front_twice.txt 2> $O/e6
+APTGPU_PROBE_LIB=$R/noaa_apt_amd/libaptgpu_probe.so APTGPU_DEBUG_SKIP=7 python3 tools/sweep.py --power --inputs 16 --steps 1200 --warmup 50 --configs "strict:16:3,fast:16:3" > $O/sweep_power_front_only.txt 2> $O/e5
+APTGPU_PROBE_LIB=$R/noaa_apt_amd/libaptgpu_probe.so APTGPU_DEBUG_REPEAT_FRONT=2 python3 tools/sweep.py --power --inputs 16 --steps 800 --warmup 50 --configs "strict:16:3" > $O/sweep_power_front_twice.txt 2> $O/e6
 python3 tools/sweep.py --power --inputs 16 --steps 400 --warmup 50 --rate 44100 --configs "strict:16:3" > $O/sweep_power_44100.txt 2> $O/e7
 for f in $O/bench*.json; do python3 - "$f" <<'PY'
 import json,sys

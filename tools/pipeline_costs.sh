@@ -25,4 +25,4 @@ V="$V,strict:16:3:APTGPU_FRONT_STREAM=1;APTGPU_CHAIN_CUS=64;APTGPU_FRONT_EXCL=1"
 V="$V,strict:16:2"
 V="$V,strict:16:4"
 V="$V,strict:16:3"
-APTGPU_LIB=$R/noaa_apt_amd/libaptgpu_probe.so timeout 600 python tools/sweep.py --configs "$V" --steps 200 --warmup 20 --inputs 16
+APTGPU_PROBE_LIB=$R/noaa_apt_amd/libaptgpu_probe.so timeout 600 python tools/sweep.py --configs "$V" --steps 200 --warmup 20 --inputs 16

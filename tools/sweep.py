@@ -37,6 +37,8 @@ def main():
 
     import torch
     import noaa_apt_amd as apt
+    if os.environ.get("APTGPU_PROBE_LIB"):  # (the probe build: APTGPU_DEBUG_* switches; timing only)
+        apt.use_library(os.environ["APTGPU_PROBE_LIB"])
     from noaa_apt_amd.testing.synth import synth_apt
 
     dev = torch.device("cuda", 0)
