@@ -66,8 +66,10 @@ def make_image(n_rows, seed):
 
 
 def synth_apt(rate_hz, seconds, seed, *, noise_sigma=400.0, amplitude=20000.0, ppm=0.0,
-              start_px=None, phase=None, chunk=1 << 22):
-    """Return (signal_f32, n_samples).  Deterministic in (rate, seconds, seed, kwargs)."""
+              start_px=None, phase=None, chunk=1 << 22, image=None):
+    """Return the signal (f32, int16-valued).  Deterministic in (rate, seconds, seed, kwargs).
+    image: rows x 2080 pixel values 0..255 to transmit instead of make_image()'s frame (repeated as often as the
+    duration needs) — e.g. rows of an image the reference itself decoded (tests/test_reference_image_structure.py)."""
     n = int(round(rate_hz * seconds))
     rng = np.random.default_rng(seed)
     if start_px is None:
@@ -76,7 +78,12 @@ def synth_apt(rate_hz, seconds, seed, *, noise_sigma=400.0, amplitude=20000.0, p
         phase = float(rng.uniform(0, 2 * np.pi))
     px_per_sample = FINAL_RATE / (rate_hz * (1.0 + ppm * 1e-6))
     n_rows = int(np.ceil((n * px_per_sample + start_px) / PX_PER_ROW)) + 2
-    img = make_image(n_rows, seed + 7919).reshape(-1)
+    if image is None:
+        img = make_image(n_rows, seed + 7919).reshape(-1)
+    else:
+        src = np.asarray(image, dtype=np.float32)
+        assert src.ndim == 2 and src.shape[1] == PX_PER_ROW, src.shape
+        img = np.tile(src, ((n_rows + src.shape[0] - 1) // src.shape[0], 1))[:n_rows].reshape(-1)
     out = np.empty(n, dtype=np.float32)
     w = 2.0 * np.pi * CARRIER_HZ / rate_hz
     for s in range(0, n, chunk):
