@@ -239,7 +239,7 @@ __host__ __device__ constexpr bool sync_plus(int j)
 // that walked the tiles with a fixed grid and kept the NEXT tile's input in registers while the stages ran was measured
 // in rounds 2 and 3 and dropped: slower in every mode)
 template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
-__global__ void __launch_bounds__(NTHR, M < 0 ? ((NTHR > 512 ? 1 : NTHR > 256 ? 2 : (T1 == 1 ? (M == -1 ? 3 : 4) : T2 == 43 ? 4 : M == -4 ? 5 : M == -2 ? 4 : 3)) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs; the fast profile's and two branches per thread: four, <= 128; four branches: five, <= 96), two 512-thread or one 1024-thread (<= 128) workgroups per CU */
+__global__ void __launch_bounds__(NTHR, M < 0 ? ((NTHR > 512 ? 1 : NTHR > 256 ? 2 : (T1 == 1 ? (M == -1 ? 3 : 4) : T2 == 43 ? 4 : M == -4 ? 5 : M == -2 ? 5 : 3)) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs; the fast profile's: four, <= 128; two or four branches per thread: five, <= 96), two 512-thread or one 1024-thread (<= 128) workgroups per CU */
                                      : M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
                                                /* specialised: as many workgroups as the CU's 160 KB of LDS hold (48 kHz SPLIT: 5, 96 kHz: 3) */
                                                : (FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), MODE == kModeF16Taps>::WGS_PER_CU * NTHR + 255) / 256)
@@ -540,14 +540,22 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 }
             }
         }
-        // its taps -> registers (16-byte loads from the L2-resident table; in flight across the barrier).  The branches
-        // are worked through one after the other; with four of them the registers hold two at a time — the taps of
-        // branch q + 2 are requested when branch q is done (all four: 80 registers, three waves per SIMD).
+        // its taps -> registers (16-byte loads from the L2-resident table; the first ones in flight across the barrier).
+        // The branches are worked through one after the other.
         typedef float f4v __attribute__((ext_vector_type(4)));
-        constexpr int NTB = NQ > 2 ? 2 : NQ;
-        f4v tq[NTB][TPPM / 4];
-        auto load_taps = [&](auto qq) {
-            constexpr int q = decltype(qq)::value;
+        // The taps of a branch are held one SEGMENT of SEG taps at a time, in two ping-pong buffers: the segment after
+        // next is requested when a segment has been used up.  One branch per thread: the whole branch is one segment,
+        // loaded before the first multiplication (one buffer).  Two branches (tpp <= 36): segments of 20 taps — 40
+        // registers where both branches' rows took 72.  Four / eight: a branch per segment.
+        constexpr int SEG = NQ == 2 ? 20 : TPPM;
+        constexpr int SPB = (TPPM + SEG - 1) / SEG;      // segments per branch
+        constexpr int NSEG = NQ * SPB;
+        constexpr int NTB = NSEG > 1 ? 2 : 1;
+        f4v tq[NTB][SEG / 4];
+        static_assert(SEG % 4 == 0 && TPPM % 4 == 0, "segments of whole quads");
+        auto load_taps = [&](auto ss) {
+            constexpr int sidx = decltype(ss)::value;
+            constexpr int q = sidx / SPB, k = sidx % SPB;
             // (exact lists: the thread-order copy — quad e of this thread's branch q is element e * NTHR + tid of its
             // [tpp / 4][NTHR] block, a wave's load 1 KB of consecutive memory; else its row of the phase-major table)
             const uint32_t tt_off = tp->tab.tt_off;  // (0: no such copy)
@@ -558,8 +566,12 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             // (quads past the row's end are never multiplied — the tap loop stops at jl_a <= tpp — and are not loaded: a
             // wave-uniform test per quad; as a select per register it cost a v_cndmask per tap)
 #pragma unroll
-            for (int e = 0; e < TPPM / 4; ++e)
-                if (static_cast<uint32_t>(4 * e) < tpp) tq[q % NTB][e] = row[static_cast<size_t>(e) * estep];
+            for (int e = 0; e < SEG / 4; ++e) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int eq = k * (SEG / 4) + e;  // quad of the branch
+                if (eq < TPPM / 4 && static_cast<uint32_t>(4 * eq) < tpp) tq[sidx % NTB][e] = row[static_cast<size_t>(eq) * estep];
+            }
         };
         if constexpr (!STREAM) static_for<0, NTB>(load_taps);
         __syncthreads();
@@ -646,7 +658,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             };
             auto tap = [&](auto ii) {
                 constexpr int i = decltype(ii)::value;
-                const f4v q4 = tq[q % NTB][i / 4];
+                const f4v q4 = tq[(q * SPB + i / SEG) % NTB][(i % SEG) / 4];
                 const float t = (i & 3) == 0 ? q4.x : (i & 3) == 1 ? q4.y : (i & 3) == 2 ? q4.z : q4.w;
                 if constexpr (FAST) {
 #pragma unroll
@@ -673,6 +685,14 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                     tap(ee);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                // a segment's last tap is behind us (or was never needed): its buffer takes the segment after next
+                if constexpr ((i0 + 1) % SEG == 0 || i0 + 1 == TPPM) {
+                    constexpr int sidx = q * SPB + i0 / SEG;
+                    if constexpr (sidx + NTB < NSEG) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_taps(std::integral_constant<int, sidx + NTB>{});
+                    }
+                }
             });
             // the predicated last tap, read from the table again (a run-time index)
             if (phq[q] < jl_b) {
@@ -686,14 +706,20 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                     else acc[q][jj] = acc[q][jj] + (f2){t, t} * xp[jj];
                 }
             }
-            if constexpr (!STREAM && q + NTB < NQ) {
-                __builtin_amdgcn_sched_barrier(0);
-                load_taps(std::integral_constant<int, q + NTB>{});
-            }
+
             });
         }
         __syncthreads();  // everyone is done with the input tile: R may land on it
         if (act) {
+            // (wave-uniform: every output of every slot lies inside the tile — l = 208, 416, 832 — and exists: plain stores)
+            const bool plain = interior && static_cast<uint32_t>(NWIN) * S <= static_cast<uint32_t>(Gm::TILE_K);
+            if (plain) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                    for (int a = 0; a < NWIN; ++a)
+                        P[static_cast<int>(u_slot + static_cast<uint32_t>(q) * SQ) + a * static_cast<int>(S)] = (a & 1) ? acc[q][a / 2].y : acc[q][a / 2].x;
+            } else {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
 #pragma unroll
@@ -703,6 +729,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                     // (outputs before the recording or at / past its end: zero; an interior tile has none)
                     if (idx < Gm::TILE_K) P[idx] = (interior || (idx >= k_lo && idx < k_hi)) ? val : 0.f;
                 }
+            }
             }
         }
         __syncthreads();
