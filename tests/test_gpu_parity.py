@@ -298,7 +298,7 @@ def test_fused_specialisations_are_used(ctx):
     for rate, profile, want in ((48000, "standard", 1), (96000, "standard", 1), (44100, "standard", 4),
                                 (11025, "standard", 4), (8000, "standard", 4), (22050, "standard", 4),
                                 (48000, "fast", 4), (48000, "slow", 1), (96000, "fast", 2), (16000, "fast", 4),
-                                (11025, "fast", 2), (96000, "slow", 2), (24960, "standard", 0)):
+                                (11025, "fast", 2), (96000, "slow", 1), (24960, "standard", 0)):
         _, st = apt.decode(ctx, apt.Settings.profile(profile), synth_apt(rate, 11, 3), apt.Rate.hz(rate),
                            True, return_stats=True)
         assert st.fused == want, (rate, profile)
@@ -455,6 +455,7 @@ PROFILE_CASES = [  # (rate, seconds, profile, fused): the fast and slow profiles
     (44100, 14, "fast", 4), (22050, 20, "fast", 4),
     # round 5: the slow profile at the sound-card rates — 197 taps per branch streamed from the table (l = 208 / 416 / 832)
     (44100, 14, "slow", 4), (22050, 20, "slow", 4), (11025, 30, "slow", 4), (44100, 41, "slow", 4),
+    (96000, 12, "slow", 1),    # round 5: SPLIT stage 1 for 13 / 60 with 5565 taps
 ]
 
 
