@@ -341,7 +341,7 @@ bool phase_geom(uint32_t threads, uint32_t nq, uint32_t l, uint32_t m, uint32_t 
     g.tpp = phase_tpp(l, t1, stream);
     // outputs between a branch's consecutive outputs: as many whole periods of l as the threads hold (nq = 1), or l
     const uint32_t stride = nq == 1 ? l * (threads / l) : l;
-    if ((tile + stride - 1) / stride > kPhaseOutputs / nq) return false;
+    if ((tile + stride - 1) / stride > std::max(1u, kPhaseOutputs / nq)) return false;
     g.step_r = stride;
     g.step_q = static_cast<uint32_t>(static_cast<uint64_t>(stride) * m / l);  // exact: l divides stride
     // paired input tile: kPhaseOutputs / nq / 2 regions of off_x f2 entries — a branch's window starts at most
@@ -350,7 +350,7 @@ bool phase_geom(uint32_t threads, uint32_t nq, uint32_t l, uint32_t m, uint32_t 
     // (the tile loader covers a region in 1024 / threads rounds; the fast profile's forms with four / eight branches per
     // thread — one or two regions only — in nine)
     if (g.off_x > ((t2 == 43 && nq > 2) ? 2304u : 1024u)) return false;
-    g.xt = (kPhaseOutputs / nq / 2) * 2 * g.off_x;
+    g.xt = std::max(1u, kPhaseOutputs / nq / 2) * 2 * g.off_x;  // (sixteen branches: one region whose second half stays zero)
     // LDS: three 256-thread workgroups (53 KB each), two 512-thread ones (80 KB) or one of 1024 threads per CU
     if (g.xt > (threads == 256 ? 13600u : threads == 512 ? 20480u : 36000u)) return false;
     g.jl_a = g.jlim / l;
@@ -390,7 +390,7 @@ bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uin
     // workgroups), the fast profile's (256 threads, one branch)
     if (t2 == 43 && pw == 4)
         return phase_geom(256, 1, l, m, t1, t2, pw, geom) || phase_geom(256, 4, l, m, t1, t2, pw, geom) ||
-               phase_geom(256, 8, l, m, t1, t2, pw, geom);
+               phase_geom(256, 8, l, m, t1, t2, pw, geom) || phase_geom(256, 16, l, m, t1, t2, pw, geom);
     // the slow profile's (61-tap low-pass, pixel width 5): its resampling filters (197 taps per branch at the sound-card
     // rates) do not fit the registers — the streamed form
     if (t2 == 61 && pw == 5)
@@ -568,6 +568,7 @@ bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, uint32_t t2, ui
         if (wide || huge) return false;
         if (geom.nq == 4) pcm16 ? fused_launch_phase4_fastp_i16(a) : fused_launch_phase4_fastp_f32(a);
         else if (geom.nq == 8) pcm16 ? fused_launch_phase8_fastp_i16(a) : fused_launch_phase8_fastp_f32(a);
+        else if (geom.nq == 16) pcm16 ? fused_launch_phase16_fastp_i16(a) : fused_launch_phase16_fastp_f32(a);
         else return false;
         return true;
     }

@@ -393,10 +393,13 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         // fits the workgroup (44 100 Hz: l = 208), NQ = 2 / 4 where l itself is two / four times too long for one slot
         // per thread (22 050 Hz: l = 416, 11 025 Hz: l = 832 — until round 5 512- and 1024-thread workgroups at two / one
         // per CU, and the table-driven stage 1): the same 256-thread kernel at three workgroups per CU for all of them.
-        constexpr int NB = 16;     // outputs per thread (NB / NQ >= ceil(TILE_K / S): checked by fused_phase_supported)
         constexpr int NQ = -M;     // branches per thread
+        // sixteen branches (l = 3328: the fast profile at 11 025 Hz, one output per branch and tile): the arithmetic stays
+        // in pairs, the pair's second output — a tile further on — a phantom that is neither loaded for nor stored
+        constexpr bool HALF = NQ == 16;
+        constexpr int NB = HALF ? 32 : 16;  // outputs per thread (NB / NQ >= ceil(TILE_K / S): checked by fused_phase_supported)
         constexpr int NWIN = NB / NQ, NREG = NWIN / 2;  // outputs per branch; regions of the paired tile
-        static_assert(NQ == 1 || NQ == 2 || NQ == 4 || NQ == 8, "one, two, four or eight branches per thread");
+        static_assert(NQ == 1 || NQ == 2 || NQ == 4 || NQ == 8 || NQ == 16, "one, two, four, eight or sixteen branches per thread");
         // T1 == 1 (unused otherwise in this mode): the STREAMED form for filters too long for the registers (the slow
         // profile: 197 taps per branch) — a branch's taps are fetched from the table sixteen at a time while the previous
         // sixteen are in use, instead of all of them before the first multiplication
@@ -482,7 +485,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             const XT *xt0 = x + xs0;    // only dereferenced inside [x_lo, x_hi)
             const int x_lo = rel(-xs0), x_hi = rel(n - xs0);
             XT za[NREG][ZROUNDS], zb[NREG][ZROUNDS];
-            if (x_lo <= 0 && x_hi >= static_cast<int>((NWIN - 1) * dq + ZR)) {
+            if (x_lo <= 0 && x_hi >= static_cast<int>((HALF ? 0 : NWIN - 1) * dq + ZR)) {
                 // interior tile (wave-uniform): every sample exists.  A scalar base per region half, advanced in scalar
                 // registers (the empty asm keeps the steps from being folded into per-lane 64-bit adds, as in load_tile),
                 // plus the lane's 32-bit byte offset — the guarded form below spends ten VALU instructions per sample
@@ -512,7 +515,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                             za[jj][rr] = *(gx_ptr)(sb + voff);
                             sb += dqb;
                             asm volatile("" : "+s"(sb));
-                            zb[jj][rr] = *(gx_ptr)(sb + voff);
+                            if constexpr (!HALF) zb[jj][rr] = *(gx_ptr)(sb + voff);
                             sb += dqb;
                             asm volatile("" : "+s"(sb));
                         }
@@ -527,7 +530,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                     const int ia = static_cast<int>(static_cast<uint32_t>(2 * jj) * dq + s_in);
                     const int ib = ia + static_cast<int>(dq);
                     za[jj][rr] = (s_in < ZR && ia >= x_lo && ia < x_hi) ? xt0[ia] : XT(0);
-                    zb[jj][rr] = (s_in < ZR && ib >= x_lo && ib < x_hi) ? xt0[ib] : XT(0);
+                    zb[jj][rr] = (!HALF && s_in < ZR && ib >= x_lo && ib < x_hi) ? xt0[ib] : XT(0);
                 }
             }
             }
@@ -712,18 +715,19 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         __syncthreads();  // everyone is done with the input tile: R may land on it
         if (act) {
             // (wave-uniform: every output of every slot lies inside the tile — l = 208, 416, 832 — and exists: plain stores)
-            const bool plain = interior && static_cast<uint32_t>(NWIN) * S <= static_cast<uint32_t>(Gm::TILE_K);
+            constexpr int NST = HALF ? 1 : NWIN;  // outputs of a branch that exist
+            const bool plain = interior && static_cast<uint32_t>(NST) * S <= static_cast<uint32_t>(Gm::TILE_K);
             if (plain) {
 #pragma unroll
                 for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                    for (int a = 0; a < NWIN; ++a)
+                    for (int a = 0; a < NST; ++a)
                         P[static_cast<int>(u_slot + static_cast<uint32_t>(q) * SQ) + a * static_cast<int>(S)] = (a & 1) ? acc[q][a / 2].y : acc[q][a / 2].x;
             } else {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
 #pragma unroll
-                for (int a = 0; a < NWIN; ++a) {
+                for (int a = 0; a < NST; ++a) {
                     const int idx = static_cast<int>(u_slot + static_cast<uint32_t>(q) * SQ) + a * static_cast<int>(S);
                     const float val = (a & 1) ? acc[q][a / 2].y : acc[q][a / 2].x;
                     // (outputs before the recording or at / past its end: zero; an interior tile has none)

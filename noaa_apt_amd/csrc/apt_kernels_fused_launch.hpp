@@ -114,6 +114,8 @@ void fused_launch_phase4_fastp_f32(const FusedLaunch &a);
 void fused_launch_phase4_fastp_i16(const FusedLaunch &a);
 void fused_launch_phase8_fastp_f32(const FusedLaunch &a);
 void fused_launch_phase8_fastp_i16(const FusedLaunch &a);
+void fused_launch_phase16_fastp_f32(const FusedLaunch &a);  // (11 025 Hz: l = 3328)
+void fused_launch_phase16_fastp_i16(const FusedLaunch &a);
 // ... the slow profile's work-rate stages (61-tap low-pass, pixel width 5), taps streamed from the table (197 per branch at
 // 44 100 / 22 050 / 11 025 Hz: l = 208 / 416 / 832, m = 441)
 void fused_launch_phase_slowp_f32(const FusedLaunch &a);

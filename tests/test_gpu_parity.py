@@ -298,7 +298,7 @@ def test_fused_specialisations_are_used(ctx):
     for rate, profile, want in ((48000, "standard", 1), (96000, "standard", 1), (44100, "standard", 4),
                                 (11025, "standard", 4), (8000, "standard", 4), (22050, "standard", 4),
                                 (48000, "fast", 4), (48000, "slow", 1), (96000, "fast", 2), (16000, "fast", 4),
-                                (11025, "fast", 2), (96000, "slow", 1), (24960, "standard", 0)):
+                                (11025, "fast", 4), (96000, "slow", 1), (24960, "standard", 0)):
         _, st = apt.decode(ctx, apt.Settings.profile(profile), synth_apt(rate, 11, 3), apt.Rate.hz(rate),
                            True, return_stats=True)
         assert st.fused == want, (rate, profile)
@@ -453,6 +453,7 @@ PROFILE_CASES = [  # (rate, seconds, profile, fused): the fast and slow profiles
     (16000, 30, "fast", 4), (32000, 16, "fast", 4), (8000, 50, "fast", 4), (12000, 40, "fast", 4), (24000, 20, "fast", 4),
     # round 5: four / eight branches per thread in front of the fast profile's stages (l = 832 / 1664)
     (44100, 14, "fast", 4), (22050, 20, "fast", 4),
+    (11025, 30, "fast", 4), (11025, 61, "fast", 4),   # l = 3328: sixteen branches per thread, one output each per tile
     # round 5: the slow profile at the sound-card rates — 197 taps per branch streamed from the table (l = 208 / 416 / 832)
     (44100, 14, "slow", 4), (22050, 20, "slow", 4), (11025, 30, "slow", 4), (44100, 41, "slow", 4),
     (96000, 12, "slow", 1),    # round 5: SPLIT stage 1 for 13 / 60 with 5565 taps
@@ -479,7 +480,7 @@ def test_profile_kernels_ragged_batched_pcm16_and_nonfinite(oracle):
     recordings that end around the tile boundaries."""
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda:0")
-    for profile, rate in (("slow", 48000), ("fast", 48000), ("slow", 44100), ("fast", 44100), ("slow", 11025), ("fast", 22050)):
+    for profile, rate in (("slow", 48000), ("fast", 48000), ("slow", 44100), ("fast", 44100), ("slow", 11025), ("fast", 22050), ("fast", 11025)):
         s = apt.Settings.profile(profile)
         os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
                                            "resample_cutout", "demodulation_atten")}
