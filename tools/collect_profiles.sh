@@ -64,8 +64,14 @@ done
 (cd $R && python bench.py --no-extras --profile slow > $O/bench_profile_slow.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --profile fast --mode fast > $O/bench_profile_fast_fastmode.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --profile slow --mode fast > $O/bench_profile_slow_fastmode.json 2>> $O/bench_strict.err)
-(cd $R && python bench.py --no-extras --profile fast --rate 11025 > $O/bench_profile_fast_11025.json 2>> $O/bench_strict.err)
-(cd $R && python bench.py --no-extras --profile slow --rate 44100 --steps 60 > $O/bench_profile_slow_44100.json 2>> $O/bench_strict.err)
+# the stock profiles at the rates recordings come in (round 5: every combination on a k_fused kernel but fast x 96 kHz)
+for PR in "fast 11025" "fast 44100" "fast 96000" "slow 11025" "slow 44100" "slow 96000"; do
+  set -- $PR
+  (cd $R && python bench.py --no-extras --no-cpu-baseline --profile $1 --rate $2 --steps 100 > $O/bench_profile_$1_$2.json 2>> $O/bench_strict.err)
+done
+(cd $R && python bench.py --no-extras --no-cpu-baseline --rate 44100 --mode fast > $O/bench_44100_fast.json 2>> $O/bench_strict.err)
+(cd $R && python bench.py --no-extras --no-cpu-baseline --rate 22050 --mode fast > $O/bench_22050_fast.json 2>> $O/bench_strict.err)
+(cd $R && python bench.py --no-extras --no-cpu-baseline --rate 11025 --mode fast > $O/bench_11025_fast.json 2>> $O/bench_strict.err)
 (cd $R && python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras > $O/bench_torchrun_n1.json 2> $O/bench_torchrun.err)
 fi
 ls $O

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/install_profiles.sh [round]: copy the summaries tools/collect_profiles.sh left under gpurun_out/prof/ into
 # profiles/ under this round's names (what bench.py and the docs cite).
-R=${1:-r04}
+R=${1:-r05}
 P=gpurun_out/prof
 cd "$(dirname "$0")/.." || exit 1
 for MODE in strict fast; do
@@ -22,4 +22,7 @@ done
 for f in $P/bench_*.json; do
   [ -f "$f" ] && cp "$f" profiles/${R}_$(basename "$f")
 done
-ls profiles
+for f in power_regimes rates_power pipeline_costs ubench_lds_bw ubench_lds_pat stage_seconds; do
+  [ -f $P/$f.txt ] && cp $P/$f.txt profiles/${R}_$f.txt
+done
+ls profiles | grep "^${R}_" | wc -l
