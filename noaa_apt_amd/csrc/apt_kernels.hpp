@@ -127,6 +127,10 @@ void gather_rows(hipStream_t s, const float *f, const uint32_t *peaks, Result *r
 void gather_rows_call(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint32_t spr, uint32_t pw,
                       uint32_t max_rows_cap, const LaunchSwitches &sw = LaunchSwitches{});
 
+// the no-sync branch's tail (decode.rs:135-159, final decimation by m2 through NoFilter) and the result records of the
+// recordings of one call in one launch; `rows_cap` of the call's records counts floats
+void nosync_rows_call(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint32_t spr, uint32_t m2, uint64_t max_w);
+
 // ---- fused specialised front end (apt_kernels_fused.hip) --------------------------
 // true when a <L, M, T1, T2, PW> specialisation exists
 bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);

@@ -457,11 +457,39 @@ k_gather_rows_flat(const CallArgs call, const SlotPtrs *__restrict__ slots, uint
 
 __global__ void k_set_result(Result *res, Result value) { *res = value; }
 
+// The no-sync branch's tail for the recordings of one call (decode.rs:135-159): F cropped to whole rows, then
+// resample_with_filter(NoFilter) = filter([1.]) + decimate(m2) (dsp.rs:106-116, 294-307): out[k] = 0.0 + F[k m2] * 1.0 for
+// k m2 >= 1, out[0] = 0 (the `i > j` guard) — k_fir_decimate's arithmetic with its one tap — and the result record.
+// blockIdx.y = recording; `rows_cap` of the call's records counts FLOATS here.  (Until round 5: two launches per recording.)
+__global__ void __launch_bounds__(kBlock)
+k_nosync_rows_call(const CallArgs call, const SlotPtrs *__restrict__ slots, uint32_t spr, uint32_t m2)
+{
+    const RecArgs rec = call.rec[blockIdx.y];
+    const float *__restrict__ f = slots[rec.slot].f;
+    const uint64_t aligned = rec.w / spr * spr;
+    uint64_t n_out = aligned / m2;
+    if (n_out > rec.rows_cap) n_out = rec.rows_cap;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t k = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < n_out; k += stride) {
+        const uint64_t i = k * m2;
+        rec.rows[k] = i < 1 ? 0.f : __fadd_rn(0.f, __fmul_rn(f[i], 1.f));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *slots[rec.slot].res = Result{0 /* APTGPU_OK */, 0, static_cast<uint32_t>(n_out / 2080u), 0, rec.w, n_out};
+}
+
 }  // namespace
 
 void set_result(hipStream_t s, Result *res, Result value)
 {
     hipLaunchKernelGGL(k_set_result, dim3(1), dim3(1), 0, s, res, value);
+}
+
+void nosync_rows_call(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slots, uint32_t spr, uint32_t m2, uint64_t max_w)
+{
+    if (call.count == 0 || spr == 0 || m2 == 0) return;
+    const uint64_t n = max_w / m2 + 1;
+    hipLaunchKernelGGL(k_nosync_rows_call, dim3(grid_for(n, kBlock), call.count), dim3(kBlock), 0, s, call, d_slots, spr, m2);
 }
 
 void resample_generic(hipStream_t s, const float *x, uint64_t n, const float *coeff,

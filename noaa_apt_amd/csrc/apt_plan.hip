@@ -709,7 +709,19 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
                     timed("gather_rows", [&] { gather_rows_call(cur, c, d_slots.ptr, spr, pw, max_cap, sw); });
                 });
     } else {
-        // decode.rs:135-159 — crop to whole rows, resample_with_filter(NoFilter)
+        // decode.rs:135-159 — crop to whole rows, resample_with_filter(NoFilter).  Where that is a pure decimation
+        // (every stock profile: l2 == 1) the recordings of the call share ONE launch, result records included
+        if (l2 == 1 && !keep_steps) {
+            for (size_t from = 0; from < live.size(); from += static_cast<size_t>(kMaxCall)) {
+                const size_t to = std::min(live.size(), from + static_cast<size_t>(kMaxCall));
+                uint64_t max_w = 0;
+                uint32_t max_cap = 0;
+                CallArgs c = make_call(live, from, to, &max_w, &max_cap);
+                for (size_t k = from; k < to; ++k)  // (floats, not rows, in this launch)
+                    c.rec[k - from].rows_cap = static_cast<uint32_t>(std::min<uint64_t>(rows_cap_floats[live[k]], 0xFFFFFFFFull));
+                timed("final_decimate", [&] { nosync_rows_call(cur, c, d_slots.ptr, spr, m2, max_w); });
+            }
+        } else
         for (int i : live) {
             Slot &sl = slots[static_cast<size_t>(slot0 + i)];
             const uint64_t w = wlen[static_cast<size_t>(i)];
