@@ -135,6 +135,8 @@ void nosync_rows_call(hipStream_t s, const CallArgs &call, const SlotPtrs *d_slo
 // true when a <L, M, T1, T2, PW> specialisation exists
 bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
 uint32_t fused_group_size(uint32_t l);
+// does the specialisation for these factors take mono PCM16 payloads as they are (else they are converted to f32 first)?
+bool fused_takes_pcm16(uint32_t l, uint32_t m);
 // host: stage-1 tap-pair table [WIN][PS][2] (see apt_kernels_fused.hip) and its size in floats
 uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1, int ch);
 void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, int ch, float *hs);

@@ -43,10 +43,13 @@ bool fused_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t 
     if (l == 13 && m == 100 && t1 == 1915 && t2 == 37 && pw == 3) return true;  // 96 kHz, standard
     if (l == 13 && m == 30 && t1 == 2783 && t2 == 61 && pw == 5) return true;    // 48 kHz, slow profile
     if (l == 13 && m == 60 && t1 == 5565 && t2 == 61 && pw == 5) return true;    // 96 kHz, slow profile (strict instantiations only)
+    if (l == 13 && m == 75 && t1 == 639 && t2 == 43 && pw == 4) return true;     // 96 kHz, fast profile (strict, f32 input only: odd m)
     return false;
 }
 
 uint32_t fused_group_size(uint32_t l) { return 4 * l; }
+
+bool fused_takes_pcm16(uint32_t l, uint32_t m) { (void)l; return m % 2 == 0; }  // (sample pairs are read as dwords)
 
 // floats in the stage-1 tap table: the SPLIT layout (apt_kernels_fused_launch.hpp), one chunk-major table per half
 uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1, int ch)
@@ -167,6 +170,7 @@ float fused_gm_slack(uint32_t pw, float scale)
 bool fused_fast_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
 {
     if (l == 13 && m == 60 && t1 == 5565) return false;  // (100 KB of unrolled taps per instantiation: the strict kernel serves fast mode)
+    if (l == 13 && m == 75) return false;
     return fused_supported(l, m, t1, t2, pw);
 }
 
@@ -221,6 +225,10 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
             pcm16 ? fused_launch_48k_slow_fast_i16(a) : fused_launch_48k_slow_fast_f32(a);
         else
             pcm16 ? fused_launch_48k_slow_i16(a) : fused_launch_48k_slow_f32(a);
+        return true;
+    }
+    if (l == 13 && m == 75 && t1 == 639 && t2 == 43 && pw == 4 && mode == kModeStrict && !pcm16) {
+        fused_launch_96k_fastp_f32(a);
         return true;
     }
     if (l == 13 && m == 60 && t1 == 5565 && t2 == 61 && pw == 5 && mode == kModeStrict) {

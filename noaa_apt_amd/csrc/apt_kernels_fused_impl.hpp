@@ -962,7 +962,8 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         // software pipeline as the unsplit form below — a chunk's taps are one contiguous run of the half's table,
         // fetched by scalar loads written as assembly into pinned tuples, waited for one chunk later — with chunks of
         // four window samples = one 16-byte LDS read (PCM16: 8-byte), 24 + 4 tap dwords.
-        static_assert(L == 13 && M % 2 == 0 && Gm::XSHIFT % 2 == 0, "SPLIT: halves of 7 and 6 branches (three pairs each), window reads of aligned sample pairs");
+        static_assert(L == 13 && Gm::XSHIFT % 2 == 0 && (M % 2 == 0 || sizeof(XT) == 4),
+                      "SPLIT: halves of 7 and 6 branches (three pairs each); window reads of aligned sample pairs, or — odd M, f32 input only — of single samples");
         constexpr bool WIDE = M % 4 == 0 && Gm::XSHIFT % 4 == 0;  // a chunk's four samples are one 16-byte LDS read (else two of 8)
         constexpr int NS = Gm::NS;
         const int wl = tid & (NS - 1);
@@ -1005,6 +1006,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 if constexpr (sizeof(XT) == 4) {
                     if constexpr (WIDE) {
                         xraw[c & 1] = *reinterpret_cast<const f4w *>(P + wl * M + q0);
+                    } else if constexpr (M % 2 != 0) {
+                        // (odd lane stride — 96 kHz at the fast profile, M = 75: windows start at any word; 4-byte reads,
+                        // conflict-free at an odd stride)
+                        const float *wp = P + wl * M + q0;
+                        xraw[c & 1] = (f4w){wp[0], wp[1], wp[2], wp[3]};
                     } else {
                         // (lane stride M = 50 words: conflict-free as 8-byte reads, see the unsplit form)
                         const f2 lo = *reinterpret_cast<const f2 *>(P + wl * M + q0), hi = *reinterpret_cast<const f2 *>(P + wl * M + q0 + 2);

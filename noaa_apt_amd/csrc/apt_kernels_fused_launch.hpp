@@ -79,6 +79,8 @@ void fused_launch_48k_slow_fast_i16(const FusedLaunch &a);
 // 96 kHz at the slow profile (13 / 60, 5565 taps): the same SPLIT form, strict instantiations only
 void fused_launch_96k_slow_f32(const FusedLaunch &a);
 void fused_launch_96k_slow_i16(const FusedLaunch &a);
+// 96 kHz at the fast profile (13 / 75, 639 taps; odd m: 4-byte window reads, f32 input only — PCM16 payloads are staged)
+void fused_launch_96k_fastp_f32(const FusedLaunch &a);
 // phase-resident taps + the FAST PROFILE's work-rate stages (43-tap low-pass, pixel width 4), 256-thread workgroups:
 // 48 kHz (l = 26), 96 kHz (l = 13, m = 75) and the other rates whose l <= 256 at work rate 16 640
 void fused_launch_phase_fastp_f32(const FusedLaunch &a);

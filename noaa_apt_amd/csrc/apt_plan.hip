@@ -509,7 +509,8 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
         // WAV ingest (wav.rs:30-51): mono PCM16 goes straight into the fused front end, anything
         // else is converted into the slot's f32 staging buffer first
         const bool pcm16 = in.codec == static_cast<int>(apt::WavCodec::I16) && in.channels == 1 && use_fused &&
-                           (reinterpret_cast<uintptr_t>(in.ptr) & (fused == 1 ? 3u : 1u)) == 0;
+                           (reinterpret_cast<uintptr_t>(in.ptr) & (fused == 1 ? 3u : 1u)) == 0 &&
+                           (fused != 1 || apt::gpu::fused_takes_pcm16(l, m));
         xin[static_cast<size_t>(i)] = in.ptr;
         is_pcm[static_cast<size_t>(i)] = pcm16 ? 1 : 0;
         if (in.codec >= 0 && !pcm16) {

@@ -297,7 +297,7 @@ def test_fused_specialisations_are_used(ctx):
     apt.cache_clear()  # (a session another test built under an APTGPU_* switch would answer for its own kernel path)
     for rate, profile, want in ((48000, "standard", 1), (96000, "standard", 1), (44100, "standard", 4),
                                 (11025, "standard", 4), (8000, "standard", 4), (22050, "standard", 4),
-                                (48000, "fast", 4), (48000, "slow", 1), (96000, "fast", 2), (16000, "fast", 4),
+                                (48000, "fast", 4), (48000, "slow", 1), (96000, "fast", 1), (16000, "fast", 4),
                                 (11025, "fast", 4), (96000, "slow", 1), (24960, "standard", 0)):
         _, st = apt.decode(ctx, apt.Settings.profile(profile), synth_apt(rate, 11, 3), apt.Rate.hz(rate),
                            True, return_stats=True)
@@ -449,7 +449,7 @@ def test_phase_stage1_long_ragged_batched_and_pcm16(oracle):
 PROFILE_CASES = [  # (rate, seconds, profile, fused): the fast and slow profiles on the specialised kernels (round 4)
     (48000, 14, "slow", 1),    # SPLIT stage 1 for 13 / 30 with 2783 taps; 61-tap low-pass, pixel width 5
     (48000, 14, "fast", 4),    # phase-resident stage 1 (l = 26) + the fast profile's work-rate stages (43 taps, pw 4)
-    (96000, 12, "fast", 2),    # l = 13, m = 75: the paired tile of the phase-resident stage 1 would not fit — run-time kernel
+    (96000, 12, "fast", 1),    # l = 13, m = 75 (odd): SPLIT stage 1 with 4-byte window reads (round 5; until then the run-time kernel)
     (16000, 30, "fast", 4), (32000, 16, "fast", 4), (8000, 50, "fast", 4), (12000, 40, "fast", 4), (24000, 20, "fast", 4),
     # round 5: four / eight branches per thread in front of the fast profile's stages (l = 832 / 1664)
     (44100, 14, "fast", 4), (22050, 20, "fast", 4),
