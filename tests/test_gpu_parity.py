@@ -480,7 +480,8 @@ def test_profile_kernels_ragged_batched_pcm16_and_nonfinite(oracle):
     recordings that end around the tile boundaries."""
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda:0")
-    for profile, rate in (("slow", 48000), ("fast", 48000), ("slow", 44100), ("fast", 44100), ("slow", 11025), ("fast", 22050), ("fast", 11025)):
+    for profile, rate in (("slow", 48000), ("fast", 48000), ("slow", 44100), ("fast", 44100), ("slow", 11025), ("fast", 22050), ("fast", 11025),
+                          ("fast", 96000), ("slow", 96000)):
         s = apt.Settings.profile(profile)
         os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
                                            "resample_cutout", "demodulation_atten")}
