@@ -401,6 +401,25 @@ def test_phase_stage1_wide_workgroups_bitexact(oracle, monkeypatch, rate, second
     assert_bitexact(got, want, f"phase stage 1 (wide) {rate}")
 
 
+@pytest.mark.parametrize("rate,seconds,profile", [(44100, 14, "standard"), (11025, 30, "standard"), (22050, 20, "slow")])
+@pytest.mark.parametrize("switch", ["APTGPU_PHASE_TT", "APTGPU_PHASE_IDENTITY"])
+def test_phase_stage1_table_switches_bitexact(oracle, monkeypatch, rate, seconds, profile, switch):
+    """The A/B switches of the phase-resident stage 1's host tables: taps from the phase-major rows only
+    (APTGPU_PHASE_TT=0: no thread-order copy) and slot = thread (APTGPU_PHASE_IDENTITY=1: no assignment lists) —
+    other memory layouts and lane assignments, the same arithmetic."""
+    monkeypatch.setenv(switch, "0" if switch.endswith("TT") else "1")
+    apt.cache_clear()
+    x = synth_apt(rate, seconds, seed=rate % 83 + seconds)
+    s = apt.Settings.profile(profile)
+    os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                       "resample_cutout", "demodulation_atten")}
+    want = oracle.decode(x, rate, True, settings=os_)
+    got, st = apt.decode(apt.Context(device=0), s, x, apt.Rate.hz(rate), True, return_stats=True)
+    apt.cache_clear()
+    assert st.fused == 4
+    assert_bitexact(got, want, f"phase stage 1 with {switch} at {rate} Hz, {profile}")
+
+
 def test_phase_stage1_long_ragged_batched_and_pcm16(oracle):
     """Many tiles, lengths that end mid-tile / mid-group, several recordings per call, PCM16 payloads at
     odd 2-byte offsets, non-finite samples, and the fast mode's tolerance — all at 44 100 Hz."""
