@@ -207,12 +207,14 @@ bool fused_table_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uin
 bool fused_table_front_end(hipStream_t s, const TableGeom &geom, int mode, bool pcm16, const CallArgs &call,
                            const FusedParams *d_prm, uint64_t max_w);
 
-// Phase-resident stage 1 + the specialised work-rate stages (k_fused in PHASE mode): thread t < S = l*floor(256/l)
-// computes the outputs t, t+S, ... of a tile with the taps of their common polyphase branch in registers.
-// Needs l <= 256, <= 16 outputs per thread, <= 76 taps per branch, an input tile that leaves room for three
-// workgroups per CU, standard-profile work-rate stages.  44 100 Hz (l = 208) is the rate this exists for.
-// TableGeom use: step_r = S, step_q = S*m/l, tpp = row stride of the table (multiple of 4), off_x = f2 entries
-// per region of the paired input tile, xt = floats of the whole tile.
+// Phase-resident stage 1 + the specialised work-rate stages (k_fused in PHASE mode): a thread holds nq slots u + q S'
+// (S' = step_r / nq <= threads) of the step_r outputs after which the polyphase branches repeat, and computes the
+// 16 / nq outputs of each that fall into the tile, with the taps of their common branch in registers (or, `stream`,
+// fetched sixteen at a time).  256 threads with nq = 1, 2, 4 (l <= 256, 512, 1024) at the standard profile, nq = 1, 4, 8,
+// 16 at the fast profile, nq = 1, 2, 4 with streamed taps at the slow profile; 512- / 1024-thread forms with nq = 1 as
+// fallbacks.  Every rate a sound card records at is served this way (44 100 Hz: l = 208; 22 050: 416; 11 025: 832).
+// TableGeom use: step_r = S, step_q = S*m/l, tpp = row stride of the table (multiple of 4; 16 when streamed), off_x = f2
+// entries per region of the paired input tile, xt = floats of the whole tile; the rest: see the struct.
 bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom);
 uint32_t fused_phase_table_floats(const TableGeom &geom);
 // host: [l][tpp] taps, rows 16-byte aligned, then the thread assignment lists (geom.perm_off)

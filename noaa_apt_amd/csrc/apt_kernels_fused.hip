@@ -8,18 +8,16 @@
 // and C never leave the CU.  Reference: src/decode.rs:77-110, src/dsp.rs:186-289,
 // 350-410, src/decode.rs:225-233.
 //
-// Mapping (template <L, M, T1, T2, PW>):  thread "a" owns the L consecutive work-rate
-// samples k = L*a .. L*a+L-1.  All of them read the same input window x[M*a ..], each
-// through its own polyphase branch of the T1-tap filter, so
-//   * the window (c_{L-1}+TP floats) is read once from LDS into registers,
-//   * the branch taps are wave-uniform -> scalar loads (s_load_dwordx*) through the
-//     scalar cache, no LDS traffic and no VGPRs for coefficients,
-//   * every product and sum is a separate v_mul_f32 / v_add_f32 in the reference's
-//     order: bit-identical to the scalar Rust loop (no FMA; #pragma fp contract(off)).
-// A workgroup of 256 threads covers 256*L work samples: 3 threads of pre-halo (the
-// low-pass and envelope look back 37 samples), 244 threads of owned outputs and 9
-// threads of post-halo (the correlation looks ahead 38*PW-1 samples).  LDS: the input
-// tile, later overwritten by R and then F (region P), plus D (region Q).
+// Behind stage 1 thread t of a 256-thread workgroup owns the 13 consecutive work-rate samples 13 t .. 13 t + 12 of a
+// tile of 3328 (halo threads either side: the low-pass and the envelope look back, the correlation looks ahead); R, D, F
+// and the pulse sums go through two LDS regions.  Stage 1 — the polyphase resampler — comes in three forms:
+//   SPLIT (M > 0: 48 / 96 kHz)   taps wave-uniform: scalar loads into pinned SGPR tuples, every window sample read once
+//                                from LDS and broadcast against a pair of taps feeding a pair of accumulators;
+//   PHASE (M < 0: every other rate a sound card records at)   taps thread-resident, samples paired in LDS;
+//   TABLE (M == 0: fallback)     taps and samples from LDS.
+// Every product and sum is a separate multiplication / addition in the reference's order: bit-identical to the scalar
+// Rust loop (no FMA; #pragma fp contract(off)).  This file: the host side — which kernel serves which geometry, the
+// tap tables in the layouts the kernels read, the launch dispatch.
 #include "apt_kernels_fused_launch.hpp"
 
 #include <hip/hip_runtime.h>

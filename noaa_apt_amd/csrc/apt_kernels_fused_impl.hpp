@@ -223,14 +223,16 @@ __host__ __device__ constexpr bool sync_plus(int j)
 // tap count — one output per thread and step, as in k_fused_any — and hands R to the SAME work-rate
 // stages (envelope, packed low-pass, correlation) as the specialised kernels; the template's L is then
 // just "work samples per thread" (13: four threads = one group of 52 positions).
-// PHASE mode (M == -1; 44 100 Hz: l = 208 — too large for one accumulator per branch, and its table + input
-// tile overflow two workgroups per CU in TABLE mode, which at one workgroup per CU is bound by the latency of
-// its two LDS reads per multiply-add): thread t < S = l * floor(NTHR / l) computes the NB outputs
-// t, t + S, t + 2S, ... of the tile.  They all use the SAME polyphase branch (S is a multiple of l), so the
-// ~70 taps of that branch are fetched once per tile into REGISTERS (16-byte loads from the L2-resident
-// phase-major table) and every tap then costs one LDS read of a sample per output and — outputs taken in
-// pairs — half a v_pk_mul_f32 + half a v_pk_add_f32 (or half a v_pk_fma_f32), as in the specialised kernels.
-// Each output still accumulates its taps in ascending order: bit-identical in strict mode.
+// PHASE mode (M == -NQ; every rate a sound card records at — 44 100 Hz: l = 208, NQ = 1; 22 050 Hz: l = 416, NQ = 2;
+// 11 025 Hz: l = 832, NQ = 4 — too many branches for one accumulator each): a thread holds NQ slots u + q S' of the S
+// outputs after which the branches repeat (S = l * floor(NTHR / l) for NQ = 1, else l; S' = S / NQ) and computes the
+// 16 / NQ outputs (u + q S') + a S of each.  They all use the SAME polyphase branch, so that branch's taps are fetched
+// once per tile into REGISTERS (16-byte loads from the L2-resident table, in thread order where the tile phases
+// repeat) and every tap then costs one LDS read of a sample pair per output pair and half a v_pk_mul_f32 + half a
+// v_pk_add_f32 (or half a v_pk_fma_f32) per output, as in the specialised kernels.  Each output still accumulates its
+// taps in ascending order: bit-identical in strict mode.  Which thread takes which slot is the host's choice
+// (fused_phase_table: the lists that keep the 8-byte LDS reads of a half-wave on distinct bank positions).  T1 == 1 marks
+// the STREAMED form (taps fetched sixteen at a time: the slow profile's 197 taps per branch do not fit the registers).
 // One workgroup per tile: blockIdx.y picks the recording, whose tiles are blockIdx.x < ceil(w / OWN_K).
 // The tile's input goes through registers (all loads issued before the first LDS write).  The specialised kernels
 // (M > 0, f32 taps) run stage 1 in the SPLIT form — two sub-tiles of 128 windows through the same LDS, each thread
@@ -239,7 +241,7 @@ __host__ __device__ constexpr bool sync_plus(int j)
 // that walked the tiles with a fixed grid and kept the NEXT tile's input in registers while the stages ran was measured
 // in rounds 2 and 3 and dropped: slower in every mode)
 template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
-__global__ void __launch_bounds__(NTHR, M < 0 ? ((NTHR > 512 ? 1 : NTHR > 256 ? 2 : (T1 == 1 ? (M == -1 ? 3 : 4) : T2 == 43 ? 4 : M == -4 ? 5 : M == -2 ? 5 : 3)) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs; the fast profile's: four, <= 128; two or four branches per thread: five, <= 96), two 512-thread or one 1024-thread (<= 128) workgroups per CU */
+__global__ void __launch_bounds__(NTHR, M < 0 ? ((NTHR > 512 ? 1 : NTHR > 256 ? 2 : (T1 == 1 ? (M == -1 ? 3 : 4) : T2 == 43 ? 4 : M == -4 ? 5 : M == -2 ? 5 : 3)) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs; the fast profile's and the streamed forms with several branches: four, <= 128; two or four branches per thread at the standard profile: five, <= 96), two 512-thread or one 1024-thread (<= 128) workgroups per CU */
                                      : M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
                                                /* specialised: as many workgroups as the CU's 160 KB of LDS hold (48 kHz SPLIT: 5, 96 kHz: 3) */
                                                : (FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), MODE == kModeF16Taps>::WGS_PER_CU * NTHR + 255) / 256)
@@ -570,8 +572,6 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             // wave-uniform test per quad; as a select per register it cost a v_cndmask per tap)
 #pragma unroll
             for (int e = 0; e < SEG / 4; ++e) {
-                constexpr int dummy = 0;
-                (void)dummy;
                 const int eq = k * (SEG / 4) + e;  // quad of the branch
                 if (eq < TPPM / 4 && static_cast<uint32_t>(4 * eq) < tpp) tq[sidx % NTB][e] = row[static_cast<size_t>(eq) * estep];
             }
