@@ -66,7 +66,12 @@ typedef struct aptgpu_settings {
     float resample_cutout;      /* Hz                                          */
     float demodulation_atten;   /* dB                                          */
     int32_t export_wav;         /* Settings.export_wav: deliver steps via step */
-    int32_t export_resample_filtered; /* must be 0 (APTGPU_ERR_UNSUPPORTED)    */
+    int32_t export_resample_filtered; /* Settings.export_resample_filtered (src/config.rs:83 ->
+                                   context.rs:113).  As in the reference it moves the decimation
+                                   phase of fast_resampling (src/dsp.rs:265-273) -- other rows,
+                                   exported or not -- and with export_wav the "resample_filtered"
+                                   step carries the expanded signal (n*l floats).  Served by the
+                                   unfused kernels: a debugging aid, not a fast path            */
 } aptgpu_settings;
 
 /* ---- context::Context (src/context.rs:100-133) -------------------------- */

@@ -316,7 +316,7 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
             key.per_call = 1;
             key.settings = *settings;
             key.settings.export_wav = 0;
-            key.settings.export_resample_filtered = 0;
+            key.settings.export_resample_filtered = settings->export_resample_filtered ? 1 : 0;  // another plan (dsp.rs:265-273)
             lease = session_acquire(key, n);
             plan = lease->plan.get();
         } else {
@@ -379,7 +379,16 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
              plan->taps_resample.size(), 0);
         if (w < 10ull * plan->spr) throw decode_error(kTooShort);  // decode.rs:79-83
         if (steps) {
-            if (plan->l > 1) {
+            if (plan->l > 1 && plan->export_filtered) {
+                // dsp.rs:269,281-285: every sum of the interpolated axis (gigabytes for a whole pass, as the
+                // reference's documentation warns)
+                const uint64_t cnt = apt::fast_resampling_export_geom(n, plan->l, plan->m, plan->taps_resample.size()).expanded;
+                apt::DeviceBuffer<float> d_ex;
+                d_ex.alloc(cnt + 16);
+                plan->expanded_filtered(s, wav ? sl.ingest.ptr : static_cast<const float *>(d_in_ptr), n, false, d_ex.ptr, cnt);
+                apt::Signal ex = download(d_ex.ptr, cnt, s);
+                step(&ctx, steps, "resample_filtered", 0, ex.data(), ex.size(), input_rate_hz * plan->l);
+            } else if (plan->l > 1) {
                 // dsp.rs:281-285: expanded signal is empty unless export_resample_filtered
                 step(&ctx, steps, "resample_filtered", 0, nullptr, 0, input_rate_hz * plan->l);
             }
@@ -445,7 +454,14 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
                 // final resample_with_filter(NoFilter) (decode.rs:158-159): the steps of dsp.rs:96-122
                 const float one = 1.f;
                 step(&ctx, steps, "resample_filter", 1, &one, 1, 0);
-                if (plan->l2 > 1) {
+                if (plan->l2 > 1 && plan->export_filtered) {
+                    const uint64_t cnt = apt::fast_resampling_export_geom(aligned, plan->l2, plan->m2, 1).expanded;
+                    apt::DeviceBuffer<float> d_ex;
+                    d_ex.alloc(cnt + 16);
+                    plan->expanded_filtered(s, sl.filtered.ptr, aligned, true, d_ex.ptr, cnt);
+                    apt::Signal ex = download(d_ex.ptr, cnt, s);
+                    step(&ctx, steps, "resample_filtered", 0, ex.data(), ex.size(), work * plan->l2);
+                } else if (plan->l2 > 1) {
                     // fast_resampling: the expanded signal is empty unless export_resample_filtered
                     step(&ctx, steps, "resample_filtered", 0, nullptr, 0, work * plan->l2);
                 } else {

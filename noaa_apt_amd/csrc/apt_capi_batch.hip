@@ -49,7 +49,8 @@ bool SessionKey::operator==(const SessionKey &o) const
            std::memcmp(&settings.resample_atten, &o.settings.resample_atten, sizeof(float)) == 0 &&
            std::memcmp(&settings.resample_delta_freq, &o.settings.resample_delta_freq, sizeof(float)) == 0 &&
            std::memcmp(&settings.resample_cutout, &o.settings.resample_cutout, sizeof(float)) == 0 &&
-           std::memcmp(&settings.demodulation_atten, &o.settings.demodulation_atten, sizeof(float)) == 0;
+           std::memcmp(&settings.demodulation_atten, &o.settings.demodulation_atten, sizeof(float)) == 0 &&
+           (settings.export_resample_filtered != 0) == (o.settings.export_resample_filtered != 0);
 }
 
 void PlanDeleter::operator()(aptgpu_plan *p) const { aptgpu_plan_destroy(p); }
@@ -468,7 +469,7 @@ void worker(Shared &sh, int device, std::vector<Item> items)
         key.depth = Session::kSets;
         key.settings = *sh.settings;
         key.settings.export_wav = 0;
-        key.settings.export_resample_filtered = 0;
+        key.settings.export_resample_filtered = sh.settings->export_resample_filtered ? 1 : 0;  // another plan (dsp.rs:265-273)
         lease = session_acquire(key, max_n);
         Session &S = *lease;
         aptgpu_plan *plan = S.plan.get();

@@ -178,4 +178,21 @@ uint64_t fast_resampling_len(uint64_t n, uint32_t l, uint32_t m, uint64_t ntaps)
     return (total - off + m - 1) / m;
 }
 
+// fast_resampling with context.export_resample_filtered set (dsp.rs:265-273): t walks the interpolated axis one
+// by one from `off`, and the output keeps the sums whose t + 1 is a multiple of m, i.e. t = j*m - 1 for
+// ceil((off + 1) / m) <= j <= n*l / m.
+ExportGeom fast_resampling_export_geom(uint64_t n, uint32_t l, uint32_t m, uint64_t ntaps)
+{
+    ExportGeom g{0, 0, 0};
+    const uint64_t off = (ntaps - 1) / 2;
+    const uint64_t total = n * l;
+    if (total <= off) return g;
+    g.expanded = total - off;
+    const uint64_t j0 = (off + m) / m;
+    const uint64_t j1 = total / m;
+    g.d0 = j0 * m - 1 - off;
+    g.count = j1 >= j0 ? j1 - j0 + 1 : 0;
+    return g;
+}
+
 }  // namespace apt

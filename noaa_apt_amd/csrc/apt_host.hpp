@@ -118,5 +118,11 @@ LM interpolation_factors(Rate input_rate, Rate output_rate);
 // Number of outputs fast_resampling produces (dsp.rs:226-277):
 // t = off, off+m, ... while t < n*l.
 uint64_t fast_resampling_len(uint64_t n, uint32_t l, uint32_t m, uint64_t ntaps);
+// The other branch of the same loop (context.export_resample_filtered, dsp.rs:265-273): the output is taken at
+// t = off + d0 + k*m, k < count, and `expanded` sums (every t in [off, n*l)) go to the "resample_filtered" step.
+struct ExportGeom {
+    uint64_t d0, count, expanded;
+};
+ExportGeom fast_resampling_export_geom(uint64_t n, uint32_t l, uint32_t m, uint64_t ntaps);
 
 }  // namespace apt

@@ -90,9 +90,6 @@ std::vector<aptgpu_kernel_time> KernelTimer::collect(hipStream_t s)
 aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &settings,
                          uint32_t input_rate, bool sync, size_t max_samples, int max_batch, int depth)
 {
-    if (settings.export_resample_filtered)
-        throw Error{ErrorKind::Unsupported,
-                    "export_resample_filtered is not available on the GPU path"};
     if (input_rate == 0) throw Error{ErrorKind::Invalid, "input_rate is 0"};
     if (max_batch < 1) max_batch = 1;
 
@@ -105,6 +102,7 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
     plan->max_samples = max_samples;
     plan->max_batch = max_batch;
     plan->sw = gpu::read_launch_switches();
+    plan->export_filtered = settings.export_resample_filtered != 0;
     if (const char *e = std::getenv("APTGPU_FORCE_WALK")) plan->picker_force = e[0] == '1' ? 1 : 0;
     if (const char *e = std::getenv("APTGPU_PICKER_LDS")) if (e[0] == '1') plan->picker_force = 4;
 
@@ -251,7 +249,7 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         // APTGPU_MODE_FAST permits deviations within the stated tolerance; where no fast kernel exists
         // (other rates / profiles) the strict kernels serve it
         const bool eligible = (plan->mode == APTGPU_MODE_STRICT || plan->mode == APTGPU_MODE_FAST) && plan->l > 1 &&
-                              plan->work_is_multiple;
+                              plan->work_is_multiple && !plan->export_filtered;
         const char *force_any = std::getenv("APTGPU_FUSED_ANY");  // tests: run-time kernel even if specialised
         plan->fused = 0;
         const bool no_spec = force_any && force_any[0] == '1';
@@ -428,15 +426,62 @@ void aptgpu_plan::upload_slot_table()
 // ------------------------------------------------------------------ geometry
 uint64_t aptgpu_plan::work_len_for(uint64_t n) const
 {
-    if (l > 1) return apt::fast_resampling_len(n, l, m, taps_resample.size());
+    if (l > 1)
+        return export_filtered ? apt::fast_resampling_export_geom(n, l, m, taps_resample.size()).count
+                               : apt::fast_resampling_len(n, l, m, taps_resample.size());
     return n / m;  // decimate, dsp.rs:299-303
 }
 
 uint64_t aptgpu_plan::out_len_nosync(uint64_t work_len) const
 {
     const uint64_t aligned = spr ? work_len / spr * spr : 0;  // decode.rs:142-147
-    if (l2 > 1) return apt::fast_resampling_len(aligned, l2, m2, 1);
+    if (l2 > 1)
+        return export_filtered ? apt::fast_resampling_export_geom(aligned, l2, m2, 1).count
+                               : apt::fast_resampling_len(aligned, l2, m2, 1);
     return aligned / m2;
+}
+
+// ------------------------------------------------------- export_resample_filtered
+// fast_resampling (dsp.rs:186-289) evaluated at t = off + d0 + k*step of the interpolated axis: the window of
+// such a t starts at the first multiple of l at or after t - off = d (:237-248), input x0 = ceil(d / l), tap
+// p = x0*l - d, then taps p + i*l while they stay <= 2*off (:254); inputs at or beyond n are skipped (:257).
+// step == m, d0 == 0 is the normal branch (k_resample_generic); the export branch (:265-273) needs d0 =
+// fast_resampling_export_geom().d0 for the output and step == 1 for the expanded signal.  Only this mode uses the
+// kernel, which is why it lives beside the plan and not with the hot kernels.
+namespace {
+__global__ void __launch_bounds__(256)
+k_resample_at(const float *__restrict__ x, uint64_t n, const float *__restrict__ coeff, uint32_t jlim, uint32_t l,
+              uint64_t d0, uint32_t step, float *__restrict__ out, uint64_t w)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    for (uint64_t k = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; k < w; k += stride) {
+        const uint64_t d = d0 + k * step;
+        uint64_t xi = (d + l - 1) / l;
+        const uint32_t p = static_cast<uint32_t>(xi * l - d);
+        float sum = 0.f;
+        for (uint32_t j = p; j < jlim; j += l, ++xi)
+            if (xi < n) sum = __fadd_rn(sum, __fmul_rn(coeff[j], x[xi]));
+        out[k] = sum;
+    }
+}
+
+void resample_at(hipStream_t s, const float *x, uint64_t n, const float *coeff, uint32_t ntaps, uint32_t l, uint64_t d0,
+                 uint32_t step, float *out, uint64_t w)
+{
+    if (w == 0) return;
+    const uint32_t jlim = 2 * ((ntaps - 1) / 2) + 1;  // n <= t + offset  <=>  j <= 2*offset
+    const uint64_t blocks = std::min<uint64_t>((w + 255) / 256, 256u * 64u);
+    hipLaunchKernelGGL(k_resample_at, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, x, n, coeff, jlim, l, d0, step,
+                       out, w);
+}
+}  // namespace
+
+void aptgpu_plan::expanded_filtered(hipStream_t s, const float *d_x, uint64_t n, bool final_stage, float *d_out,
+                                    uint64_t count)
+{
+    if (final_stage) resample_at(s, d_x, n, d_one.ptr, 1, l2, 0, 1, d_out, count);
+    else resample_at(s, d_x, n, d_taps_resample.ptr, static_cast<uint32_t>(taps_resample.size()), l, 0, 1, d_out, count);
+    apt::hip_check(hipGetLastError(), "kernel launch (expanded signal)");
 }
 
 void aptgpu_plan::sync_all()
@@ -624,7 +669,10 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
                 sl.demodulated.alloc(max_work_len + 64);
             }
             // 1. resample to work_rate (dsp.rs:62-126)
-            if (l > 1 && mode == APTGPU_MODE_FP16_TAPS) {
+            if (l > 1 && export_filtered) {
+                const uint64_t d0 = apt::fast_resampling_export_geom(n, l, m, t1).d0;
+                timed("resample_generic", [&] { resample_at(cur, d_signal, n, d_taps_resample.ptr, t1, l, d0, m, sl.resampled.ptr, w); });
+            } else if (l > 1 && mode == APTGPU_MODE_FP16_TAPS) {
                 timed("resample_f16taps", [&] {
                     resample_f16taps(cur, d_signal, n, d_taps_f16.ptr, t1, l, m, f16_unscale, sl.resampled.ptr, w);
                 });
@@ -729,7 +777,10 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
             const uint64_t aligned = w / spr * spr;
             uint64_t n_out = out_len_nosync(w);
             if (n_out > rows_cap_floats[i]) n_out = rows_cap_floats[i];
-            if (l2 > 1) {
+            if (l2 > 1 && export_filtered) {
+                const uint64_t d0 = apt::fast_resampling_export_geom(aligned, l2, m2, 1).d0;
+                timed("final_resample", [&] { resample_at(cur, sl.filtered.ptr, aligned, d_one.ptr, 1, l2, d0, m2, d_rows[i], n_out); });
+            } else if (l2 > 1) {
                 timed("final_resample", [&] {
                     resample_generic(cur, sl.filtered.ptr, aligned, d_one.ptr, 1, l2, m2, d_rows[i], n_out);
                 });

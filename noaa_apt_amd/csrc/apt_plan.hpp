@@ -183,6 +183,15 @@ struct aptgpu_plan {
     uint64_t work_len_for(uint64_t n) const;
     uint64_t out_len_nosync(uint64_t work_len) const;
 
+    // Settings.export_resample_filtered (config.rs:83 -> context.rs:113): fast_resampling then walks every t of the
+    // interpolated axis and decimates at (t + 1) % m == 0 (dsp.rs:265-273) — another phase than the t = off + k*m of
+    // the normal branch, whether or not anything is exported.  Such a plan runs the unfused kernels.
+    bool export_filtered = false;
+    // the "resample_filtered" step of that mode (dsp.rs:269,281-285): every sum of the interpolated axis from t = off
+    // on, `count` of them into d_out; final_stage: the NoFilter resample to 4160 Hz (decode.rs:158-159) instead of
+    // the first one
+    void expanded_filtered(hipStream_t s, const float *d_x, uint64_t n, bool final_stage, float *d_out, uint64_t count);
+
     // what a recording looks like in HBM: the f32 Signal (codec < 0), or the payload of a WAV
     // data chunk (codec = apt::WavCodec) that is converted on the device — inside the fused
     // front end for mono PCM16, through the slot's staging buffer otherwise

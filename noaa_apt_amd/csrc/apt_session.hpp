@@ -28,7 +28,7 @@ struct SessionKey {
     bool sync = true;
     int per_call = 1;
     int depth = 1;  // calls in flight the plan is built for: 1 (aptgpu_decode: one stream, `plan->stream`), kSets (batch workers)
-    aptgpu_settings settings{};  // the five fields decode() reads (export flags zeroed)
+    aptgpu_settings settings{};  // the five fields decode() reads + export_resample_filtered (it changes the plan); export_wav zeroed
     bool operator==(const SessionKey &o) const;
 };
 

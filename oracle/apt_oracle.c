@@ -321,12 +321,81 @@ static uint32_t gcd_u32(uint32_t a, uint32_t b)
     return a;
 }
 
+/* fast_resampling with context.export_resample_filtered set, src/dsp.rs:186-289: every t of the
+ * interpolated axis is evaluated (:265-273), `expanded` receives all of them (:269) and the output
+ * the ones with (t + 1) % m == 0 (:270-273) -- NOT the t = offset + k*m of the other branch. */
+float *apt_oracle_fast_resampling_export(const float *signal, size_t len, uint32_t l32, uint32_t m32,
+                                         const float *coeff, size_t ncoeff, size_t *n_out,
+                                         float **expanded_out, size_t *n_expanded)
+{
+    uint64_t l = l32, m = m32;
+    uint64_t interpolated_len = (uint64_t)len * l; /* :203 */
+    uint64_t offset = ((uint64_t)ncoeff - 1) / 2;  /* :226 */
+    size_t cap = (size_t)(interpolated_len / m) + 2;
+    float *output = (float *)malloc(sizeof(float) * cap);
+    size_t ecap = interpolated_len > offset ? (size_t)(interpolated_len - offset) : 1;
+    float *expanded = (float *)malloc(sizeof(float) * ecap);
+    size_t cnt = 0, ecnt = 0;
+    uint64_t n;
+    uint64_t t = offset; /* :230 */
+
+    while (t < interpolated_len) { /* :234 */
+        if (t > offset) {          /* :237-248 */
+            n = t - offset;
+            uint64_t rem = n % l;
+            if (rem != 0) n += l - rem;
+        } else {
+            n = 0;
+        }
+        float sum = 0.f; /* :252 */
+        uint64_t x = n / l;
+        while (n <= t + offset) { /* :254 */
+            if (x < (uint64_t)len) {
+                sum += coeff[n + offset - t] * signal[x]; /* :259 */
+            }
+            x += 1;
+            n += l;
+        }
+        expanded[ecnt++] = sum; /* :269 */
+        t += 1;                 /* :270 */
+        if (t % m == 0) {       /* :271 */
+            if (cnt == cap) {
+                cap *= 2;
+                output = (float *)realloc(output, sizeof(float) * cap);
+            }
+            output[cnt++] = sum; /* :272 */
+        }
+    }
+    *n_out = cnt;
+    if (expanded_out) {
+        *expanded_out = expanded;
+        if (n_expanded) *n_expanded = ecnt;
+    } else {
+        free(expanded);
+    }
+    return output;
+}
+
 /* resample_with_filter, src/dsp.rs:62-126 */
 int apt_oracle_resample_with_filter(const float *x, size_t n, uint32_t in_rate,
                                     uint32_t out_rate, apt_oracle_filter_spec filt, float **out,
                                     size_t *n_out, float **coeff_out, size_t *ncoeff_out,
                                     char *err, size_t err_cap)
 {
+    return apt_oracle_resample_with_filter_ex(x, n, in_rate, out_rate, filt, 0, out, n_out, coeff_out,
+                                              ncoeff_out, NULL, NULL, err, err_cap);
+}
+
+/* the same with Context.export_resample_filtered (src/context.rs:113) as an argument; `expanded_out`
+ * (nullable) receives what the "resample_filtered" step would carry (dsp.rs:281-285; on the l == 1 branch
+ * the step carries the filtered signal, :110-114) */
+int apt_oracle_resample_with_filter_ex(const float *x, size_t n, uint32_t in_rate, uint32_t out_rate,
+                                       apt_oracle_filter_spec filt, int export_resample_filtered,
+                                       float **out, size_t *n_out, float **coeff_out, size_t *ncoeff_out,
+                                       float **expanded_out, size_t *n_expanded, char *err, size_t err_cap)
+{
+    if (expanded_out) *expanded_out = NULL;
+    if (n_expanded) *n_expanded = 0;
     if (out_rate == 0) { /* :69-71 */
         set_err(err, err_cap, "Can't resample to 0Hz");
         return APT_ORACLE_ERR_INTERNAL;
@@ -350,12 +419,20 @@ int apt_oracle_resample_with_filter(const float *x, size_t n, uint32_t in_rate,
         }
         apt_oracle_filter_resample(&filt, in_rate, (uint32_t)prod); /* :93 */
         coeff = apt_oracle_filter_design(&filt, &ncoeff);           /* :94 */
-        *out = apt_oracle_fast_resampling(x, n, l, m, coeff, ncoeff, n_out); /* :98 */
+        if (export_resample_filtered)
+            *out = apt_oracle_fast_resampling_export(x, n, l, m, coeff, ncoeff, n_out, expanded_out, n_expanded);
+        else
+            *out = apt_oracle_fast_resampling(x, n, l, m, coeff, ncoeff, n_out); /* :98 */
     } else {
         coeff = apt_oracle_filter_design(&filt, &ncoeff);
         float *filtered = apt_oracle_fir(x, n, coeff, ncoeff); /* :108 */
         *out = apt_oracle_decimate(filtered, n, m, n_out);        /* :116 */
-        free(filtered);
+        if (expanded_out) { /* :110-114 */
+            *expanded_out = filtered;
+            if (n_expanded) *n_expanded = n;
+        } else {
+            free(filtered);
+        }
     }
     if (coeff_out) {
         *coeff_out = coeff;
@@ -478,7 +555,23 @@ int apt_oracle_decode(const apt_oracle_settings *s, const float *x, size_t n,
                       uint32_t input_rate, int sync, float **out, size_t *n_out,
                       apt_oracle_steps *steps, char *err, size_t err_cap)
 {
+    return apt_oracle_decode_ex(s, x, n, input_rate, sync, 0, out, n_out, steps, NULL, NULL, NULL, NULL,
+                                err, err_cap);
+}
+
+/* decode with Context.export_resample_filtered as an argument (it moves the decimation phase of every
+ * fast_resampling call, dsp.rs:265-273, whether or not anything is exported); expanded1 / expanded2
+ * (nullable) receive the "resample_filtered" steps of the first and of the final resample */
+int apt_oracle_decode_ex(const apt_oracle_settings *s, const float *x, size_t n, uint32_t input_rate,
+                         int sync, int export_resample_filtered, float **out, size_t *n_out,
+                         apt_oracle_steps *steps, float **expanded1, size_t *n_expanded1,
+                         float **expanded2, size_t *n_expanded2, char *err, size_t err_cap)
+{
     int rc;
+    if (expanded1) *expanded1 = NULL;
+    if (n_expanded1) *n_expanded1 = 0;
+    if (expanded2) *expanded2 = NULL;
+    if (n_expanded2) *n_expanded2 = 0;
     double t0, t1;
     if (steps) memset(steps, 0, sizeof(*steps));
     *out = NULL;
@@ -495,8 +588,8 @@ int apt_oracle_decode(const apt_oracle_settings *s, const float *x, size_t n,
     float *sig = NULL, *coeff1 = NULL;
     size_t nsig = 0, ncoeff1 = 0;
     t0 = now_s();
-    rc = apt_oracle_resample_with_filter(x, n, input_rate, work_rate, f1, &sig, &nsig, &coeff1,
-                                         &ncoeff1, err, err_cap);
+    rc = apt_oracle_resample_with_filter_ex(x, n, input_rate, work_rate, f1, export_resample_filtered, &sig,
+                                            &nsig, &coeff1, &ncoeff1, expanded1, n_expanded1, err, err_cap);
     t1 = now_s();
     if (rc) return rc;
     if (steps) {
@@ -603,8 +696,9 @@ int apt_oracle_decode(const apt_oracle_settings *s, const float *x, size_t n,
      * -> l == 1 branch: filter([1.]) then decimate(m) */
     apt_oracle_filter_spec nf = {APT_FILTER_NOFILTER, 0.f, 0.f, 0.f};
     t0 = now_s();
-    rc = apt_oracle_resample_with_filter(aligned, naligned, work_rate, FINAL_RATE, nf, out, n_out,
-                                         NULL, NULL, err, err_cap);
+    rc = apt_oracle_resample_with_filter_ex(aligned, naligned, work_rate, FINAL_RATE, nf,
+                                            export_resample_filtered, out, n_out, NULL, NULL, expanded2,
+                                            n_expanded2, err, err_cap);
     t1 = now_s();
     if (steps) {
         steps->t_gather += t1 - t0;

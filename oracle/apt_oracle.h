@@ -104,6 +104,11 @@ void apt_oracle_filter_resample(apt_oracle_filter_spec *f, uint32_t in_rate, uin
 /* --- dsp.rs ------------------------------------------------------------- */
 float *apt_oracle_fast_resampling(const float *x, size_t n, uint32_t l, uint32_t m,
                                   const float *coeff, size_t ncoeff, size_t *n_out);
+/* the same with context.export_resample_filtered set (dsp.rs:265-273): other decimation phase,
+ * expanded_out (nullable) = the "resample_filtered" step */
+float *apt_oracle_fast_resampling_export(const float *x, size_t n, uint32_t l, uint32_t m,
+                                         const float *coeff, size_t ncoeff, size_t *n_out,
+                                         float **expanded_out, size_t *n_expanded);
 float *apt_oracle_decimate(const float *x, size_t n, uint32_t m, size_t *n_out);
 float *apt_oracle_demodulate(const float *x, size_t n, float carrier_pi_rad);
 float *apt_oracle_fir(const float *x, size_t n, const float *coeff, size_t ncoeff);
@@ -112,6 +117,10 @@ int apt_oracle_resample_with_filter(const float *x, size_t n, uint32_t in_rate,
                                     float **out, size_t *n_out,
                                     float **coeff_out, size_t *ncoeff_out,
                                     char *err, size_t err_cap);
+int apt_oracle_resample_with_filter_ex(const float *x, size_t n, uint32_t in_rate, uint32_t out_rate,
+                                       apt_oracle_filter_spec filt, int export_resample_filtered,
+                                       float **out, size_t *n_out, float **coeff_out, size_t *ncoeff_out,
+                                       float **expanded_out, size_t *n_expanded, char *err, size_t err_cap);
 /* dsp::resample (the WAV->WAV tool path, src/dsp.rs:132-162) */
 int apt_oracle_resample(const float *x, size_t n, uint32_t in_rate, uint32_t out_rate,
                         float atten, float delta_w_pi_rad, float **out, size_t *n_out,
@@ -128,6 +137,11 @@ int apt_oracle_find_sync(const float *x, size_t n, uint32_t work_rate,
 int apt_oracle_decode(const apt_oracle_settings *s, const float *x, size_t n,
                       uint32_t input_rate, int sync, float **out, size_t *n_out,
                       apt_oracle_steps *steps /* nullable */, char *err, size_t err_cap);
+
+int apt_oracle_decode_ex(const apt_oracle_settings *s, const float *x, size_t n, uint32_t input_rate,
+                         int sync, int export_resample_filtered, float **out, size_t *n_out,
+                         apt_oracle_steps *steps /* nullable */, float **expanded1, size_t *n_expanded1,
+                         float **expanded2, size_t *n_expanded2, char *err, size_t err_cap);
 
 /* --- consumers of decode()'s rows (apt_oracle_image.c) ---------- */
 /* dsp::get_max / get_min, src/dsp.rs:20-54 */

@@ -121,6 +121,14 @@ def lib():
     L.apt_oracle_decode.argtypes = [
         C.POINTER(Settings), _f32p, C.c_size_t, C.c_uint32, C.c_int, C.POINTER(_f32p),
         C.POINTER(C.c_size_t), C.POINTER(Steps), C.c_char_p, C.c_size_t]
+    L.apt_oracle_fast_resampling_export.restype = _f32p
+    L.apt_oracle_fast_resampling_export.argtypes = [_f32p, C.c_size_t, C.c_uint32, C.c_uint32, _f32p, C.c_size_t,
+                                                    C.POINTER(C.c_size_t), C.POINTER(_f32p), C.POINTER(C.c_size_t)]
+    L.apt_oracle_decode_ex.restype = C.c_int
+    L.apt_oracle_decode_ex.argtypes = [
+        C.POINTER(Settings), _f32p, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.POINTER(_f32p),
+        C.POINTER(C.c_size_t), C.POINTER(Steps), C.POINTER(_f32p), C.POINTER(C.c_size_t), C.POINTER(_f32p),
+        C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]
     L.apt_oracle_free.restype = None
     L.apt_oracle_free.argtypes = [C.c_void_p]
     L.apt_oracle_free_steps.restype = None
@@ -197,6 +205,16 @@ def fast_resampling(x, l, m, coeff):
     n = C.c_size_t()
     p = lib().apt_oracle_fast_resampling(xp, x.size, l, m, cp, c.size, C.byref(n))
     return _take(p, n.value)
+
+
+def fast_resampling_export(x, l, m, coeff):
+    """fast_resampling with context.export_resample_filtered set (dsp.rs:265-273): (output, expanded)."""
+    x, xp = _as_f32(x)
+    c, cp = _as_f32(coeff)
+    n, ne = C.c_size_t(), C.c_size_t()
+    ex = _f32p()
+    p = lib().apt_oracle_fast_resampling_export(xp, x.size, l, m, cp, c.size, C.byref(n), C.byref(ex), C.byref(ne))
+    return _take(p, n.value), _take(ex, ne.value)
 
 
 def decimate(x, m):
@@ -280,16 +298,26 @@ SLOW = dict(work_rate=20800, resample_atten=40.0, resample_delta_freq=500.0,
             resample_cutout=4800.0, demodulation_atten=25.0)
 
 
-def decode(x, input_rate, sync=True, settings=None, want_steps=False):
-    """Oracle decode(): returns rows (flat f32, len rows*2080) [and a dict of steps]."""
+def decode(x, input_rate, sync=True, settings=None, want_steps=False, export_resample_filtered=False):
+    """Oracle decode(): returns rows (flat f32, len rows*2080) [and a dict of steps].  export_resample_filtered is
+    Context.export_resample_filtered (context.rs:113): it moves the decimation phase of fast_resampling (dsp.rs:265-273);
+    with want_steps the dict then also holds "expanded1" / "expanded2", the two "resample_filtered" steps."""
     s = Settings(**(settings or STANDARD))
     x, xp = _as_f32(x)
     out, n = _f32p(), C.c_size_t()
     steps = Steps()
+    e1, ne1, e2, ne2 = _f32p(), C.c_size_t(), _f32p(), C.c_size_t()
+    want_ex = bool(want_steps and export_resample_filtered)
     err = C.create_string_buffer(1024)
-    rc = lib().apt_oracle_decode(C.byref(s), xp, x.size, input_rate, 1 if sync else 0,
-                                 C.byref(out), C.byref(n),
-                                 C.byref(steps) if want_steps else None, err, 1024)
+    rc = lib().apt_oracle_decode_ex(C.byref(s), xp, x.size, input_rate, 1 if sync else 0,
+                                    1 if export_resample_filtered else 0, C.byref(out), C.byref(n),
+                                    C.byref(steps) if want_steps else None,
+                                    C.byref(e1) if want_ex else None, C.byref(ne1) if want_ex else None,
+                                    C.byref(e2) if want_ex else None, C.byref(ne2) if want_ex else None, err, 1024)
+    expanded = {}
+    if want_ex:
+        expanded = dict(expanded1=_take(e1, ne1.value) if e1 else np.zeros(0, np.float32),
+                        expanded2=_take(e2, ne2.value) if e2 else np.zeros(0, np.float32))
     if rc != OK:
         if want_steps:
             lib().apt_oracle_free_steps(C.byref(steps))
@@ -298,6 +326,7 @@ def decode(x, input_rate, sync=True, settings=None, want_steps=False):
     if not want_steps:
         return rows
     d = dict(
+        **expanded,
         resample_filter=_copy(steps.resample_filter, steps.n_resample_filter),
         resampled=_copy(steps.resampled, steps.n_resampled),
         demodulated=_copy(steps.demodulated, steps.n_demodulated),

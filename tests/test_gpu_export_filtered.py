@@ -1,0 +1,120 @@
+"""Settings.export_resample_filtered on the GPU path (/root/reference/src/config.rs:83 -> context.rs:113): the flag
+moves the decimation phase of fast_resampling (dsp.rs:265-273: (t + 1) % m == 0 instead of t = offset + k*m), so it
+changes decode()'s rows whether or not anything is exported, and with export_wav it delivers the expanded signal as
+the "resample_filtered" step (dsp.rs:269,281-285).  Bit-exact against the oracle's restatement of that branch
+(tests/test_oracle_export_filtered.py pins the restatement to a transcription of the loop)."""
+import numpy as np
+import pytest
+
+import noaa_apt_amd as apt
+from noaa_apt_amd.testing.synth import synth_apt
+from noaa_apt_amd.testing.wavfile import make_wav
+
+pytestmark = pytest.mark.gpu
+
+f32 = np.float32
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, f32).view(np.uint32)
+
+
+def assert_bitexact(got, want, what=""):
+    got, want = np.asarray(got, f32), np.asarray(want, f32)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.array_equal(_bits(got), _bits(want)), what
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert apt.device_count() >= 1, "no HIP device: the GPU tests must run on the GPU box"
+    return apt.Context(device=0)
+
+
+def _settings(profile, **kw):
+    s = apt.Settings.profile(profile)
+    s.export_resample_filtered = True
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+CASES = [(48000, 7, "standard"), (11025, 7, "standard"), (44100, 7, "standard"), (48000, 7, "fast"), (48000, 7, "slow"),
+         (12480, 7, "standard")]  # the last one: l == 1, fast_resampling is not called and the flag changes nothing
+
+
+@pytest.mark.parametrize("sync", [True, False])
+@pytest.mark.parametrize("rate,seconds,profile", CASES)
+def test_flag_moves_the_decimation_phase(ctx, oracle, rate, seconds, profile, sync):
+    x = synth_apt(rate, seconds, 40 + rate % 97)
+    o = {"standard": oracle.STANDARD, "fast": oracle.FAST, "slow": oracle.SLOW}[profile]
+    rows, st = apt.decode(ctx, _settings(profile), x, apt.Rate.hz(rate), sync, return_stats=True)
+    want = oracle.decode(x, rate, sync, settings=o, export_resample_filtered=True)
+    assert_bitexact(rows, want, "rows under export_resample_filtered")
+    normal = apt.decode(ctx, apt.Settings.profile(profile), x, apt.Rate.hz(rate), sync)
+    if st.l > 1:
+        assert st.fused == 0  # the unfused kernels serve this mode
+        assert rows.size != normal.size or not np.array_equal(_bits(rows), _bits(normal))
+    else:
+        assert_bitexact(rows, normal)
+    # a second call comes from the session cache (its key holds the flag) and a normal call in between must not
+    # have replaced the plan
+    again = apt.decode(ctx, _settings(profile), x, apt.Rate.hz(rate), sync)
+    assert_bitexact(again, want)
+
+
+@pytest.mark.parametrize("sync", [True, False])
+def test_expanded_signal_is_exported(oracle, sync):
+    x = synth_apt(48000, 7, 77)
+    got = []
+    c = apt.Context(step_callback=lambda i, v, d, r: got.append((i, v, d, r)), device=0)
+    rows = apt.decode(c, _settings("standard", export_wav=True), x, apt.Rate.hz(48000), sync)
+    want_rows, st = oracle.decode(x, 48000, sync, want_steps=True, export_resample_filtered=True)
+    assert_bitexact(rows, want_rows)
+    by = {}
+    for i, v, d, r in got:
+        by.setdefault(i, []).append((v, d, r))
+    assert [g[0] for g in got][:4] == ["input", "resample_filter", "resample_filtered", "resample_decimated"]
+    assert by["resample_filtered"][0][2] == 48000 * 13
+    assert_bitexact(by["resample_filtered"][0][1], st["expanded1"], "expanded signal")
+    assert_bitexact(by["resample_decimated"][0][1], st["resampled"])
+    assert_bitexact(by["demodulation_result"][0][1], st["demodulated"])
+    assert_bitexact(by["filter_result"][0][1], st["filtered"])
+    if sync:
+        assert_bitexact(by["sync_correlation"][0][1], st["correlation"])
+        assert_bitexact(by["sync_result"][0][1], st["aligned"])
+    # the final stage of a stock profile is filter + decimate (l == 1): its "resample_filtered" is the filtered signal
+    assert_bitexact(by["resample_filtered"][1][1], st["expanded2"])
+    assert_bitexact(by["resample_decimated"][1][1], want_rows)
+
+
+def test_expanded_signal_of_the_final_stage(oracle):
+    """work_rate 11025 (4160 does not divide it; no-sync only): the NoFilter resample to 4160 Hz is fast_resampling
+    too (l2 = 832, m2 = 2205) and follows the flag."""
+    x = synth_apt(48000, 6, 78)
+    got = []
+    c = apt.Context(step_callback=lambda i, v, d, r: got.append((i, v, d, r)), device=0)
+    rows = apt.decode(c, _settings("standard", export_wav=True, work_rate=11025), x, apt.Rate.hz(48000), False)
+    s = dict(oracle.STANDARD, work_rate=11025)
+    want_rows, st = oracle.decode(x, 48000, False, settings=s, want_steps=True, export_resample_filtered=True)
+    assert_bitexact(rows, want_rows)
+    ex = [g for g in got if g[0] == "resample_filtered"]
+    assert len(ex) == 2 and ex[0][3] == 48000 * 147 and ex[1][3] == 11025 * 832
+    assert_bitexact(ex[0][2], st["expanded1"], "expanded signal, first resample")
+    assert_bitexact(ex[1][2], st["expanded2"], "expanded signal, final resample")
+    # and without the step export the rows are the same ones
+    rows2 = apt.decode(None, _settings("standard", work_rate=11025), x, apt.Rate.hz(48000), False)
+    assert_bitexact(rows2, want_rows)
+
+
+def test_wav_input_and_batch_follow_the_flag(ctx, oracle):
+    xs = [synth_apt(11025, 7, 91), synth_apt(11025, 8, 92)]
+    want = [oracle.decode(x, 11025, True, export_resample_filtered=True) for x in xs]
+    out = apt.decode_batch(ctx, _settings("standard"), xs, apt.Rate.hz(11025), True)
+    for r, w in zip(out, want):
+        assert not isinstance(r, Exception), r
+        assert_bitexact(r, w)
+    wav = make_wav(xs[0].astype(np.int16), 11025)  # the synthetic recordings are int16-valued (wav.rs:37 hands them over unscaled)
+    rows, st = apt.decode_wav(ctx, _settings("standard"), wav, True, return_stats=True)
+    assert st.fused == 0
+    assert_bitexact(rows, want[0])

@@ -1,0 +1,122 @@
+"""The oracle's restatement of fast_resampling's OTHER branch — context.export_resample_filtered set
+(/root/reference/src/dsp.rs:211-223,265-273): every t of the interpolated axis is evaluated, all sums go to the
+"resample_filtered" step and the output keeps the ones with (t + 1) % m == 0, a different decimation phase than the
+t = offset + k*m of the normal branch — against a line-by-line pure-Python transcription on small inputs, against the
+closed form the product uses for its lengths, and against the normal branch where the two must agree."""
+import numpy as np
+import pytest
+
+from noaa_apt_amd.testing.synth import synth_apt
+
+f32 = np.float32
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, f32).view(np.uint32)
+
+
+def _loop(signal, l, m, coeff, export):
+    """dsp.rs:186-289, statement by statement (f32 products and sums, u64 indices)."""
+    interpolated_len = len(signal) * l
+    output, expanded = [], []
+    offset = (len(coeff) - 1) // 2
+    t = offset
+    while t < interpolated_len:
+        if t > offset:
+            n = t - offset
+            rem = n % l
+            if rem != 0:
+                n += l - rem
+        else:
+            n = 0
+        s = f32(0.0)
+        x = n // l
+        while n <= t + offset:
+            if x < len(signal):
+                s = f32(s + f32(coeff[n + offset - t] * signal[x]))
+            x += 1
+            n += l
+        if export:
+            expanded.append(s)
+            t += 1
+            if t % m == 0:
+                output.append(s)
+        else:
+            output.append(s)
+            t += m
+    return np.array(output, f32), np.array(expanded, f32)
+
+
+CASES = [(13, 50, 959, 400), (3, 2, 41, 300), (208, 735, 1405, 60), (2, 3, 1, 500), (5, 3, 1, 333), (7, 4, 8, 200),
+         (832, 735, 1999, 25), (3, 2, 41, 5), (13, 50, 959, 20)]
+
+
+@pytest.mark.parametrize("l,m,ntaps,n", CASES)
+def test_export_branch_matches_the_transcription(oracle, l, m, ntaps, n):
+    rng = np.random.default_rng(l * 1000 + m)
+    x = (rng.standard_normal(n) * 1000).astype(f32)
+    c = (rng.standard_normal(ntaps) / l).astype(f32)
+    out, ex = oracle.fast_resampling_export(x, l, m, c)
+    want_out, want_ex = _loop(x, l, m, c, True)
+    assert out.shape == want_out.shape and ex.shape == want_ex.shape
+    assert np.array_equal(_bits(out), _bits(want_out))
+    assert np.array_equal(_bits(ex), _bits(want_ex))
+    # the transcription's normal branch is the oracle's normal branch too
+    nrm = oracle.fast_resampling(x, l, m, c)
+    assert np.array_equal(_bits(nrm), _bits(_loop(x, l, m, c, False)[0]))
+
+
+@pytest.mark.parametrize("l,m,ntaps,n", CASES)
+def test_export_branch_closed_form(oracle, l, m, ntaps, n):
+    """What the product computes lengths and positions from (apt_host.cpp fast_resampling_export_geom): expanded has
+    n*l - off sums; the output is expanded[d0 + k*m] with d0 = j0*m - 1 - off, j0 = ceil((off + 1) / m), for
+    j0 <= j <= n*l / m; and the normal branch is expanded[k*m]."""
+    rng = np.random.default_rng(7 + n)
+    x = rng.standard_normal(n).astype(f32)
+    c = rng.standard_normal(ntaps).astype(f32)
+    out, ex = oracle.fast_resampling_export(x, l, m, c)
+    off, total = (ntaps - 1) // 2, n * l
+    assert ex.size == max(total - off, 0)
+    j0, j1 = (off + m) // m, total // m
+    count = j1 - j0 + 1 if j1 >= j0 and total > off else 0
+    assert out.size == count
+    d0 = j0 * m - 1 - off
+    assert np.array_equal(_bits(out), _bits(ex[d0 + np.arange(count) * m]))
+    nrm = oracle.fast_resampling(x, l, m, c)
+    assert np.array_equal(_bits(nrm), _bits(ex[np.arange(nrm.size) * m]))
+
+
+@pytest.mark.parametrize("sync", [True, False])
+def test_decode_with_the_flag(oracle, sync):
+    """decode() under export_resample_filtered: another first-resample output (same taps, shifted phase), hence
+    other rows; the first "resample_filtered" step is the expanded signal the output was cut from."""
+    x = synth_apt(48000, 7, 3)
+    rows, st = oracle.decode(x, 48000, sync, want_steps=True, export_resample_filtered=True)
+    normal, st0 = oracle.decode(x, 48000, sync, want_steps=True)
+    assert rows.size % 2080 == 0 and rows.size > 0
+    assert np.array_equal(_bits(st["resample_filter"]), _bits(st0["resample_filter"]))
+    off, m = (st["resample_filter"].size - 1) // 2, 50
+    assert st["expanded1"].size == x.size * 13 - off
+    d0 = (off + m) // m * m - 1 - off
+    assert np.array_equal(_bits(st["resampled"]), _bits(st["expanded1"][d0 + np.arange(st["resampled"].size) * m]))
+    assert np.array_equal(_bits(st0["resampled"]), _bits(st["expanded1"][np.arange(st0["resampled"].size) * m]))
+    assert not np.array_equal(_bits(st["resampled"][:1000]), _bits(st0["resampled"][:1000]))
+    # the final stage of a stock profile is filter([1.]) + decimate (l == 1): its step is the filtered signal
+    assert st["expanded2"].size == st["aligned"].size
+    assert rows.size != normal.size or not np.array_equal(_bits(rows), _bits(normal))
+
+
+def test_decode_with_the_flag_final_stage(oracle):
+    """A work rate that 4160 does not divide (no-sync only): the final resample is fast_resampling as well, with the
+    single tap of NoFilter — its expanded signal is the cropped signal with l - 1 zeros between samples."""
+    x = synth_apt(48000, 6, 5)
+    s = dict(oracle.STANDARD, work_rate=11025)
+    rows, st = oracle.decode(x, 48000, False, settings=s, want_steps=True, export_resample_filtered=True)
+    l2, m2 = 832, 2205  # 4160 / 5, 11025 / 5
+    a = st["aligned"]
+    assert st["expanded2"].size == a.size * l2
+    up = st["expanded2"].reshape(-1, l2)
+    assert np.array_equal(_bits(up[:, 0]), _bits(a + f32(0.0))) and not up[:, 1:].any()
+    count = a.size * l2 // m2
+    assert rows.size == count
+    assert np.array_equal(_bits(rows), _bits(st["expanded2"][m2 - 1 + np.arange(count) * m2]))
