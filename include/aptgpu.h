@@ -497,6 +497,19 @@ int aptgpu_resample_wav(const aptgpu_context *ctx, const void *file_bytes, size_
 int aptgpu_resample_wav_file(const aptgpu_context *ctx, const char *input_path,
                              const char *output_path, uint32_t output_rate_hz, float atten,
                              float delta_w_pi_rad, char *err, size_t err_cap);
+/* Both with Context::resample's second flag (src/context.rs:214-218; main.rs:125-130 passes
+ * settings.export_resample_filtered): nonzero = fast_resampling's other decimation phase
+ * (src/dsp.rs:265-273) and, when ctx->step is set, the expanded signal in "resample_filtered".
+ * With ctx->step set every entry point of this section delivers the steps of Context::resample in the
+ * reference's order: "input", "resample_filter", "resample_filtered", "resample_decimated". */
+int aptgpu_resample_wav_ex(const aptgpu_context *ctx, const void *file_bytes, size_t n,
+                           uint32_t output_rate_hz, float atten, float delta_w_pi_rad,
+                           int export_resample_filtered, const char *output_name, void **wav_out,
+                           size_t *n_out, char *err, size_t err_cap);
+int aptgpu_resample_wav_file_ex(const aptgpu_context *ctx, const char *input_path,
+                                const char *output_path, uint32_t output_rate_hz, float atten,
+                                float delta_w_pi_rad, int export_resample_filtered, char *err,
+                                size_t err_cap);
 
 /* ====================================================================== */
 /* 6. misc                                                                 */

@@ -246,6 +246,9 @@ def lib():
     L.aptgpu_resample_wav.argtypes = [cp, C.c_char_p, sz, u32, f, f, C.c_char_p, C.POINTER(vp),
                                       C.POINTER(sz), C.c_char_p, sz]
     L.aptgpu_resample_wav_file.argtypes = [cp, C.c_char_p, C.c_char_p, u32, f, f, C.c_char_p, sz]
+    L.aptgpu_resample_wav_ex.argtypes = [cp, C.c_char_p, sz, u32, f, f, i32, C.c_char_p, C.POINTER(vp),
+                                         C.POINTER(sz), C.c_char_p, sz]
+    L.aptgpu_resample_wav_file_ex.argtypes = [cp, C.c_char_p, C.c_char_p, u32, f, f, i32, C.c_char_p, sz]
     L.aptgpu_plan_decode_device_wav.argtypes = [vp, i32, C.POINTER(vp), wsp, C.POINTER(vp),
                                                 C.POINTER(sz), C.c_char_p, sz]
     i32p = C.POINTER(C.c_int32)
@@ -633,16 +636,17 @@ def resample_wav(context, settings, input_wav, output_filename, output_rate: int
     output file's bytes back (output_filename then only labels the status text)."""
     cctx = (context or Context())._c()
     atten, delta = settings.wav_resample_atten, settings.wav_resample_delta_freq
+    flag = 1 if settings.export_resample_filtered else 0  # main.rs:125-130 -> Context::resample
     err = C.create_string_buffer(_ERRCAP)
     if isinstance(input_wav, (bytes, bytearray, memoryview)):
         data = bytes(input_wav)
         out, n = C.c_void_p(), C.c_size_t()
         name = os.fsencode(output_filename) if output_filename else None
-        _check(lib().aptgpu_resample_wav(C.byref(cctx), data, len(data), output_rate, atten, delta, name,
-                                         C.byref(out), C.byref(n), err, _ERRCAP), err)
+        _check(lib().aptgpu_resample_wav_ex(C.byref(cctx), data, len(data), output_rate, atten, delta, flag, name,
+                                            C.byref(out), C.byref(n), err, _ERRCAP), err)
         return _take_bytes(out, n.value)
-    _check(lib().aptgpu_resample_wav_file(C.byref(cctx), os.fsencode(input_wav), os.fsencode(output_filename),
-                                          output_rate, atten, delta, err, _ERRCAP), err)
+    _check(lib().aptgpu_resample_wav_file_ex(C.byref(cctx), os.fsencode(input_wav), os.fsencode(output_filename),
+                                             output_rate, atten, delta, flag, err, _ERRCAP), err)
     return None
 
 

@@ -109,13 +109,23 @@ struct Scratch {
     }
 };
 
-// resample_with_filter (dsp.rs:62-126) on a signal already in HBM; returns the output length
+// resample_with_filter (dsp.rs:62-126) on a signal already in HBM; returns the output length.
+// steps_ctx (nullable; used when it has a step callback): the Context::step calls of dsp.rs:96-122 and of
+// fast_resampling (:281-285) in the reference's order.  export_filtered: context.export_resample_filtered — the other
+// decimation phase of fast_resampling (dsp.rs:265-273) and, with steps, the expanded signal.
 inline uint64_t resample_device(Scratch &sc, const float *d_x, size_t n, uint32_t in_hz, uint32_t out_hz,
-                                apt::Filter &filt, apt::DeviceBuffer<float> &d_y)
+                                apt::Filter &filt, apt::DeviceBuffer<float> &d_y, bool export_filtered = false,
+                                const aptgpu_context *steps_ctx = nullptr)
 {
     if (out_hz == 0) throw Error{ErrorKind::Internal, "Can't resample to 0Hz"};  // dsp.rs:69-71
+    const bool on = steps_ctx && steps_ctx->step;
     const apt::Rate in_rate = apt::Rate::hz(in_hz), out_rate = apt::Rate::hz(out_hz);
     const apt::LM lm = apt::interpolation_factors(in_rate, out_rate);
+    auto export_signal = [&](const char *id, const float *d, uint64_t count, uint32_t rate) {
+        float *h = sc.download_malloc(d, count);
+        struct Free { float *p; ~Free() { std::free(p); } } guard{h};
+        step(steps_ctx, on, id, 0, h, count, rate);
+    };
     uint64_t w;
     if (lm.l > 1) {
         apt::Rate interpolated{};
@@ -130,20 +140,43 @@ inline uint64_t resample_device(Scratch &sc, const float *d_x, size_t n, uint32_
         }
         filt.resample(in_rate, interpolated);
         const apt::Signal coeff = filt.design();
-        w = apt::fast_resampling_len(n, lm.l, lm.m, coeff.size());
+        const uint32_t ntaps = static_cast<uint32_t>(coeff.size());
+        step(steps_ctx, on, "resample_filter", 1, coeff.data(), coeff.size(), 0);  // dsp.rs:96
         auto d_c = sc.upload(coeff.data(), coeff.size());
-        d_y.alloc(w + 16);
-        apt::gpu::resample_generic(sc.stream, d_x, n, d_c.ptr, static_cast<uint32_t>(coeff.size()), lm.l, lm.m,
-                                   d_y.ptr, w);
+        if (export_filtered) {
+            const apt::ExportGeom g = apt::fast_resampling_export_geom(n, lm.l, lm.m, coeff.size());
+            w = g.count;
+            d_y.alloc(w + 16);
+            apt::resample_at(sc.stream, d_x, n, d_c.ptr, ntaps, lm.l, g.d0, lm.m, d_y.ptr, w);
+            if (on) {  // dsp.rs:269,281-285
+                apt::DeviceBuffer<float> d_ex;
+                d_ex.alloc(g.expanded + 16);
+                apt::resample_at(sc.stream, d_x, n, d_c.ptr, ntaps, lm.l, 0, 1, d_ex.ptr, g.expanded);
+                export_signal("resample_filtered", d_ex.ptr, g.expanded, in_hz * lm.l);
+            }
+        } else {
+            w = apt::fast_resampling_len(n, lm.l, lm.m, coeff.size());
+            d_y.alloc(w + 16);
+            apt::gpu::resample_generic(sc.stream, d_x, n, d_c.ptr, ntaps, lm.l, lm.m, d_y.ptr, w);
+            step(steps_ctx, on, "resample_filtered", 0, nullptr, 0, in_hz * lm.l);  // empty unless exporting it
+        }
         apt::hip_check(hipStreamSynchronize(sc.stream), "hipStreamSynchronize");  // d_c goes out of scope
     } else {
         const apt::Signal coeff = filt.design();
+        step(steps_ctx, on, "resample_filter", 1, coeff.data(), coeff.size(), 0);  // dsp.rs:106
         w = n / lm.m;
         auto d_c = sc.upload(coeff.data(), coeff.size());
         d_y.alloc(w + 16);
+        if (on) {  // dsp.rs:108-114: the filtered signal before the decimation
+            apt::DeviceBuffer<float> d_f;
+            d_f.alloc(n + 16);
+            apt::gpu::fir_decimate(sc.stream, d_x, n, d_c.ptr, static_cast<uint32_t>(coeff.size()), 1, d_f.ptr, n);
+            export_signal("resample_filtered", d_f.ptr, n, in_hz);
+        }
         apt::gpu::fir_decimate(sc.stream, d_x, n, d_c.ptr, static_cast<uint32_t>(coeff.size()), lm.m, d_y.ptr, w);
         apt::hip_check(hipStreamSynchronize(sc.stream), "hipStreamSynchronize");
     }
+    if (on) export_signal("resample_decimated", d_y.ptr, w, out_hz);  // dsp.rs:100-104,118-122
     return w;
 }
 

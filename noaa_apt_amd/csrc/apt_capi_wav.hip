@@ -114,7 +114,7 @@ void *to_malloc(const std::vector<uint8_t> &v)
 // resample::resample (resample.rs:17-71) between file images
 std::vector<uint8_t> resample_wav_impl(const aptgpu_context *ctx, const uint8_t *bytes, size_t n,
                                        uint32_t output_rate, float atten, float delta_w_pi_rad,
-                                       const char *output_name, bool reading_announced)
+                                       const char *output_name, bool reading_announced, bool export_filtered)
 {
     if (!reading_announced) status(ctx, 0.0f, "Reading WAV file");  // resample.rs:25
     const apt::WavInfo w = apt::parse_wav(bytes, n);
@@ -144,7 +144,7 @@ std::vector<uint8_t> resample_wav_impl(const aptgpu_context *ctx, const uint8_t 
                                  : apt::Freq::hz(static_cast<float>(output_rate) / 2.f, in_rate);
     apt::Lowpass f(cutout, atten, apt::Freq::pi_rad(delta_w_pi_rad));
     apt::DeviceBuffer<float> d_y;
-    const uint64_t n_res = resample_device(sc, d_sig.ptr, w.n_frames, w.sample_rate, output_rate, f, d_y);
+    const uint64_t n_res = resample_device(sc, d_sig.ptr, w.n_frames, w.sample_rate, output_rate, f, d_y, export_filtered, ctx);
     if (n_res == 0)  // resample.rs:45-51
         throw Error{ErrorKind::Internal,
                     "Got zero samples after resampling, audio file too short or output sampling frequency too low"};
@@ -177,12 +177,21 @@ int aptgpu_resample_wav(const aptgpu_context *ctx, const void *file_bytes, size_
                         float atten, float delta_w_pi_rad, const char *output_name, void **wav_out,
                         size_t *n_out, char *err, size_t err_cap)
 {
+    return aptgpu_resample_wav_ex(ctx, file_bytes, n, output_rate_hz, atten, delta_w_pi_rad, 0, output_name, wav_out,
+                                  n_out, err, err_cap);
+}
+
+int aptgpu_resample_wav_ex(const aptgpu_context *ctx, const void *file_bytes, size_t n, uint32_t output_rate_hz,
+                           float atten, float delta_w_pi_rad, int export_resample_filtered, const char *output_name,
+                           void **wav_out, size_t *n_out, char *err, size_t err_cap)
+{
     if ((!file_bytes && n) || !wav_out || !n_out) return APTGPU_ERR_INVALID;
     *wav_out = nullptr;
     *n_out = 0;
     return guarded(err, err_cap, [&] {
         const std::vector<uint8_t> file = resample_wav_impl(ctx, static_cast<const uint8_t *>(file_bytes), n,
-                                                            output_rate_hz, atten, delta_w_pi_rad, output_name, false);
+                                                            output_rate_hz, atten, delta_w_pi_rad, output_name, false,
+                                                            export_resample_filtered != 0);
         *wav_out = to_malloc(file);
         *n_out = file.size();
         status(ctx, 1.f, "Finished");  // resample.rs:69
@@ -194,6 +203,13 @@ int aptgpu_resample_wav_file(const aptgpu_context *ctx, const char *input_path, 
                              uint32_t output_rate_hz, float atten, float delta_w_pi_rad, char *err,
                              size_t err_cap)
 {
+    return aptgpu_resample_wav_file_ex(ctx, input_path, output_path, output_rate_hz, atten, delta_w_pi_rad, 0, err, err_cap);
+}
+
+int aptgpu_resample_wav_file_ex(const aptgpu_context *ctx, const char *input_path, const char *output_path,
+                                uint32_t output_rate_hz, float atten, float delta_w_pi_rad,
+                                int export_resample_filtered, char *err, size_t err_cap)
+{
     if (!input_path || !output_path) return APTGPU_ERR_INVALID;
     return guarded(err, err_cap, [&] {
         status(ctx, 0.0f, "Reading WAV file");
@@ -202,7 +218,7 @@ int aptgpu_resample_wav_file(const aptgpu_context *ctx, const char *input_path, 
         if (::stat(input_path, &st) != 0)  // misc::read_timestamp, misc.rs:181-194
             throw Error{ErrorKind::Internal, "Could not read metadata from input file: stat failed"};
         const std::vector<uint8_t> out = resample_wav_impl(ctx, in.data(), in.size(), output_rate_hz, atten,
-                                                           delta_w_pi_rad, output_path, true);
+                                                           delta_w_pi_rad, output_path, true, export_resample_filtered != 0);
         std::FILE *f = std::fopen(output_path, "wb");
         if (!f) throw Error{ErrorKind::Io, std::string("could not create ") + output_path};
         const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();

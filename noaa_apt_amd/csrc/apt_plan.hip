@@ -465,6 +465,9 @@ k_resample_at(const float *__restrict__ x, uint64_t n, const float *__restrict__
     }
 }
 
+}  // namespace
+
+namespace apt {
 void resample_at(hipStream_t s, const float *x, uint64_t n, const float *coeff, uint32_t ntaps, uint32_t l, uint64_t d0,
                  uint32_t step, float *out, uint64_t w)
 {
@@ -474,7 +477,8 @@ void resample_at(hipStream_t s, const float *x, uint64_t n, const float *coeff, 
     hipLaunchKernelGGL(k_resample_at, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, x, n, coeff, jlim, l, d0, step,
                        out, w);
 }
-}  // namespace
+}  // namespace apt
+using apt::resample_at;
 
 void aptgpu_plan::expanded_filtered(hipStream_t s, const float *d_x, uint64_t n, bool final_stage, float *d_out,
                                     uint64_t count)

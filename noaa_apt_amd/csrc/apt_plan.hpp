@@ -79,6 +79,14 @@ private:
 
 }  // namespace apt
 
+namespace apt {
+// fast_resampling (dsp.rs:186-289) evaluated at t = off + d0 + k*step of the interpolated axis, k < w (apt_plan.hip):
+// the export_resample_filtered branch (dsp.rs:265-273) — d0 from fast_resampling_export_geom and step = m for the output,
+// d0 = 0 and step = 1 for the expanded signal
+void resample_at(hipStream_t s, const float *x, uint64_t n, const float *coeff, uint32_t ntaps, uint32_t l, uint64_t d0,
+                 uint32_t step, float *out, uint64_t w);
+}  // namespace apt
+
 // The opaque C-ABI plan.
 struct aptgpu_plan {
     int device = 0;

@@ -459,6 +459,20 @@ int apt_oracle_resample(const float *x, size_t n, uint32_t in_rate, uint32_t out
                                            err, err_cap);
 }
 
+/* the same with Context.export_resample_filtered and the steps of Context::resample (context.rs:214-256):
+ * coeff_out = "resample_filter", expanded_out = "resample_filtered" (all nullable) */
+int apt_oracle_resample_ex(const float *x, size_t n, uint32_t in_rate, uint32_t out_rate, float atten,
+                           float delta_w_pi_rad, int export_resample_filtered, float **out, size_t *n_out,
+                           float **coeff_out, size_t *ncoeff_out, float **expanded_out, size_t *n_expanded,
+                           char *err, size_t err_cap)
+{
+    float cutout = out_rate > in_rate ? apt_oracle_freq_hz((float)in_rate / 2.f, in_rate)   /* :144 */
+                                      : apt_oracle_freq_hz((float)out_rate / 2.f, in_rate); /* :148 */
+    apt_oracle_filter_spec f = {APT_FILTER_LOWPASS, cutout, atten, delta_w_pi_rad};
+    return apt_oracle_resample_with_filter_ex(x, n, in_rate, out_rate, f, export_resample_filtered, out, n_out,
+                                              coeff_out, ncoeff_out, expanded_out, n_expanded, err, err_cap);
+}
+
 /* ---------------------------------------------------------------------- */
 /* decode.rs                                                               */
 /* ---------------------------------------------------------------------- */

@@ -126,6 +126,11 @@ int apt_oracle_resample(const float *x, size_t n, uint32_t in_rate, uint32_t out
                         float atten, float delta_w_pi_rad, float **out, size_t *n_out,
                         char *err, size_t err_cap);
 
+int apt_oracle_resample_ex(const float *x, size_t n, uint32_t in_rate, uint32_t out_rate, float atten,
+                           float delta_w_pi_rad, int export_resample_filtered, float **out, size_t *n_out,
+                           float **coeff_out, size_t *ncoeff_out, float **expanded_out, size_t *n_expanded,
+                           char *err, size_t err_cap);
+
 /* --- decode.rs ---------------------------------------------------------- */
 int apt_oracle_generate_sync_frame(uint32_t work_rate, int8_t **out, size_t *n_out,
                                    char *err, size_t err_cap);

@@ -124,6 +124,11 @@ def lib():
     L.apt_oracle_fast_resampling_export.restype = _f32p
     L.apt_oracle_fast_resampling_export.argtypes = [_f32p, C.c_size_t, C.c_uint32, C.c_uint32, _f32p, C.c_size_t,
                                                     C.POINTER(C.c_size_t), C.POINTER(_f32p), C.POINTER(C.c_size_t)]
+    L.apt_oracle_resample_ex.restype = C.c_int
+    L.apt_oracle_resample_ex.argtypes = [
+        _f32p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_int, C.POINTER(_f32p),
+        C.POINTER(C.c_size_t), C.POINTER(_f32p), C.POINTER(C.c_size_t), C.POINTER(_f32p), C.POINTER(C.c_size_t),
+        C.c_char_p, C.c_size_t]
     L.apt_oracle_decode_ex.restype = C.c_int
     L.apt_oracle_decode_ex.argtypes = [
         C.POINTER(Settings), _f32p, C.c_size_t, C.c_uint32, C.c_int, C.c_int, C.POINTER(_f32p),
@@ -265,6 +270,22 @@ def resample(x, in_rate, out_rate, atten, delta_w_pi_rad):
                                    C.byref(out), C.byref(n), err, 1024)
     _check(rc, err)
     return _take(out, n.value)
+
+
+def resample_ex(x, in_rate, out_rate, atten, delta_w_pi_rad, export_resample_filtered=False):
+    """dsp::resample under Context::resample(export_wav, export_resample_filtered): (output, dict of the steps
+    "resample_filter" / "resample_filtered" as the reference would export them)."""
+    x, xp = _as_f32(x)
+    out, n = _f32p(), C.c_size_t()
+    co, nco, ex, nex = _f32p(), C.c_size_t(), _f32p(), C.c_size_t()
+    err = C.create_string_buffer(1024)
+    rc = lib().apt_oracle_resample_ex(xp, x.size, in_rate, out_rate, atten, delta_w_pi_rad,
+                                      1 if export_resample_filtered else 0, C.byref(out), C.byref(n), C.byref(co),
+                                      C.byref(nco), C.byref(ex), C.byref(nex), err, 1024)
+    _check(rc, err)
+    steps = dict(resample_filter=_take(co, nco.value),
+                 resample_filtered=_take(ex, nex.value) if ex else np.zeros(0, np.float32))
+    return _take(out, n.value), steps
 
 
 def generate_sync_frame(work_rate):

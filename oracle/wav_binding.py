@@ -57,11 +57,17 @@ def write_wav_i16(signal, rate) -> bytes:
     return _b._take(out, n.value, np.uint8).tobytes()
 
 
-def resample_wav(file_bytes: bytes, output_rate, atten, delta_w_pi_rad) -> bytes:
-    """resample::resample (resample.rs:17-71) between file images."""
+def resample_wav(file_bytes: bytes, output_rate, atten, delta_w_pi_rad, export_resample_filtered=False,
+                 return_steps=False):
+    """resample::resample (resample.rs:17-71) between file images; return_steps: also the dict of what
+    Context::resample would export ("input", "resample_filter", "resample_filtered", "resample_decimated")."""
     sig, spec = load_wav(file_bytes)
-    res = _b.resample(sig, spec.sample_rate, output_rate, atten, delta_w_pi_rad)
+    res, steps = _b.resample_ex(sig, spec.sample_rate, output_rate, atten, delta_w_pi_rad, export_resample_filtered)
     if res.size == 0:
         raise _b.OracleError(1, "Got zero samples after resampling, audio file too short or output "
                                 "sampling frequency too low")
-    return write_wav_i16(res, output_rate)
+    out = write_wav_i16(res, output_rate)
+    if not return_steps:
+        return out
+    steps.update(input=sig, resample_decimated=res)
+    return out, steps

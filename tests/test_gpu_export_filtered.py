@@ -118,3 +118,42 @@ def test_wav_input_and_batch_follow_the_flag(ctx, oracle):
     rows, st = apt.decode_wav(ctx, _settings("standard"), wav, True, return_stats=True)
     assert st.fused == 0
     assert_bitexact(rows, want[0])
+
+
+# ---- the WAV -> WAV tool (resample.rs:17-71; main.rs:125-130 hands settings.export_resample_filtered to
+# Context::resample): the steps of Context::resample in the reference's order, and the flag
+@pytest.fixture(scope="module")
+def ow():
+    from oracle import wav_binding
+    wav_binding.lib()
+    return wav_binding
+
+
+@pytest.mark.parametrize("flag", [False, True])
+@pytest.mark.parametrize("in_rate,out_rate", [(11025, 48000), (11025, 6000), (11025, 3675), (48000, 11025)])
+def test_resample_tool_steps_and_flag(ow, in_rate, out_rate, flag):
+    x = synth_apt(in_rate, 2, seed=out_rate % 89)
+    data = make_wav(x.astype(np.int16), in_rate)
+    s = apt.Settings(export_resample_filtered=flag)
+    got = []
+    c = apt.Context(step_callback=lambda ident, variant, arr, rate: got.append((ident, variant, arr, rate)), device=0)
+    out = apt.resample_wav(c, s, data, "out.wav", out_rate)
+    want, st = ow.resample_wav(data, out_rate, s.wav_resample_atten, s.wav_resample_delta_freq,
+                               export_resample_filtered=flag, return_steps=True)
+    assert out == want
+    assert [g[0] for g in got] == ["input", "resample_filter", "resample_filtered", "resample_decimated"]
+    by = {g[0]: g for g in got}
+    assert_bitexact(by["input"][2], st["input"])
+    assert by["resample_filter"][1] == 1
+    assert_bitexact(by["resample_filter"][2], st["resample_filter"])
+    g = int(np.gcd(in_rate, out_rate))
+    l = out_rate // g
+    assert_bitexact(by["resample_filtered"][2], st["resample_filtered"], "resample_filtered")
+    assert by["resample_filtered"][3] == in_rate * l  # (input_rate itself where l == 1, dsp.rs:110-114)
+    assert (by["resample_filtered"][2].size > 0) == (flag or l == 1)
+    assert_bitexact(by["resample_decimated"][2], st["resample_decimated"])
+    assert by["resample_decimated"][3] == out_rate
+    # without a step callback: the same file
+    assert apt.resample_wav(None, s, data, None, out_rate) == want
+    if flag and l > 1:
+        assert want != ow.resample_wav(data, out_rate, s.wav_resample_atten, s.wav_resample_delta_freq)

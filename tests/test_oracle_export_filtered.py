@@ -120,3 +120,30 @@ def test_decode_with_the_flag_final_stage(oracle):
     count = a.size * l2 // m2
     assert rows.size == count
     assert np.array_equal(_bits(rows), _bits(st["expanded2"][m2 - 1 + np.arange(count) * m2]))
+
+
+@pytest.mark.parametrize("in_rate,out_rate", [(11025, 48000), (11025, 6000), (48000, 11025)])
+def test_resample_tool_with_the_flag(oracle, in_rate, out_rate):
+    """dsp::resample under Context::resample(.., export_resample_filtered) (main.rs:125-130): the Lowpass of
+    dsp.rs:132-162 through the export branch."""
+    x = synth_apt(in_rate, 1, 11)[:4000]
+    out, st = oracle.resample_ex(x, in_rate, out_rate, 40.0, 0.1, True)
+    nrm, st0 = oracle.resample_ex(x, in_rate, out_rate, 40.0, 0.1, False)
+    assert np.array_equal(_bits(nrm), _bits(oracle.resample(x, in_rate, out_rate, 40.0, 0.1)))
+    assert np.array_equal(_bits(st["resample_filter"]), _bits(st0["resample_filter"])) and st0["resample_filtered"].size == 0
+    g = np.gcd(in_rate, out_rate)
+    l, m = out_rate // g, in_rate // g
+    off = (st["resample_filter"].size - 1) // 2
+    ex = st["resample_filtered"]
+    assert ex.size == x.size * l - off
+    d0 = (off + m) // m * m - 1 - off
+    assert np.array_equal(_bits(out), _bits(ex[d0 + np.arange(out.size) * m]))
+    assert np.array_equal(_bits(nrm), _bits(ex[np.arange(nrm.size) * m]))
+
+
+def test_resample_tool_pure_decimation_ignores_the_flag(oracle):
+    x = synth_apt(11025, 1, 12)[:4000]
+    out, st = oracle.resample_ex(x, 11025, 3675, 40.0, 0.1, True)  # l == 1: filter + decimate (dsp.rs:106-122)
+    nrm, st0 = oracle.resample_ex(x, 11025, 3675, 40.0, 0.1, False)
+    assert np.array_equal(_bits(out), _bits(nrm))
+    assert st["resample_filtered"].size == x.size and np.array_equal(_bits(out), _bits(st["resample_filtered"][::3][:out.size]))
