@@ -33,6 +33,9 @@ CASES = [
     # the rates served by k_fused's phase-resident stage 1 (256- and 512-thread workgroups)
     ("apt44100_std", "apt", dict(rate_hz=44100, seconds=13, seed=8), 44100, "STANDARD", True),
     ("apt22050_std", "apt", dict(rate_hz=22050, seconds=14, seed=9), 22050, "STANDARD", True),
+    # Settings.export_resample_filtered: fast_resampling's other decimation phase (dsp.rs:265-273) and the expanded signal
+    ("apt48k_std_export_filtered", "apt", dict(rate_hz=48000, seconds=9, seed=12), 48000, "STANDARD", True, True),
+    ("apt11025_std_export_filtered", "apt", dict(rate_hz=11025, seconds=8, seed=13), 11025, "STANDARD", False, True),
 ]
 
 
@@ -45,9 +48,11 @@ def make_input(kind, args):
 
 
 def main():
-    for name, kind, args, rate, profile, sync in CASES:
+    for name, kind, args, rate, profile, sync, *rest in CASES:
+        export = bool(rest and rest[0])
         x = make_input(kind, args)
-        rows, st = oracle.decode(x, rate, sync, settings=getattr(oracle, profile), want_steps=True)
+        rows, st = oracle.decode(x, rate, sync, settings=getattr(oracle, profile), want_steps=True,
+                                 export_resample_filtered=export)
         img = rows.reshape(-1, 2080)
         g = {
             "name": name, "generator": kind, "args": args, "rate": rate, "profile": profile,
@@ -68,6 +73,10 @@ def main():
             # a few literal values as u32 bit patterns so a human can diff them
             "row3_first8_bits": [int(v) for v in img[3, :8].view(np.uint32)] if img.shape[0] > 3 else [],
         }
+        if export:  # (keys only where set: the files of the other cases stay byte-identical)
+            g["export_resample_filtered"] = True
+            g["n_expanded"] = int(st["expanded1"].size)
+            g["expanded_sha256"] = sha(st["expanded1"])
         with open(os.path.join(HERE, name + ".json"), "w") as f:
             json.dump(g, f, indent=1)
         print(name, g["n_rows"], "rows", g["rows_sha256"][:16])

@@ -29,7 +29,11 @@ def load(path):
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-5] for p in GOLDEN])
 def test_oracle_matches_golden(oracle, path):
     g, x = load(path)
-    rows, st = oracle.decode(x, g["rate"], g["sync"], settings=getattr(oracle, g["profile"]), want_steps=True)
+    export = bool(g.get("export_resample_filtered"))
+    rows, st = oracle.decode(x, g["rate"], g["sync"], settings=getattr(oracle, g["profile"]), want_steps=True,
+                             export_resample_filtered=export)
+    if export:
+        assert st["expanded1"].size == g["n_expanded"] and sha(st["expanded1"]) == g["expanded_sha256"]
     assert st["resample_filter"].size == g["n_resample_taps"]
     assert sha(st["resample_filter"]) == g["resample_filter_sha256"]
     assert sha(st["filter_filter"]) == g["filter_filter_sha256"]
@@ -48,12 +52,15 @@ def test_gpu_matches_golden(path):
     import noaa_apt_amd as apt
     g, x = load(path)
     s = apt.Settings.profile(g["profile"].lower())
+    s.export_resample_filtered = bool(g.get("export_resample_filtered"))
     # every exported step, hashed
     got = {}
     c = apt.Context(step_callback=lambda i, v, d, r: got.setdefault(i, []).append(d), device=0)
     rows = apt.decode(c, apt.Settings(**{**s.__dict__, "export_wav": True}), x, apt.Rate.hz(g["rate"]), g["sync"])
     assert sha(got["resample_filter"][0]) == g["resample_filter_sha256"]
     assert sha(got["resample_decimated"][0]) == g["resampled_sha256"]
+    if s.export_resample_filtered:
+        assert got["resample_filtered"][0].size == g["n_expanded"] and sha(got["resample_filtered"][0]) == g["expanded_sha256"]
     assert sha(got["demodulation_result"][0]) == g["demodulated_sha256"]
     assert sha(got["filter_result"][0]) == g["filtered_sha256"]
     if g["sync"]:
