@@ -193,6 +193,9 @@ struct FusedParams {
     float gm_slack;         // strict modes: half-width of a group's bounds per unit of sum|F| (fused_gm_slack)
     const float *table;     // TABLE mode: phase-major tap table [l][tpp] (fused_any_table)
     TableGeom tab;
+    // kModeMfma: the plain resampler taps and their count (the scalar path of tiles that hold a non-finite sample)
+    const float *coeff;
+    uint32_t t1;
 };
 // One launch over the recordings of `call`: x -> F (slot's filtered buffer) and, if prm->want_gm, the
 // per-group maxima of the sync cross-correlation.  Returns false if no specialisation matches.
@@ -200,6 +203,12 @@ struct FusedParams {
 // mode: 0 strict, 1 fp16 taps, 2 fast.
 bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, int mode,
                      bool pcm16, const CallArgs &call, const FusedParams *d_prm, uint64_t max_w, int lds_pad = 0);
+// kModeMfma (mode 3 of fused_front_end): which geometries have a matrix-core instantiation, and its table —
+// [3 pieces][K / 32][64 lanes][4 dwords] bf16 fragments of the banded Toeplitz matrix of the resampler (h = h0 + h1 + h2
+// exactly)
+bool fused_mfma_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
+uint32_t fused_mfma_table_dwords(uint32_t l, uint32_t m);
+void fused_mfma_table(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, uint32_t *table);
 // Table-driven stage 1 + the specialised work-rate stages (k_fused in TABLE mode): any (l, m, taps) whose
 // phase-major table and input tile fit two 512-thread workgroups per CU, standard-profile work-rate
 // stages (37-tap low-pass, pw = 3).  11 025 Hz (l = 832) is the rate this exists for.

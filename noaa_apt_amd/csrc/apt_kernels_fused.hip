@@ -172,6 +172,76 @@ bool fused_fast_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint
     return fused_supported(l, m, t1, t2, pw);
 }
 
+// ---- kModeMfma: the FIRs as banded Toeplitz products on the matrix cores (apt_kernels_fused_launch.hpp)
+bool fused_mfma_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
+{
+    if (l != 13 || t2 != 37 || pw != 3 || (t1 & 1u) == 0) return false;  // (Kaiser lengths are odd: filters.rs:164-167)
+    if (m == 50) return t1 <= static_cast<uint32_t>(kMfmaT1Max48k);
+    if (m == 100) return t1 <= static_cast<uint32_t>(kMfmaT1Max96k);
+    return false;
+}
+
+namespace {
+uint32_t mfma_kpad(uint32_t l, uint32_t m)
+{
+    const uint32_t t1max = m == 50 ? kMfmaT1Max48k : kMfmaT1Max96k;
+    const uint32_t win = ((l - 1) * m + l - 1) / l + (t1max + l - 1) / l;
+    return (win + 31u) / 32u * 32u;
+}
+// a row-major [rows <= 16][K] matrix -> A fragments of v_mfma_f32_16x16x32_bf16, three bf16 pieces per entry:
+// table[(piece * nks + s) * 64 + lane] = 8 halves = entries (row = lane & 15, k = 32 s + 8 (lane >> 4) + j), j < 8, of
+// piece 0 = the upper half of v's f32 pattern, piece 1 = that of v - piece 0, piece 2 = v - piece 0 - piece 1: three 8-bit
+// pieces of the 24-bit significand, v = p0 + p1 + p2 exactly (subnormal taps aside: their last piece is truncated)
+template <typename At>
+void mfma_fragments(At &&at, uint32_t nks, uint32_t *table)
+{
+    auto upper = [](float v) -> uint32_t {
+        uint32_t u;
+        __builtin_memcpy(&u, &v, 4);
+        return u >> 16;
+    };
+    auto value = [](uint32_t h) -> float {
+        const uint32_t u = h << 16;
+        float v;
+        __builtin_memcpy(&v, &u, 4);
+        return v;
+    };
+    for (uint32_t s = 0; s < nks; ++s)
+        for (uint32_t lane = 0; lane < 64; ++lane)
+            for (uint32_t jp = 0; jp < 4; ++jp) {
+                uint32_t w[3] = {0, 0, 0};
+                for (uint32_t h = 0; h < 2; ++h) {
+                    const float v = at(lane & 15u, 32u * s + 8u * (lane >> 4) + 2u * jp + h);
+                    const uint32_t p0 = upper(v);
+                    const float r1 = v - value(p0);
+                    const uint32_t p1 = upper(r1);
+                    const float r2 = r1 - value(p1);
+                    const uint32_t p2 = upper(r2);
+                    w[0] |= p0 << (16u * h);
+                    w[1] |= p1 << (16u * h);
+                    w[2] |= p2 << (16u * h);
+                }
+                for (uint32_t pc = 0; pc < 3; ++pc) table[((pc * nks + s) * 64u + lane) * 4u + jp] = w[pc];
+            }
+}
+}  // namespace
+
+uint32_t fused_mfma_table_dwords(uint32_t l, uint32_t m) { return 3u * (mfma_kpad(l, m) / 32u) * 64u * 4u; }
+
+// host: H[b][q] = coeff[p_b + (q - c_b) l] (0 outside the branch's taps): branch b of a window against window sample q
+// (dsp.rs:252-263; c_b = ceil(b m / l), p_b = c_b l - b m), rows 13 .. 15 zero
+void fused_mfma_table(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, uint32_t *table)
+{
+    auto at = [&](uint32_t b, uint32_t q) -> float {
+        if (b >= l) return 0.f;
+        const uint32_t cb = (b * m + l - 1) / l, pb = cb * l - b * m;
+        if (q < cb) return 0.f;
+        const uint64_t j = pb + static_cast<uint64_t>(q - cb) * l;
+        return j < t1 ? coeff[j] : 0.f;
+    };
+    mfma_fragments(at, mfma_kpad(l, m) / 32u, table);  // (no prescale: bf16 pieces carry f32's exponent)
+}
+
 bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, int mode,
                      bool pcm16, const CallArgs &call, const FusedParams *d_prm, uint64_t max_w, int lds_pad)
 {
@@ -180,6 +250,12 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
         for (uint32_t i = 0; i < call.count; ++i)
             if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 3u) return false;
     const FusedLaunch a{s, &call, d_prm, max_w, 0, lds_pad};
+    if (mode == kModeMfma) {
+        if (!fused_mfma_supported(l, m, t1, t2, pw)) return false;
+        if (m == 50) pcm16 ? fused_launch_48k_mfma_i16(a) : fused_launch_48k_mfma_f32(a);
+        else pcm16 ? fused_launch_96k_mfma_i16(a) : fused_launch_96k_mfma_f32(a);
+        return true;
+    }
     if (l == 13 && m == 50 && t1 == 959 && t2 == 37 && pw == 3) {
         if (mode == kModeF16Taps)  // fp16-tap stage 1: hb is the half2 table of fused_f16_branch_taps
             pcm16 ? fused_launch_48k_f16taps_i16(a) : fused_launch_48k_f16taps_f32(a);

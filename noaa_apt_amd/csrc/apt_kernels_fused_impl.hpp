@@ -57,6 +57,12 @@ namespace {
 #ifndef APT_FUSED_PERSIST
 #define APT_FUSED_PERSIST 0
 #endif
+// waves per SIMD the kModeMfma kernels are compiled for (= workgroups per CU; the LDS would hold six, the registers do
+// not: 119 VGPRs with sub-tile 1's loads in flight under sub-tile 0's products.  tools/probes/mfma_variants.sh builds the
+// other values: five and six workgroups spill and measured 12 % / 22 % slower)
+#ifndef APT_MFMA_WAVES
+#define APT_MFMA_WAVES 4
+#endif
 // Halo threads of a tile (FusedGeom::kPreThreads / kPostThreads).  The low-pass and the envelope need T2 + 1 = 38 work
 // samples of history, the correlation G - 1 = 113 of look-ahead: 3 + 9 threads of 13 samples in the specialised
 // kernels (round 2: 4 + 12 — a whole group of four either side; 244 instead of 240 of 256 threads own samples, 116
@@ -101,8 +107,11 @@ __host__ __device__ constexpr int branch_phase(int b)  // p_b = c_b*L - b*M
 // half the tile)
 // M == 0 selects the table-driven stage 1 (TABLE mode, see k_fused): the resampling factors, tap count and
 // input tile are then run-time quantities (FusedParams::tab) and only the work-rate geometry is static.
-template <int L, int M, int T1, int T2, int PW, int NTHR, int XB = 4, bool F16TAPS = false>
+// VAR (fused_geom_var): 0 the f32 stage 1, 1 the fp16-tap stage 1 (kModeF16Taps), 2 stage 1 on the matrix cores (kModeMfma:
+// the input tile is two bf16 planes of K-padded windows; T1 is then the LARGEST tap count the instantiation serves)
+template <int L, int M, int T1, int T2, int PW, int NTHR, int XB = 4, int VAR = 0>
 struct FusedGeom {
+    static constexpr bool F16TAPS = VAR == 1, MFMA = VAR == 2;
     static constexpr bool TABLE = M <= 0;   // run-time resampling factors (table-driven or phase-resident stage 1)
     static constexpr bool PHASE = M < 0;    // ... with the taps of a thread's -M polyphase branches in registers
     static constexpr int kFusedThreads = NTHR;
@@ -127,8 +136,9 @@ struct FusedGeom {
     static constexpr int XSHIFT = TABLE ? 0 : (4 - (kPreThreads * M) % 4) % 4;
     static_assert(TABLE || (kOwnThreads * M) % 4 == 0, "every tile starts at the same offset from a 16-byte boundary");
     static_assert(XSHIFT % 2 == 0, "window reads stay 8-byte aligned (and PCM16 pairs whole)");
-    static constexpr int XT = TABLE ? 4 : (NS - 1) * M + WIN + 2 + XSHIFT;  // input floats per (sub-)tile
-    static constexpr int XT_PAD = (XT + 3) & ~3;
+    static constexpr int KPAD = (WIN + 31) / 32 * 32;                 // MFMA: the window padded to whole K steps
+    static constexpr int XT = TABLE ? 4 : (NS - 1) * M + (MFMA ? KPAD : WIN + 2) + XSHIFT;  // input floats per (sub-)tile
+    static constexpr int XT_PAD = MFMA ? (XT + 7) & ~7 : (XT + 3) & ~3;
     static constexpr int G = 38 * PW;                                 // sync template length
     static constexpr int FWIN = L + G - 1;                            // F window per thread
     // one LDS region: the x tile, then R / F at [0, TILE_K) (+ the few words the last thread's pulse-sum window reads past
@@ -137,7 +147,8 @@ struct FusedGeom {
     // and the per-thread |F| sums had 256 words of their own: 28.5 KB, five workgroups per CU.  Trimmed — the |F| sums
     // now land on the dead F region — the work-rate stages need 26.1 KB: SIX workgroups per CU for kernels of <= 80 VGPRs.
     static constexpr int D_OFF = (TILE_K + 2 * PW + 2 + 3) & ~3;
-    static constexpr int XT_LDS = XB == 2 ? (XT_PAD / 2 + 4) : XT_PAD;  // floats of LDS under the x tile
+    // floats of LDS under the x tile (MFMA: two bf16 planes of XT_PAD samples, then the tile's non-finite flag)
+    static constexpr int XT_LDS = MFMA ? XT_PAD + 8 : XB == 2 ? (XT_PAD / 2 + 4) : XT_PAD;
     // the pulse sums a thread of stage 4 reads: positions p0 + 2 PW n, n <= 31, p0 <= PRE_K + (blocks - 1) * 2 PW L + 2 PW - 1
     static constexpr int NBLK4 = (OWN_K + 2 * PW * L - 1) / (2 * PW * L);
     static constexpr int QMAX = PRE_K + (NBLK4 - 1) * 2 * PW * L + 2 * PW - 1 + 2 * PW * 31;
@@ -244,7 +255,8 @@ template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
 __global__ void __launch_bounds__(NTHR, M < 0 ? ((NTHR > 512 ? 1 : NTHR > 256 ? 2 : (T1 == 1 ? (M == -1 ? 3 : 4) : T2 == 43 ? 4 : M == -4 ? 5 : M == -2 ? 5 : 3)) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs; the fast profile's and the streamed forms with several branches: four, <= 128; two or four branches per thread at the standard profile: five, <= 96), two 512-thread or one 1024-thread (<= 128) workgroups per CU */
                                      : M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
                                                /* specialised: as many workgroups as the CU's 160 KB of LDS hold (48 kHz SPLIT: 5, 96 kHz: 3) */
-                                               : (FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), MODE == kModeF16Taps>::WGS_PER_CU * NTHR + 255) / 256)
+                                               : MODE == kModeMfma ? APT_MFMA_WAVES
+                                               : (FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), fused_geom_var(MODE)>::WGS_PER_CU * NTHR + 255) / 256)
 k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 {
     // The call's arguments are read where they lie, in the kernel-argument segment (constant address
@@ -258,11 +270,12 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     // use, and the register allocator answered the extra pressure by spilling the table pointer
     // itself inside the hot loop.
     const cf2_ptr hs = (cf2_ptr)(prm->hs);  // [WIN][PS] tap pairs
-    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), MODE == kModeF16Taps>;
+    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), fused_geom_var(MODE)>;
     constexpr int kFusedThreads = NTHR;
     constexpr int kOwnThreads = Gm::kOwnThreads, kPreThreads = Gm::kPreThreads, kPostThreads = Gm::kPostThreads;
     constexpr bool F16 = MODE == kModeF16Taps;
-    constexpr bool FAST = MODE == kModeFast;
+    constexpr bool MFMA = MODE == kModeMfma;         // the FIRs on the matrix cores; everything else as kModeFast
+    constexpr bool FAST = MODE == kModeFast || MFMA;
     extern __shared__ float lds[];
     float *P = lds;                  // x tile -> R -> F
     float *Q = lds + Gm::D_OFF;      // D (inside the dead part of the x tile), later the pulse sums (fast mode)
@@ -891,8 +904,10 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 #pragma unroll
         for (int b = 0; b < L; ++b) r[b] = P[kq + b];
     } else {
+    if constexpr (!MFMA) {  // (the matrix-core stage 1 writes its own LDS image of the tile)
     tile_to_lds(xr);
     __syncthreads();
+    }
     if constexpr (APT_FUSED_STOP == 1) return;
     APT_MARK("BEGIN stage1");
 
@@ -956,6 +971,168 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         const float f16_unscale = prm->f16_unscale;  // 2^-s of the fp16 tap prescale
 #pragma unroll
         for (int b = 0; b < L; ++b) r[b] = (kq + b < k_lo || kq + b >= k_hi) ? 0.f : acc[b] * f16_unscale;
+    } else if constexpr (MFMA) {
+        // ---- stage 1 on the matrix cores (kModeMfma, apt_kernels_fused_launch.hpp): the SPLIT frame — two sub-tiles of NS
+        // windows through the same LDS — with each sub-tile as two bf16 planes (x = x0 + x1 + a remainder below 2^-16 |x|:
+        // none for 16-bit samples) and, per group of 16 windows, R[branch][window] = sum over K of H[branch][k] X[k][window]
+        // as five chains of v_mfma_f32_16x16x32_bf16 — h2 x0, h1 x1, h1 x0, h0 x1, h0 x0 with h = h0 + h1 + h2 exactly
+        // (three 8-bit pieces of the 24-bit tap) — accumulated in f32.  bf16 has f32's exponent: no scaling anywhere.
+        static_assert(Gm::SPLIT && L <= 16 && M % 2 == 0 && Gm::XSHIFT % 2 == 0, "windows start on sample pairs");
+        constexpr int NS = Gm::NS, NKS = Gm::KPAD / 32, PLANE = Gm::XT_PAD / 2;  // (dwords per plane)
+        constexpr int NGW = NS / 16 / (NTHR / 64);                                // window groups per wave and sub-tile
+        static_assert(NGW * 16 * (NTHR / 64) == NS, "whole groups per wave");
+        uint32_t *l32 = reinterpret_cast<uint32_t *>(lds);
+        uint32_t *nf_flag = l32 + 2 * PLANE;  // a non-finite result somewhere in the tile (see below)
+        const int lane = tid & 63, wave = tid >> 6;
+        typedef uint32_t u4m __attribute__((ext_vector_type(4)));
+        typedef __bf16 b8m __attribute__((ext_vector_type(8)));
+        auto as_b8 = [](u4m v) -> b8m { return __builtin_bit_cast(b8m, v); };
+        // H's fragments: [3 pieces][NKS][64 lanes] (fused_mfma_table), read per K step (L1-resident: 6 KB)
+        typedef const u4m __attribute__((address_space(1))) *gu4_ptr;
+        const gu4_ptr atab = (gu4_ptr)(prm->hs) + lane;
+        if (tid == 0) *nf_flag = 0u;
+        // registers -> the two planes: x0 = the upper half of the f32 pattern, x1 = the upper half of x - x0 (exact
+        // subtraction); PCM16: `*x as f32` (wav.rs:37) first
+        auto planes_to_lds = [&](const XReg (&xv)[NXR]) {
+#pragma unroll
+            for (int e = 0; e < NXR; ++e) {
+                const int q = (tid + e * kFusedThreads) * 4;
+                if (q < Gm::XT_PAD) {
+                    float v[4];
+                    if constexpr (sizeof(XT) == 4) {
+                        v[0] = xv[e].x, v[1] = xv[e].y, v[2] = xv[e].z, v[3] = xv[e].w;
+                    } else {
+                        v[0] = static_cast<float>(static_cast<int16_t>(xv[e].x & 0xFFFFu)), v[1] = static_cast<float>(static_cast<int32_t>(xv[e].x) >> 16);
+                        v[2] = static_cast<float>(static_cast<int16_t>(xv[e].y & 0xFFFFu)), v[3] = static_cast<float>(static_cast<int32_t>(xv[e].y) >> 16);
+                    }
+                    float r[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] = v[i] - __uint_as_float(__float_as_uint(v[i]) & 0xFFFF0000u);
+                    const u2 w0 = (u2){__builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u),
+                                       __builtin_amdgcn_perm(__float_as_uint(v[3]), __float_as_uint(v[2]), 0x07060302u)};
+                    const u2 w1 = (u2){__builtin_amdgcn_perm(__float_as_uint(r[1]), __float_as_uint(r[0]), 0x07060302u),
+                                       __builtin_amdgcn_perm(__float_as_uint(r[3]), __float_as_uint(r[2]), 0x07060302u)};
+                    *reinterpret_cast<u2 *>(l32 + q / 2) = w0;
+                    *reinterpret_cast<u2 *>(l32 + PLANE + q / 2) = w1;
+                }
+            }
+        };
+        f4 racc[2][NGW];
+        auto mfma_sub = [&](auto subc) {
+            constexpr int SUB = decltype(subc)::value;
+            int base[NGW];
+#pragma unroll
+            for (int g = 0; g < NGW; ++g) {
+                racc[SUB][g] = (f4){0.f, 0.f, 0.f, 0.f};
+                const int wl = (wave * NGW + g) * 16 + (lane & 15);
+                base[g] = wl * (M / 2) + Gm::XSHIFT / 2 + 4 * (lane >> 4);
+            }
+            // (H's fragments one K step ahead of the products that use them)
+            u4m an0 = atab[0], an1 = atab[NKS * 64], an2 = atab[2 * NKS * 64];
+#pragma unroll
+            for (int s_ = 0; s_ < NKS; ++s_) {
+                const u4m a0 = an0, a1 = an1, a2 = an2;
+                if (s_ + 1 < NKS) {
+                    an0 = atab[(s_ + 1) * 64];
+                    an1 = atab[(NKS + s_ + 1) * 64];
+                    an2 = atab[(2 * NKS + s_ + 1) * 64];
+                }
+                u4m b0[NGW], b1[NGW];
+#pragma unroll
+                for (int g = 0; g < NGW; ++g) {
+                    const uint32_t *bp = l32 + base[g] + 16 * s_;
+                    b0[g] = (u4m){bp[0], bp[1], bp[2], bp[3]};
+                    b1[g] = (u4m){bp[PLANE], bp[PLANE + 1], bp[PLANE + 2], bp[PLANE + 3]};
+                }
+                // (the small terms first; the groups alternate so that no MFMA waits for the one before it)
+#pragma unroll
+                for (int g = 0; g < NGW; ++g) racc[SUB][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_b8(a2), as_b8(b0[g]), racc[SUB][g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NGW; ++g) racc[SUB][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_b8(a1), as_b8(b1[g]), racc[SUB][g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NGW; ++g) racc[SUB][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_b8(a1), as_b8(b0[g]), racc[SUB][g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NGW; ++g) racc[SUB][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_b8(a0), as_b8(b1[g]), racc[SUB][g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NGW; ++g) racc[SUB][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_b8(a0), as_b8(b0[g]), racc[SUB][g], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // sub-tile 0 is in registers; sub-tile 1's loads are in flight under sub-tile 0's products
+        XReg xr1[NXR];
+        planes_to_lds(xr);
+        __builtin_amdgcn_sched_barrier(0);  // (sub-tile 1's loads behind sub-tile 0's conversion: 28 registers fewer)
+        load_tile(ri, tile, 1, xr1);
+        __syncthreads();
+        mfma_sub(std::integral_constant<int, 0>{});
+        __syncthreads();  // everyone is done reading sub-tile 0
+        planes_to_lds(xr1);
+        __syncthreads();
+        mfma_sub(std::integral_constant<int, 1>{});
+        APT_MARK("END stage1");
+        // A NaN or an infinity among the samples spreads over whole groups of the matrix product (0 x inf): the sum of a
+        // lane's results is then not finite, and the tile is evaluated again sample by sample below.  (An overflowing sum
+        // of finite results takes that path too: the same values, slowly.)
+        {
+            float sum = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int g = 0; g < NGW; ++g) sum += (racc[sub][g].x + racc[sub][g].y) + (racc[sub][g].z + racc[sub][g].w);
+            if ((__float_as_uint(sum) & 0x7F800000u) == 0x7F800000u) *nf_flag = 1u;
+        }
+        __syncthreads();  // everyone is done reading sub-tile 1: R may land on it
+        const bool tile_nf = *nf_flag != 0u;
+        {
+            // D: column = lane & 15 (window), row = 4 (lane >> 4) + register (branch)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int g = 0; g < NGW; ++g) {
+                    const int wdw = sub * NS + (wave * NGW + g) * 16 + (lane & 15);
+#pragma unroll
+                    for (int rr_ = 0; rr_ < 4; ++rr_) {
+                        const int b = 4 * (lane >> 4) + rr_;
+                        if (b < L) P[wdw * L + b] = racc[sub][g][rr_];
+                    }
+                }
+        }
+        if (tile_nf) {
+            // (wave-uniform; never on recordings) kModeFast's chain of fused multiply-adds, from HBM
+            __syncthreads();
+            const XT *__restrict__ xg = static_cast<const XT *>(call.rec[ri].x);
+            const uint64_t n_in = call.rec[ri].n;
+            const float *__restrict__ cf = prm->coeff;
+            const uint32_t t1r = prm->t1;
+            for (int b = 0; b < L; ++b) {
+                const int64_t k = (tile * Gm::OWN_K - Gm::PRE_K) + kq + b;
+                float sum = 0.f;
+                if (k >= 0) {
+                    const uint64_t v = static_cast<uint64_t>(k) * static_cast<uint64_t>(M);
+                    uint64_t x0 = (v + L - 1) / L;
+                    for (uint64_t j = x0 * L - v; j < t1r; j += L, ++x0)
+                        if (x0 < n_in) sum = __builtin_fmaf(cf[j], static_cast<float>(xg[x0]), sum);
+                }
+                P[tid * L + b] = sum;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < L; ++b) r[b] = P[tid * L + b];
+        if (!interior) {
+            bool any = false;
+#pragma unroll
+            for (int b = 0; b < L; ++b)
+                if (kq + b < k_lo || kq + b >= k_hi) {
+                    r[b] = 0.f;
+                    any = true;
+                }
+            if (any) {
+#pragma unroll
+                for (int b = 0; b < L; ++b) P[tid * L + b] = r[b];
+            }
+            __syncthreads();
+        }
     } else if constexpr (Gm::SPLIT) {
         // ---- SPLIT stage 1 (apt_kernels_fused_launch.hpp): two sub-tiles of NS windows through the same LDS; in each,
         // the threads of half h = tid / NS compute the branches [B0, B0 + NBR) of window wl = tid % NS.  Same
@@ -1836,7 +2013,7 @@ inline void ensure_dynamic_lds(size_t lds)
 template <int L, int M, int T1, int T2, int PW, int NTHR, int MODE, typename XT>
 void launch_fused_args(const FusedLaunch &a)
 {
-    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), MODE == kModeF16Taps>;
+    using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), fused_geom_var(MODE)>;
     size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
     if constexpr (Gm::TABLE) lds = std::max<size_t>(a.table_lds_floats, Gm::W_LDS_FLOATS) * sizeof(float);
     // APTGPU_FUSED_LDS_PAD=bytes (A/B switch, read at plan creation): more dynamic LDS than the kernel uses = fewer workgroups

@@ -10,6 +10,21 @@ namespace apt::gpu {
 constexpr int kModeStrict = 0;
 constexpr int kModeF16Taps = 1;
 constexpr int kModeFast = 2;
+// kModeMfma (round 6): APTGPU_MODE_FAST with the resampler on the matrix cores.  Stage 1 is the banded Toeplitz product
+// R[16 branches][16 windows] = H[16][K] X[K][16] through v_mfma_f32_16x16x32_bf16, f32 accumulation, on bf16 PIECES of the
+// f32 operands: taps h = h0 + h1 + h2 exactly (three 8-bit pieces, split on the host), samples x = x0 + x1 (+ a remainder
+// below 2^-16 |x|: none for 16-bit samples), split while the tile goes to LDS; five products (h0 x0, h0 x1, h1 x0, h1 x1,
+// h2 x0) carry every term above 2^-24 of the largest.  bf16 has f32's exponent range: no scaling.  The f32-input MFMA,
+// which would be bit-identical to kModeFast, shares the VALU's datapath and measured 0.66x; an f16 form with a
+// power-of-two scale per sub-tile measured at parity with the VALU kernel, this one 6 % behind it (fast
+// mode is bound by the tile's HBM round trip, not by the FIRs).  The work-rate stages behind are kModeFast's.  Tap COUNT
+// is a run-time quantity here (the table is zero-padded to the kernel's K): a tuned resample_atten / resample_delta_freq
+// stays on a specialised kernel while its taps per branch fit — what this mode is kept for.
+constexpr int kModeMfma = 3;
+// FusedGeom's variant argument for a mode
+constexpr int fused_geom_var(int mode) { return mode == kModeF16Taps ? 1 : mode == kModeMfma ? 2 : 0; }
+// tap counts the MFMA instantiations are compiled for (window of a tile's last branch + taps per branch <= K = 128 / 256)
+constexpr int kMfmaT1Max48k = 1053, kMfmaT1Max96k = 2119;
 
 // Window samples per stage-1 chunk (one scalar-load wait per chunk) of the specialised kernels; host (table builder)
 // and device agree through this and the layout functions below.  (Rounds 1-3: two samples x all 13 branches per chunk
@@ -71,6 +86,11 @@ void fused_launch_48k_fast_f32(const FusedLaunch &a);
 void fused_launch_48k_fast_i16(const FusedLaunch &a);
 void fused_launch_96k_fast_f32(const FusedLaunch &a);
 void fused_launch_96k_fast_i16(const FusedLaunch &a);
+// APTGPU_MODE_FAST on the matrix cores (kModeMfma): 48 / 96 kHz, standard profile, any tap count up to kMfmaT1Max*
+void fused_launch_48k_mfma_f32(const FusedLaunch &a);
+void fused_launch_48k_mfma_i16(const FusedLaunch &a);
+void fused_launch_96k_mfma_f32(const FusedLaunch &a);
+void fused_launch_96k_mfma_i16(const FusedLaunch &a);
 // 48 kHz at the slow profile (13 / 30, 2783 taps; 61-tap low-pass, pixel width 5): the same SPLIT form
 void fused_launch_48k_slow_f32(const FusedLaunch &a);
 void fused_launch_48k_slow_i16(const FusedLaunch &a);

@@ -254,7 +254,16 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         plan->fused = 0;
         const bool no_spec = force_any && force_any[0] == '1';
         const char *phase_first = std::getenv("APTGPU_PHASE_FIRST");  // tests: 0 = the table-driven stage 1 wherever it exists
-        if (eligible && gpu::fused_supported(plan->l, plan->m, t1, t2, plan->pw) && !no_spec)
+        // APTGPU_MODE_FAST on the matrix cores (kModeMfma: 48 / 96 kHz at the standard profile, ANY tap count its K holds).
+        // Measured at parity with / a few percent behind the VALU fast kernels at the stock tap counts (fast
+        // mode is bound by the tile's HBM round trip, not by the FIRs), so it serves the plans those kernels cannot — a tuned
+        // resample_atten / resample_delta_freq, which changes the tap count — and, APTGPU_FAST_MFMA=1 (A/B switch, tests), all
+        // it has an instantiation for; APTGPU_FAST_MFMA=0 switches it off.
+        const char *mfma_env = std::getenv("APTGPU_FAST_MFMA");
+        const bool mfma_want = mfma_env ? mfma_env[0] == '1' : !gpu::fused_supported(plan->l, plan->m, t1, t2, plan->pw);
+        const bool mfma_ok = eligible && !no_spec && plan->mode == APTGPU_MODE_FAST && mfma_want &&
+                             gpu::fused_mfma_supported(plan->l, plan->m, t1, t2, plan->pw);
+        if (eligible && (gpu::fused_supported(plan->l, plan->m, t1, t2, plan->pw) || mfma_ok) && !no_spec)
             plan->fused = 1;
         // (where both the table-driven and the phase-resident stage 1 exist, the latter: since round 5 — thread assignment
         // lists, interior tile loads, pipelined taps, two / four branches per thread — it is the faster one at every rate
@@ -283,11 +292,14 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
                              "(same results, lower throughput)\n",
                              plan->input_rate, plan->settings.work_rate, t1, t2, plan->fused);
         }
+        plan->fused_mfma = mfma_ok && plan->fused == 1;
         plan->fused_fast = plan->mode == APTGPU_MODE_FAST &&
-                           ((plan->fused == 1 && gpu::fused_fast_supported(plan->l, plan->m, t1, t2, plan->pw)) ||
+                           ((plan->fused == 1 && (plan->fused_mfma || gpu::fused_fast_supported(plan->l, plan->m, t1, t2, plan->pw))) ||
                             plan->fused == 3 || plan->fused == 4);
         // fp16-tap mode inside the specialised fused kernel where one exists (else the generic kernel)
-        if (plan->mode == APTGPU_MODE_FP16_TAPS && plan->l > 1 && plan->work_is_multiple &&
+        // (not with export_resample_filtered: the fused kernels decimate at t = off + k m, the flag moves the phase —
+        // dsp.rs:265-273 — and work_len_for() follows the flag; the unfused k_resample_at path serves such a plan)
+        if (plan->mode == APTGPU_MODE_FP16_TAPS && plan->l > 1 && plan->work_is_multiple && !plan->export_filtered &&
             gpu::fused_f16_supported(plan->l, plan->m, t1, t2, plan->pw)) {
             plan->fused = 1;
             plan->fused_f16 = true;
@@ -328,7 +340,13 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         // (the kernel that will read it: fast plans run the fast instantiation, whose chunks may differ)
         const int ch = gpu::fused_chunk_of(plan->m, plan->fused_fast);
         Signal hs(static_cast<size_t>(gpu::fused_tap_table_floats(plan->l, plan->m, t1, ch)) + 16, 0.f);
-        if (plan->fused_f16) {
+        if (plan->fused_mfma) {
+            // same buffer, different content: the bf16 fragments of the resampler's Toeplitz matrix
+            std::vector<uint32_t> tab(gpu::fused_mfma_table_dwords(plan->l, plan->m) + 16, 0u);
+            gpu::fused_mfma_table(plan->l, plan->m, plan->taps_resample.data(), t1, tab.data());
+            hs.assign(tab.size(), 0.f);
+            std::memcpy(hs.data(), tab.data(), tab.size() * sizeof(uint32_t));
+        } else if (plan->fused_f16) {
             // same buffer, different content: half2 tap pairs as raw dwords
             std::vector<uint32_t> tab(gpu::fused_f16_table_dwords(plan->l, plan->m, t1) + 16, 0u);
             plan->f16_unscale = gpu::fused_f16_branch_taps(plan->l, plan->m, plan->taps_resample.data(), t1, tab.data());
@@ -414,6 +432,8 @@ void aptgpu_plan::upload_slot_table()
         prm.sinphi = sinphi;
         prm.inv_sinphi = inv_sinphi;
         prm.f16_unscale = fused_f16 ? f16_unscale : 0.f;
+        prm.coeff = d_taps_resample.ptr;
+        prm.t1 = static_cast<uint32_t>(taps_resample.size());
         prm.want_gm = (sync && work_is_multiple) ? 1 : 0;
         prm.gm_slack = apt::gpu::fused_gm_slack(pw, sw.gm_slack_scale);
         if (!d_fused_params.ptr) d_fused_params.alloc(1);
@@ -629,7 +649,7 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
             for (int rf = 0; rf < rep_f; ++rf)
             for_chunks(idx, [&](const CallArgs &c, uint64_t max_w, uint32_t) {
                 timed_on(fs, "fused_front_end", [&] {
-                    const int kmode = fused_f16 ? 1 : (fused_fast ? 2 : 0);
+                    const int kmode = fused_f16 ? 1 : (fused_mfma ? 3 : (fused_fast ? 2 : 0));
                     const bool ok = fused == 4 ? fused_phase_front_end(fs, table_geom, t2, pw, kmode, kind == 1, c,
                                                                        d_fused_params.ptr, max_w)
                                   : fused == 3 ? fused_table_front_end(fs, table_geom, kmode, kind == 1, c,

@@ -64,6 +64,24 @@ def test_flag_moves_the_decimation_phase(ctx, oracle, rate, seconds, profile, sy
 
 
 @pytest.mark.parametrize("sync", [True, False])
+def test_flag_is_honoured_in_fp16_taps_mode(oracle, sync):
+    """APTGPU_MODE_FP16_TAPS at 48 kHz normally runs stage 1 inside the specialised fused kernel, which decimates at
+    t = off + k m; with export_resample_filtered the plan must leave it (advisor, round 5): same row count and the same
+    rows as the oracle's flagged decode within that mode's tolerance (2e-3 of full scale), not the unflagged phase."""
+    x = synth_apt(48000, 9, 71)
+    c = apt.Context(device=0, mode=apt.MODE_FP16_TAPS)
+    rows, st = apt.decode(c, _settings("standard"), x, apt.Rate.hz(48000), sync, return_stats=True)
+    want = oracle.decode(x, 48000, sync, settings=oracle.STANDARD, export_resample_filtered=True)
+    assert st.fused == 0  # not the fused fp16 kernel
+    assert rows.shape == np.asarray(want).shape
+    err = np.max(np.abs(rows - want)) / np.max(np.abs(want))
+    assert err <= 2e-3, err
+    unflagged = oracle.decode(x, 48000, sync, settings=oracle.STANDARD)
+    if np.asarray(unflagged).shape == rows.shape:
+        assert np.max(np.abs(rows - unflagged)) / np.max(np.abs(want)) > err  # closer to the flagged decode
+
+
+@pytest.mark.parametrize("sync", [True, False])
 def test_expanded_signal_is_exported(oracle, sync):
     x = synth_apt(48000, 7, 77)
     got = []
