@@ -134,7 +134,7 @@ def run_config4(args):
         mine = [(rank, local_rank)] if rank < G else []
     else:
         mine = [(g, g) for g in range(min(G, visible))]
-    settings = apt.Settings.profile(args.profile)
+    settings = tuned_settings(apt, args)
     rate = apt.Rate.hz(rate_hz)
     mode = {"strict": apt.MODE_STRICT, "generic": apt.MODE_GENERIC, "fp16taps": apt.MODE_FP16_TAPS, "fast": apt.MODE_FAST}[args.mode]
     B = max(1, args.batch)
@@ -224,6 +224,17 @@ def run_config4(args):
         dist.destroy_process_group()
 
 
+def tuned_settings(apt, args):
+    """The profile's Settings with the --set overrides applied."""
+    settings = apt.Settings.profile(args.profile)
+    for kv in args.set:
+        k, _, v = kv.partition("=")
+        if not hasattr(settings, k):
+            raise SystemExit(f"--set: no Settings field {k!r}")
+        setattr(settings, k, type(getattr(settings, k))(float(v)))
+    return settings
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,6 +247,9 @@ def main():
     ap.add_argument("--rate", type=int, default=48000)
     ap.add_argument("--seconds", type=float, default=600.0)
     ap.add_argument("--profile", default="standard")
+    ap.add_argument("--set", action="append", default=[], metavar="FIELD=VALUE",
+                    help="override a Settings field of the profile, e.g. --set resample_atten=31 (default_settings.toml is a "
+                         "user-editable file: which kernel a tuned filter lands on is part of the product)")
     ap.add_argument("--mode", default="strict", choices=["strict", "generic", "fp16taps", "fast"],
                     help="strict (default): bit-exact; fast: APTGPU_MODE_FAST, tolerance of SURVEY.md §8(d), "
                          "checked against the oracle after the timed region")
@@ -305,7 +319,7 @@ def main():
         if dist is not None:
             dist.barrier(group=cpu_group) if cpu_group is not None else dist.barrier()
 
-    settings = apt.Settings.profile(args.profile)
+    settings = tuned_settings(apt, args)
     rate = apt.Rate.hz(args.rate)
 
     # ---- synthetic recording (seeded per rank), moved to HBM before any timing

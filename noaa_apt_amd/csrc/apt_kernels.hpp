@@ -139,7 +139,10 @@ uint32_t fused_group_size(uint32_t l);
 bool fused_takes_pcm16(uint32_t l, uint32_t m);
 // host: stage-1 tap-pair table [WIN][PS][2] (see apt_kernels_fused.hip) and its size in floats
 uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1, int ch);
-void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, int ch, float *hs);
+void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, int ch, float *hs, uint32_t t1_layout = 0);
+// kModeStrictPad (mode 4 of fused_front_end): the tap-count bound of the padded strict kernel that serves (l, m, t1, t2, pw),
+// or 0 where there is none (then t1 must match a kernel exactly: fused_supported)
+uint32_t fused_pad_t1(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
 int fused_chunk_of(uint32_t m, bool fast);  // window samples per stage-1 chunk of the specialised kernel for (m, strict / fast)
 // host: stage-3 tap pairs h2p[k] = (h2[k-1], h2[k]), k = 0 .. t2  (2*(t2+1) floats)
 void fused_lowpass_pairs(const float *h2, uint32_t t2, float *h2p);

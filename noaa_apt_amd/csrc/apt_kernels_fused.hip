@@ -53,6 +53,7 @@ bool fused_takes_pcm16(uint32_t l, uint32_t m) { (void)l; return m % 2 == 0; }  
 uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1, int ch)
 {
     (void)ch;  // kSplitChunk
+    // (t1: the tap count the kernel is compiled for — the filter's own, or kModeStrictPad's bound)
     const int li = static_cast<int>(l), mi = static_cast<int>(m), ti = static_cast<int>(t1);
     return static_cast<uint32_t>(fused_split_table_offset(li, mi, ti, 1) + (fused_split_nch(li, mi, ti, 1) + 1) * kSplitChunkDwords);
 }
@@ -62,10 +63,13 @@ uint32_t fused_tap_table_floats(uint32_t l, uint32_t m, uint32_t t1, int ch)
 // branch's taps at q = w0 + 4 c .. + 3 at dwords 24 .. 27; 0 where a branch has no tap for q; one zero row behind
 // each half.  Tap of branch b at window sample q: coeff[p_b + (q - c_b) l], c_b = ceil(b m / l), p_b = c_b l - b m
 // (dsp.rs:252-263).
-void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, int ch, float *hs)
+// t1_layout (0: t1): the tap count the kernel is compiled for when that is a bound (kModeStrictPad) — the table then has
+// that kernel's chunks and zeros behind the filter's last tap.
+void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, int ch, float *hs, uint32_t t1_layout)
 {
     (void)ch;
-    const uint32_t tp = (t1 + l - 1) / l;
+    if (t1_layout == 0) t1_layout = t1;
+    const uint32_t tp = (t1_layout + l - 1) / l;
     const uint32_t clast = ((l - 1) * m + l - 1) / l;
     const uint32_t win = clast + tp;
     auto tap = [&](uint32_t b, int64_t q) -> float {
@@ -75,7 +79,7 @@ void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, 
         const uint64_t j = pb + static_cast<uint64_t>(q - cb) * l;
         return j < t1 ? coeff[j] : 0.f;
     };
-    const int li = static_cast<int>(l), mi = static_cast<int>(m), ti = static_cast<int>(t1);
+    const int li = static_cast<int>(l), mi = static_cast<int>(m), ti = static_cast<int>(t1_layout);
     for (int h = 0; h < 2; ++h) {
         const int b0 = fused_split_b0(li, h), nbr = fused_split_nbr(li, h), w0 = fused_split_w0(li, mi, h);
         const int nch_h = fused_split_nch(li, mi, ti, h);
@@ -172,6 +176,15 @@ bool fused_fast_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint
     return fused_supported(l, m, t1, t2, pw);
 }
 
+// ---- kModeStrictPad: the strict SPLIT kernels compiled for a tap-count bound (apt_kernels_fused_launch.hpp)
+uint32_t fused_pad_t1(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
+{
+    if (l != 13 || t2 != 37 || pw != 3 || (t1 & 1u) == 0) return 0;  // (Kaiser lengths are odd: filters.rs:164-167)
+    if (m == 50 && t1 <= static_cast<uint32_t>(kPadT1Max48k)) return kPadT1Max48k;
+    if (m == 100 && t1 <= static_cast<uint32_t>(kPadT1Max96k)) return kPadT1Max96k;
+    return 0;
+}
+
 // ---- kModeMfma: the FIRs as banded Toeplitz products on the matrix cores (apt_kernels_fused_launch.hpp)
 bool fused_mfma_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
 {
@@ -250,6 +263,12 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
         for (uint32_t i = 0; i < call.count; ++i)
             if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 3u) return false;
     const FusedLaunch a{s, &call, d_prm, max_w, 0, lds_pad};
+    if (mode == kModeStrictPad) {
+        if (fused_pad_t1(l, m, t1, t2, pw) == 0) return false;
+        if (m == 50) pcm16 ? fused_launch_48k_pad_i16(a) : fused_launch_48k_pad_f32(a);
+        else pcm16 ? fused_launch_96k_pad_i16(a) : fused_launch_96k_pad_f32(a);
+        return true;
+    }
     if (mode == kModeMfma) {
         if (!fused_mfma_supported(l, m, t1, t2, pw)) return false;
         if (m == 50) pcm16 ? fused_launch_48k_mfma_i16(a) : fused_launch_48k_mfma_f32(a);

@@ -111,7 +111,7 @@ __host__ __device__ constexpr int branch_phase(int b)  // p_b = c_b*L - b*M
 // the input tile is two bf16 planes of K-padded windows; T1 is then the LARGEST tap count the instantiation serves)
 template <int L, int M, int T1, int T2, int PW, int NTHR, int XB = 4, int VAR = 0>
 struct FusedGeom {
-    static constexpr bool F16TAPS = VAR == 1, MFMA = VAR == 2;
+    static constexpr bool F16TAPS = VAR == 1, MFMA = VAR == 2, PAD = VAR == 3;
     static constexpr bool TABLE = M <= 0;   // run-time resampling factors (table-driven or phase-resident stage 1)
     static constexpr bool PHASE = M < 0;    // ... with the taps of a thread's -M polyphase branches in registers
     static constexpr int kFusedThreads = NTHR;
@@ -148,7 +148,8 @@ struct FusedGeom {
     // now land on the dead F region — the work-rate stages need 26.1 KB: SIX workgroups per CU for kernels of <= 80 VGPRs.
     static constexpr int D_OFF = (TILE_K + 2 * PW + 2 + 3) & ~3;
     // floats of LDS under the x tile (MFMA: two bf16 planes of XT_PAD samples, then the tile's non-finite flag)
-    static constexpr int XT_LDS = MFMA ? XT_PAD + 8 : XB == 2 ? (XT_PAD / 2 + 4) : XT_PAD;
+    // (PAD: one more word behind the tile — the "results not all finite" flag of kModeStrictPad)
+    static constexpr int XT_LDS = MFMA ? XT_PAD + 8 : (XB == 2 ? (XT_PAD / 2 + 4) : XT_PAD) + (PAD ? 4 : 0);
     // the pulse sums a thread of stage 4 reads: positions p0 + 2 PW n, n <= 31, p0 <= PRE_K + (blocks - 1) * 2 PW L + 2 PW - 1
     static constexpr int NBLK4 = (OWN_K + 2 * PW * L - 1) / (2 * PW * L);
     static constexpr int QMAX = PRE_K + (NBLK4 - 1) * 2 * PW * L + 2 * PW - 1 + 2 * PW * 31;
@@ -275,6 +276,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     constexpr int kOwnThreads = Gm::kOwnThreads, kPreThreads = Gm::kPreThreads, kPostThreads = Gm::kPostThreads;
     constexpr bool F16 = MODE == kModeF16Taps;
     constexpr bool MFMA = MODE == kModeMfma;         // the FIRs on the matrix cores; everything else as kModeFast
+    constexpr bool PAD = MODE == kModeStrictPad;     // strict arithmetic, T1 a bound (zero-padded table)
     constexpr bool FAST = MODE == kModeFast || MFMA;
     extern __shared__ float lds[];
     float *P = lds;                  // x tile -> R -> F
@@ -1146,6 +1148,10 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         const int wl = tid & (NS - 1);
         constexpr int NH0 = fused_split_nbr(L, 0);   // 7: results a thread holds per sub-tile (half 1: 6)
         float rh[2][NH0];
+        if constexpr (PAD) {
+#pragma unroll
+            for (int j = 0; j < NH0; ++j) rh[0][j] = rh[1][j] = 0.f;
+        }
         auto half = [&](auto hc, auto subc) {
             constexpr int H = decltype(hc)::value, SUB = decltype(subc)::value;
             constexpr int B0 = fused_split_b0(L, H), NBR = fused_split_nbr(L, H);
@@ -1323,6 +1329,12 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         // (24 % more instructions than half 1's three pairs), and a workgroup's waves 0, 1 / 2, 3 land on the same
         // SIMDs in every workgroup — without the swap two SIMDs of a CU would carry the heavy half of every tile.
         const bool first_half = (tid < NS) != ((tile & 1) != 0);
+        // kModeStrictPad: "this tile's results are not all finite" (one word behind the x tile; re-armed per tile, two
+        // barriers before it can be set)
+        [[maybe_unused]] uint32_t *pad_flag = reinterpret_cast<uint32_t *>(lds) + (Gm::XT_LDS - 4);
+        if constexpr (PAD && sizeof(XT) == 4) {
+            if (tid == 0) *pad_flag = 0u;
+        }
         // sub-tile 0 is in LDS; sub-tile 1's loads are in flight under its stage 1
         XReg xr1[NXR];
         load_tile(ri, tile, 1, xr1);
@@ -1334,6 +1346,15 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         if (first_half) half(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
         else half(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
         APT_MARK("END stage1");
+        if constexpr (PAD && sizeof(XT) == 4) {
+            // 0 * inf / 0 * NaN behind the filter's last tap (the reference skips those taps): any non-finite result
+            // sends the tile to the sample-by-sample evaluation below.  (A sum of finite results that overflows does too:
+            // the same values, slowly.)
+            float chk = 0.f;
+#pragma unroll
+            for (int j = 0; j < fused_split_nbr(L, 0); ++j) chk = chk + (rh[0][j] + rh[1][j]);  // (half 1: its unused seventh slot is 0-initialised below)
+            if ((__float_as_uint(chk) & 0x7F800000u) == 0x7F800000u) *pad_flag = 1u;
+        }
         __syncthreads();  // everyone is done reading sub-tile 1: R may land on it
         if (first_half) {
 #pragma unroll
@@ -1346,6 +1367,29 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             for (int j = 0; j < fused_split_nbr(L, 1); ++j) {
                 P[wl * L + fused_split_b0(L, 1) + j] = rh[0][j];
                 P[(NS + wl) * L + fused_split_b0(L, 1) + j] = rh[1][j];
+            }
+        }
+        if constexpr (PAD && sizeof(XT) == 4) {
+            // (the flag lies behind the x tile: R, which has just landed on the tile, does not reach it)
+            static_assert(Gm::XT_LDS - 4 >= Gm::TILE_K, "the flag lies behind R");
+            if (*pad_flag != 0u) {
+                // (workgroup-uniform; never on recordings) the reference's loop, sample by sample from HBM (dsp.rs:252-263)
+                __syncthreads();
+                const XT *__restrict__ xg = static_cast<const XT *>(call.rec[ri].x);
+                const uint64_t n_in = call.rec[ri].n;
+                const float *__restrict__ cf = prm->coeff;
+                const uint32_t t1r = prm->t1;
+                for (int b = 0; b < L; ++b) {
+                    const int64_t k = (tile * Gm::OWN_K - Gm::PRE_K) + kq + b;
+                    float sum = 0.f;
+                    if (k >= 0) {
+                        const uint64_t v = static_cast<uint64_t>(k) * static_cast<uint64_t>(M);
+                        uint64_t x0 = (v + L - 1) / L;
+                        for (uint64_t j = x0 * L - v; j < t1r; j += L, ++x0)
+                            if (x0 < n_in) sum = sum + cf[j] * static_cast<float>(xg[x0]);
+                    }
+                    P[tid * L + b] = sum;
+                }
             }
         }
         __syncthreads();

@@ -21,8 +21,17 @@ constexpr int kModeFast = 2;
 // is a run-time quantity here (the table is zero-padded to the kernel's K): a tuned resample_atten / resample_delta_freq
 // stays on a specialised kernel while its taps per branch fit — what this mode is kept for.
 constexpr int kModeMfma = 3;
+// kModeStrictPad (round 6): kModeStrict's arithmetic in a SPLIT kernel compiled for a tap-count BOUND: the chunk-major table
+// is laid out for the bound and holds zeros behind the filter's last tap.  sum + 0 * x = sum exactly for finite x (the sum
+// starts at +0 and never becomes -0), so the results are bit-identical to the reference's, which skips those taps; a
+// tile whose results are not all finite — where 0 * inf would have put a NaN the reference does not have — is evaluated
+// again sample by sample from HBM, in the reference's order.  default_settings.toml:108-140 is a user-editable file:
+// a tuned resample_atten / resample_delta_freq changes the tap count, and until round 6 such a plan fell to k_fused_any.
+constexpr int kModeStrictPad = 4;
 // FusedGeom's variant argument for a mode
-constexpr int fused_geom_var(int mode) { return mode == kModeF16Taps ? 1 : mode == kModeMfma ? 2 : 0; }
+constexpr int fused_geom_var(int mode) { return mode == kModeF16Taps ? 1 : mode == kModeMfma ? 2 : mode == kModeStrictPad ? 3 : 0; }
+// tap counts the padded strict instantiations are compiled for (83 / 165 taps per branch; stock: 74 / 148)
+constexpr int kPadT1Max48k = 1079, kPadT1Max96k = 2145;
 // tap counts the MFMA instantiations are compiled for (window of a tile's last branch + taps per branch <= K = 128 / 256)
 constexpr int kMfmaT1Max48k = 1053, kMfmaT1Max96k = 2119;
 
@@ -91,6 +100,11 @@ void fused_launch_48k_mfma_f32(const FusedLaunch &a);
 void fused_launch_48k_mfma_i16(const FusedLaunch &a);
 void fused_launch_96k_mfma_f32(const FusedLaunch &a);
 void fused_launch_96k_mfma_i16(const FusedLaunch &a);
+// strict, any tap count up to kPadT1Max* (kModeStrictPad): 48 / 96 kHz, standard profile
+void fused_launch_48k_pad_f32(const FusedLaunch &a);
+void fused_launch_48k_pad_i16(const FusedLaunch &a);
+void fused_launch_96k_pad_f32(const FusedLaunch &a);
+void fused_launch_96k_pad_i16(const FusedLaunch &a);
 // 48 kHz at the slow profile (13 / 30, 2783 taps; 61-tap low-pass, pixel width 5): the same SPLIT form
 void fused_launch_48k_slow_f32(const FusedLaunch &a);
 void fused_launch_48k_slow_i16(const FusedLaunch &a);

@@ -263,8 +263,18 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         const bool mfma_want = mfma_env ? mfma_env[0] == '1' : !gpu::fused_supported(plan->l, plan->m, t1, t2, plan->pw);
         const bool mfma_ok = eligible && !no_spec && plan->mode == APTGPU_MODE_FAST && mfma_want &&
                              gpu::fused_mfma_supported(plan->l, plan->m, t1, t2, plan->pw);
-        if (eligible && (gpu::fused_supported(plan->l, plan->m, t1, t2, plan->pw) || mfma_ok) && !no_spec)
+        // a tap count no specialised kernel is compiled for (a tuned resample_atten / resample_delta_freq): the strict kernel
+        // compiled for a tap-count BOUND, its table zero-padded (kModeStrictPad; APTGPU_FUSED_PAD=1 forces it for the stock
+        // counts too, =0 switches it off: A/B, tests)
+        const char *pad_env = std::getenv("APTGPU_FUSED_PAD");
+        const bool exact = gpu::fused_supported(plan->l, plan->m, t1, t2, plan->pw);
+        const uint32_t pad_t1 = (eligible && !no_spec && !mfma_ok && (pad_env ? pad_env[0] == '1' : !exact))
+                                    ? gpu::fused_pad_t1(plan->l, plan->m, t1, t2, plan->pw) : 0u;
+        plan->fused_pad_t1 = 0;
+        if (eligible && (exact || mfma_ok || pad_t1 != 0) && !no_spec) {
             plan->fused = 1;
+            plan->fused_pad_t1 = pad_t1;
+        }
         // (where both the table-driven and the phase-resident stage 1 exist, the latter: since round 5 — thread assignment
         // lists, interior tile loads, pipelined taps, two / four branches per thread — it is the faster one at every rate
         // measured (8 / 11.025 / 16 / 32 kHz: 0.60 / 0.64 / 0.71 / 0.95 against 0.70 / 0.68 / 0.94 / 1.56 ms per 16 recordings,
@@ -288,13 +298,14 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
             if (!(q && q[0] == '1') && !told.exchange(true))
                 std::fprintf(stderr,
                              "aptgpu: %u -> %u Hz with %u resample / %u low-pass taps has no compile-time specialised front end "
-                             "(those exist for 959 / 1915 resample taps and 37 low-pass taps at 48 / 96 kHz); using kernel path %d "
+                             "(those exist for up to 1079 / 2145 resample taps and 37 low-pass taps at 48 / 96 kHz); using kernel path %d "
                              "(same results, lower throughput)\n",
                              plan->input_rate, plan->settings.work_rate, t1, t2, plan->fused);
         }
         plan->fused_mfma = mfma_ok && plan->fused == 1;
         plan->fused_fast = plan->mode == APTGPU_MODE_FAST &&
-                           ((plan->fused == 1 && (plan->fused_mfma || gpu::fused_fast_supported(plan->l, plan->m, t1, t2, plan->pw))) ||
+                           ((plan->fused == 1 && plan->fused_pad_t1 == 0 &&
+                             (plan->fused_mfma || gpu::fused_fast_supported(plan->l, plan->m, t1, t2, plan->pw))) ||
                             plan->fused == 3 || plan->fused == 4);
         // fp16-tap mode inside the specialised fused kernel where one exists (else the generic kernel)
         // (not with export_resample_filtered: the fused kernels decimate at t = off + k m, the flag moves the phase —
@@ -339,7 +350,8 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         const uint32_t t1 = static_cast<uint32_t>(plan->taps_resample.size());
         // (the kernel that will read it: fast plans run the fast instantiation, whose chunks may differ)
         const int ch = gpu::fused_chunk_of(plan->m, plan->fused_fast);
-        Signal hs(static_cast<size_t>(gpu::fused_tap_table_floats(plan->l, plan->m, t1, ch)) + 16, 0.f);
+        const uint32_t t1_layout = plan->fused_pad_t1 ? plan->fused_pad_t1 : t1;
+        Signal hs(static_cast<size_t>(gpu::fused_tap_table_floats(plan->l, plan->m, t1_layout, ch)) + 16, 0.f);
         if (plan->fused_mfma) {
             // same buffer, different content: the bf16 fragments of the resampler's Toeplitz matrix
             std::vector<uint32_t> tab(gpu::fused_mfma_table_dwords(plan->l, plan->m) + 16, 0u);
@@ -353,7 +365,7 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
             hs.assign(tab.size(), 0.f);
             std::memcpy(hs.data(), tab.data(), tab.size() * sizeof(uint32_t));
         } else {
-            gpu::fused_branch_taps(plan->l, plan->m, plan->taps_resample.data(), t1, ch, hs.data());
+            gpu::fused_branch_taps(plan->l, plan->m, plan->taps_resample.data(), t1, ch, hs.data(), t1_layout);
         }
         upload(plan->d_taps_branch, hs);
         Signal h2p(2 * (plan->taps_lowpass.size() + 1) + 16, 0.f);
@@ -649,7 +661,7 @@ void aptgpu_plan::run_call(int count, const Input *ins, float *const *d_rows, co
             for (int rf = 0; rf < rep_f; ++rf)
             for_chunks(idx, [&](const CallArgs &c, uint64_t max_w, uint32_t) {
                 timed_on(fs, "fused_front_end", [&] {
-                    const int kmode = fused_f16 ? 1 : (fused_mfma ? 3 : (fused_fast ? 2 : 0));
+                    const int kmode = fused_f16 ? 1 : (fused_mfma ? 3 : (fused_pad_t1 ? 4 : (fused_fast ? 2 : 0)));
                     const bool ok = fused == 4 ? fused_phase_front_end(fs, table_geom, t2, pw, kmode, kind == 1, c,
                                                                        d_fused_params.ptr, max_w)
                                   : fused == 3 ? fused_table_front_end(fs, table_geom, kmode, kind == 1, c,

@@ -152,6 +152,7 @@ struct aptgpu_plan {
     bool fused_f16 = false;   // APTGPU_MODE_FP16_TAPS served by the specialised fused kernel (fp16 stage 1)
     bool fused_fast = false;  // APTGPU_MODE_FAST served by the specialised fused kernel
     bool fused_mfma = false;  // ... by its matrix-core form (kModeMfma: tuned tap counts, or APTGPU_FAST_MFMA=1)
+    uint32_t fused_pad_t1 = 0;  // != 0: the strict kernel compiled for this tap-count bound serves the plan (kModeStrictPad)
     // 0 unfused generic kernels, 1 compile-time specialised k_fused, 2 run-time k_fused_any,
     // 3 k_fused with the table-driven stage 1 (run-time l / m / taps, specialised work-rate stages)
     int fused = 0;

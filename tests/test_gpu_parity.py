@@ -976,3 +976,69 @@ def test_split_stage1_recording_ends_around_the_sub_tile_boundaries(oracle, rate
     for e, g, w in zip(ends, got, wants):
         assert not isinstance(g, Exception), (e, g)
         assert_bitexact(g, w, f"{rate} Hz PCM16, recording ends {e} samples into a tile")
+
+
+# ------------------------------------------------------------------ user-tuned tap counts (kModeStrictPad)
+TUNED = [(48000, dict(resample_atten=29.0)), (48000, dict(resample_atten=31.0)), (48000, dict(resample_delta_freq=900.0)),
+         (48000, dict(resample_delta_freq=1100.0)), (96000, dict(resample_atten=31.0)), (96000, dict(resample_delta_freq=900.0)),
+         (96000, dict(resample_delta_freq=1100.0)), (48000, dict(resample_cutout=5200.0))]
+
+
+@pytest.mark.parametrize("rate,kw", TUNED)
+@pytest.mark.parametrize("sync", [True, False])
+def test_tuned_settings_stay_on_the_specialised_kernel(ctx, oracle, rate, kw, sync):
+    """default_settings.toml:108-140 is a user-editable file.  A tuned resample_atten / resample_delta_freq changes the tap
+    COUNT (959 / 1915 at the stock values): such a plan runs the strict SPLIT kernel compiled for a tap-count bound, with a
+    zero-padded table (kModeStrictPad) — stats.fused == 1, bit-exact (until round 6: k_fused_any)."""
+    s = apt.Settings(**kw)
+    os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                       "resample_cutout", "demodulation_atten")}
+    x = synth_apt(rate, 12, seed=51)
+    want, st = oracle.decode(x, rate, sync, settings=os_, want_steps=True)
+    got, stats = apt.decode(ctx, s, x, apt.Rate.hz(rate), sync, return_stats=True)
+    assert stats.n_resample_taps == st["resample_filter"].size
+    assert stats.fused == 1, (rate, kw, stats.n_resample_taps)
+    assert_bitexact(got, want, f"tuned {rate} {kw} sync={sync}")
+
+
+def test_padded_kernel_on_the_stock_tap_counts_and_non_finite_samples(oracle, monkeypatch):
+    """APTGPU_FUSED_PAD=1: the padded kernels serve the stock tap counts too (74 of their 83 / 148 of 165 taps per branch
+    real, the rest zeros) — bit-exact, also where a NaN or an infinity sits under a zero tap (0 x inf = NaN where the
+    reference, which skips that tap, has none: such a tile is evaluated again sample by sample), and with PCM16 input."""
+    monkeypatch.setenv("APTGPU_FUSED_PAD", "1")
+    apt.cache_clear()
+    c = apt.Context(device=0)
+    for rate in (48000, 96000):
+        x = synth_apt(rate, 12, seed=52)
+        got, stats = apt.decode(c, apt.Settings(), x, apt.Rate.hz(rate), True, return_stats=True)
+        assert stats.fused == 1
+        assert_bitexact(got, oracle.decode(x, rate, True), f"padded, stock taps, {rate}")
+        for bad in (np.nan, np.inf, -np.inf):
+            y = x.copy()
+            for i in (5, 77777, 200001, 200002, y.size - 3):
+                y[i] = bad
+            for sync in (True, False):
+                try:
+                    want = oracle.decode(y, rate, sync)
+                except oracle.OracleError as e:
+                    with pytest.raises(apt.AptError) as ge:
+                        apt.decode(c, apt.Settings(), y, apt.Rate.hz(rate), sync)
+                    assert str(ge.value) == str(e)
+                    continue
+                assert_same_values(apt.decode(c, apt.Settings(), y, apt.Rate.hz(rate), sync), want, f"padded {rate} {bad} sync={sync}")
+    # PCM16 payload
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    x = synth_apt(48000, 12, seed=53)
+    want = oracle.decode(x, 48000, True)
+    plan = apt.Plan(apt.Settings(), apt.Rate.hz(48000), True, max_samples=x.size)
+    d_pcm = torch.from_numpy(x.astype(np.int16)).to(dev)
+    cap = int(plan.info.max_rows)
+    d_out = torch.empty(cap * 2080, dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    spec = apt.WavSpec(1, 16, 2, 0, 48000, 1, 0, 2 * x.size, x.size, x.size)
+    plan.decode_device_wav([d_pcm.data_ptr()], [spec], [d_out.data_ptr()], [cap])
+    res = plan.results(1)[0]
+    assert_bitexact(d_out[:res.n_out].cpu().numpy(), want, "padded, PCM16")
+    plan.close()
+    apt.cache_clear()

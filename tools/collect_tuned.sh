@@ -1,0 +1,34 @@
+#!/bin/bash
+# tools/collect_tuned.sh <round-tag>: the settings cliff.  bench.py at 48 kHz with a tuned
+# resample_atten / resample_delta_freq — tap counts the exact-count kernels are not compiled for — on the padded strict
+# kernel (kModeStrictPad, the default for such plans) and, APTGPU_FUSED_PAD=0 / APTGPU_FAST_MFMA=0, on what served them
+# until round 6 (k_fused_any); stock settings beside them.  -> gpurun_out/prof/<tag>_bench_tuned_*.json + a table.
+TAG=${1:-r06}
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/prof; mkdir -p $O
+cd $R
+run() {  # name, env..., -- bench args
+  local name=$1; shift
+  local envs=()
+  while [ "$1" != "--" ]; do envs+=("$1"); shift; done
+  shift
+  env "${envs[@]}" timeout 300 python bench.py --steps 60 --warmup 10 --no-extras --no-cpu-baseline "$@" > $O/${TAG}_bench_tuned_$name.json 2> $O/${TAG}_bench_tuned_$name.err
+  python - $O/${TAG}_bench_tuned_$name.json $name <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    w = d["config"]["workload"]
+    taps = w[w.index("resample"):].split("->")[0].strip()
+    print(f"{sys.argv[2]:28s} {taps:28s} ms/step {d['ms_per_step']:.4f}  front end alone {d['roofline']['kernel_avg_ms']:.4f} ms  frac {d['roofline']['frac']:.4f}  parity: {str(d.get('parity'))[:60]}")
+except Exception as e:
+    print(sys.argv[2], "FAILED", e)
+PY
+}
+run stock APTGPU_QUIET=1 --
+for kv in resample_atten=29 resample_atten=31 resample_delta_freq=900 resample_delta_freq=1100; do
+  run ${kv}_pad APTGPU_QUIET=1 -- --set $kv
+  run ${kv}_any APTGPU_QUIET=1 APTGPU_FUSED_PAD=0 -- --set $kv
+done
+run fast_stock APTGPU_QUIET=1 -- --mode fast
+run fast_atten31_mfma APTGPU_QUIET=1 -- --mode fast --set resample_atten=31
+run fast_atten31_any APTGPU_QUIET=1 APTGPU_FAST_MFMA=0 APTGPU_FUSED_PAD=0 -- --mode fast --set resample_atten=31
+rm -f $O/${TAG}_bench_tuned_*.err
