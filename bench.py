@@ -400,13 +400,15 @@ def main():
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
-        job_barrier()
+        # what the power manager does meanwhile (every rank, its own device): the SMU's accumulators read before and after
+        # the timed region — no thread beside it — and a sampled loop of the same steps behind it.  The first snapshot is
+        # taken BEFORE the barrier: its latency varies from call to call, and between barrier and t0 it would skew the
+        # ranks' starts (the job's time is the slowest rank's).
+        snap0 = smu.snapshot() if smu is not None else None
         # timed region: HIP events bracket the dominant kernel of every 8th step (the markers
         # serialise the stream for ~6 us each; sampling keeps the measurement live but cheap)
         plan.enable_timing(0 if args.no_kernel_timing else 1)
-        # what the power manager does meanwhile (rank 0): the SMU's accumulators read before and after the timed region
-        # — no thread beside it — and a sampled loop of the same steps behind it
-        snap0 = smu.snapshot() if smu is not None else None
+        job_barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -420,7 +422,7 @@ def main():
         plan.enable_timing(0)
         power = None
         if smu is not None:
-            power = {"source": "amd-smi gpu_metrics on rank 0: energy and throttler-residency accumulators read before / after the timed "
+            power = {"source": "amd-smi gpu_metrics, per rank (this object: rank 0's device): energy and throttler-residency accumulators read before / after the timed "
                                "region; socket power and per-XCD gfx clocks sampled every 2 ms during the loop behind it",
                      "timed_region": smu.between(snap0, smu.snapshot())}
             if smu.available:
@@ -746,7 +748,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5),
-            "joules_per_call": mine["joules_per_call"],  # socket energy accumulator over the timed region / K (rank 0's device)
+            "joules_per_call": mine["joules_per_call"],  # socket energy accumulator over the timed region / K: rank 0's device (every rank's: per_rank)
             "per_rank": per_rank,
             "higher_is_better": True,
             "scaling": "weak",
@@ -816,9 +818,12 @@ def main():
                 "achieved": round(pipe_achieved, 2),
                 "unit": "GB/s",
                 "frac": round(pipe_achieved / HBM_PEAK_GBS, 5),
-                "sum_kernel_ms": round(kernel_sum_ms, 5),
+                "sum_kernel_span_ms": round(kernel_sum_ms, 5),
                 "host_enqueue_ms_per_step": round(1e3 * (t_enq - t0) / args.steps, 5),
-                "kernels_ms": {k: round(v[0], 5) for k, v in sorted(ktimes.items())},
+                # event-to-event spans of every kernel in a SEPARATE 10-step pass of the pipelined loop: they include the time
+                # a launch waits behind the other streams' work (queueing), so they overlap and exceed ms_per_step — a picture
+                # of the overlap, not GPU time.  The GPU time of a kernel is kernels_alone_ms (one call in flight at a time).
+                "kernels_span_in_pipeline_ms": {k: round(v[0], 5) for k, v in sorted(ktimes.items())},
                 "kernels_alone_ms": {k: round(v[0], 5) for k, v in sorted(iso_times.items())},
             },
         }

@@ -281,8 +281,10 @@ int aptgpu_plan_read_internal(aptgpu_plan *plan, int i, const char *name, void *
  * worker-level error (HIP failure, bad argument).  Host buffers may be pageable; pinned ones
  * (aptgpu_host_alloc) are DMA'd directly. */
 /* ABI note (0.2.0): `struct_size` is the caller's sizeof(aptgpu_batch_stats), set BEFORE the call; the library fills
- * at most that many bytes, so a caller built against this header keeps working when fields are appended (0 is read
- * as "this header's size").  The struct had no such field in 0.1.0 and grew twice: check aptgpu_abi_version(). */
+ * at most that many bytes, so a caller built against this header keeps working when fields are appended.  A
+ * struct_size below 8 (a zero-initialised struct; the bytes a 0.1.0 caller's `double seconds` starts with) is refused
+ * with APTGPU_ERR_INVALID before anything runs.  The struct had no such field in 0.1.0 and grew twice: a binding
+ * checks aptgpu_abi_version() at load time. */
 typedef struct aptgpu_batch_stats {
     uint32_t struct_size;  /* in: sizeof(aptgpu_batch_stats) as the caller was compiled              */
     uint32_t reserved;

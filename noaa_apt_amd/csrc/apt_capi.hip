@@ -374,6 +374,26 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
             status(&ctx, 0.1f, "Resampling to " + std::to_string(work));
         }
 
+        // The expanded signal of export_resample_filtered (n * l floats: gigabytes for a whole pass) on the device and on
+        // the host.  Where either allocation fails the step is delivered empty and the decode goes on — the reference logs
+        // "Expanded filtered signal can't fit in memory, skipping step" and does the same (dsp.rs:211-220).
+        auto export_expanded = [&](uint64_t cnt, uint32_t rate, auto &&fill) {
+            try {
+                apt::DeviceBuffer<float> d_ex;
+                d_ex.alloc(cnt + 16);
+                fill(d_ex.ptr);
+                apt::Signal ex = download(d_ex.ptr, cnt, s);
+                step(&ctx, steps, "resample_filtered", 0, ex.data(), ex.size(), rate);
+                return;
+            } catch (const Error &e) {
+                if (e.kind != ErrorKind::Hip || e.hip_code != static_cast<int>(hipErrorOutOfMemory)) throw;
+                (void)hipGetLastError();
+            } catch (const std::bad_alloc &) {
+            }
+            std::fprintf(stderr, "aptgpu: expanded filtered signal (%llu samples) can't fit in memory, skipping step\n",
+                         static_cast<unsigned long long>(cnt));
+            step(&ctx, steps, "resample_filtered", 0, nullptr, 0, rate);
+        };
         // dsp.rs:96 / :106 — the resample filter, then the resample steps
         step(&ctx, steps, "resample_filter", 1, plan->taps_resample.data(),
              plan->taps_resample.size(), 0);
@@ -383,14 +403,20 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
                 // dsp.rs:269,281-285: every sum of the interpolated axis (gigabytes for a whole pass, as the
                 // reference's documentation warns)
                 const uint64_t cnt = apt::fast_resampling_export_geom(n, plan->l, plan->m, plan->taps_resample.size()).expanded;
-                apt::DeviceBuffer<float> d_ex;
-                d_ex.alloc(cnt + 16);
-                plan->expanded_filtered(s, wav ? sl.ingest.ptr : static_cast<const float *>(d_in_ptr), n, false, d_ex.ptr, cnt);
-                apt::Signal ex = download(d_ex.ptr, cnt, s);
-                step(&ctx, steps, "resample_filtered", 0, ex.data(), ex.size(), input_rate_hz * plan->l);
+                export_expanded(cnt, input_rate_hz * plan->l, [&](float *d_ex) {
+                    plan->expanded_filtered(s, wav ? sl.ingest.ptr : static_cast<const float *>(d_in_ptr), n, false, d_ex, cnt);
+                });
             } else if (plan->l > 1) {
                 // dsp.rs:281-285: expanded signal is empty unless export_resample_filtered
                 step(&ctx, steps, "resample_filtered", 0, nullptr, 0, input_rate_hz * plan->l);
+            } else {
+                // l == 1 (dsp.rs:106-116): filter() then decimate(); the step carries the filtered signal, at the input rate
+                apt::DeviceBuffer<float> d_fl;
+                d_fl.alloc(n + 16);
+                apt::gpu::fir_decimate(s, wav ? sl.ingest.ptr : static_cast<const float *>(d_in_ptr), n, plan->d_taps_resample.ptr,
+                                       static_cast<uint32_t>(plan->taps_resample.size()), 1, d_fl.ptr, n);
+                apt::Signal fl = download(d_fl.ptr, n, s);
+                step(&ctx, steps, "resample_filtered", 0, fl.data(), fl.size(), input_rate_hz);
             }
             apt::Signal r = download(sl.resampled.ptr, w, s);
             step(&ctx, steps, "resample_decimated", 0, r.data(), r.size(), work);
@@ -456,11 +482,7 @@ int decode_host(const aptgpu_context *ctx_in, const aptgpu_settings *settings, c
                 step(&ctx, steps, "resample_filter", 1, &one, 1, 0);
                 if (plan->l2 > 1 && plan->export_filtered) {
                     const uint64_t cnt = apt::fast_resampling_export_geom(aligned, plan->l2, plan->m2, 1).expanded;
-                    apt::DeviceBuffer<float> d_ex;
-                    d_ex.alloc(cnt + 16);
-                    plan->expanded_filtered(s, sl.filtered.ptr, aligned, true, d_ex.ptr, cnt);
-                    apt::Signal ex = download(d_ex.ptr, cnt, s);
-                    step(&ctx, steps, "resample_filtered", 0, ex.data(), ex.size(), work * plan->l2);
+                    export_expanded(cnt, work * plan->l2, [&](float *d_ex) { plan->expanded_filtered(s, sl.filtered.ptr, aligned, true, d_ex, cnt); });
                 } else if (plan->l2 > 1) {
                     // fast_resampling: the expanded signal is empty unless export_resample_filtered
                     step(&ctx, steps, "resample_filtered", 0, nullptr, 0, work * plan->l2);

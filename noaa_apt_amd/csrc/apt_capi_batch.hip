@@ -700,6 +700,12 @@ int decode_batch_impl(const aptgpu_context *ctx, const aptgpu_settings *settings
         put_err(err, err_cap, "bad argument to aptgpu_decode_batch");
         return APTGPU_ERR_INVALID;
     }
+    // (the caller's sizeof, set before the call; 0 — a zero-initialised struct, or the first half of a 0.1.0 caller's
+    // `double seconds` — is not a size the library may guess: include/aptgpu.h)
+    if (stats && stats->struct_size < 2 * sizeof(uint32_t)) {
+        put_err(err, err_cap, "aptgpu_batch_stats.struct_size is not set (sizeof(aptgpu_batch_stats) of the caller's header)");
+        return APTGPU_ERR_INVALID;
+    }
     return guarded(err, err_cap, [&]() -> int {
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<int32_t> devs(devices, devices + n_devices);
@@ -771,7 +777,7 @@ int decode_batch_impl(const aptgpu_context *ctx, const aptgpu_settings *settings
         if (stats) {
             // (filled in a local copy, then at most the caller's struct_size bytes go out: include/aptgpu.h)
             aptgpu_batch_stats full{};
-            const uint32_t want = stats->struct_size ? stats->struct_size : static_cast<uint32_t>(sizeof full);
+            const uint32_t want = stats->struct_size;
             full.struct_size = want;
             full.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             full.samples = total_samples;

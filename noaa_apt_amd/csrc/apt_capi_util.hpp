@@ -148,11 +148,24 @@ inline uint64_t resample_device(Scratch &sc, const float *d_x, size_t n, uint32_
             w = g.count;
             d_y.alloc(w + 16);
             apt::resample_at(sc.stream, d_x, n, d_c.ptr, ntaps, lm.l, g.d0, lm.m, d_y.ptr, w);
-            if (on) {  // dsp.rs:269,281-285
-                apt::DeviceBuffer<float> d_ex;
-                d_ex.alloc(g.expanded + 16);
-                apt::resample_at(sc.stream, d_x, n, d_c.ptr, ntaps, lm.l, 0, 1, d_ex.ptr, g.expanded);
-                export_signal("resample_filtered", d_ex.ptr, g.expanded, in_hz * lm.l);
+            if (on) {  // dsp.rs:269,281-285; where the n * l floats do not fit: an empty step, as dsp.rs:211-220 skips it
+                bool done = false;
+                try {
+                    apt::DeviceBuffer<float> d_ex;
+                    d_ex.alloc(g.expanded + 16);
+                    apt::resample_at(sc.stream, d_x, n, d_c.ptr, ntaps, lm.l, 0, 1, d_ex.ptr, g.expanded);
+                    export_signal("resample_filtered", d_ex.ptr, g.expanded, in_hz * lm.l);
+                    done = true;
+                } catch (const Error &e) {
+                    if (e.kind != ErrorKind::Hip || e.hip_code != static_cast<int>(hipErrorOutOfMemory)) throw;
+                    (void)hipGetLastError();
+                } catch (const std::bad_alloc &) {
+                }
+                if (!done) {
+                    std::fprintf(stderr, "aptgpu: expanded filtered signal (%llu samples) can't fit in memory, skipping step\n",
+                                 static_cast<unsigned long long>(g.expanded));
+                    step(steps_ctx, on, "resample_filtered", 0, nullptr, 0, in_hz * lm.l);
+                }
             }
         } else {
             w = apt::fast_resampling_len(n, lm.l, lm.m, coeff.size());

@@ -45,6 +45,21 @@ def test_struct_layouts_match_header(L):
     assert ctypes.sizeof(apt.BatchStats) == 88 and apt.BatchStats.struct_size.offset == 0 and apt.BatchStats.seconds.offset == 8
 
 
+def test_batch_stats_without_struct_size_is_refused(L):
+    """aptgpu_batch_stats.struct_size is the caller's sizeof; 0 — a zero-initialised struct, or what a
+    0.1.0 caller's leading `double seconds` happens to hold — must not be read as "this header's size" (the library would
+    write 88 bytes into whatever the caller has).  Refused before anything runs: no GPU needed to see it."""
+    import ctypes as C
+    cs = apt.Settings()._c()
+    cctx = apt.Context()._c()
+    st = apt.BatchStats()  # struct_size == 0
+    err = C.create_string_buffer(512)
+    rc = L.aptgpu_decode_batch(C.byref(cctx), C.byref(cs), 48000, 1, 0, None, None, None, 0, 0, None, None, None, None,
+                               C.byref(st), err, 512)
+    assert rc == apt.InvalidError.code and b"struct_size" in err.value
+    assert st.seconds == 0.0 and st.workers == 0  # nothing written
+
+
 def test_no_environment_variable_redirects_the_loader(L, monkeypatch):
     """the shipped module loads the in-tree product library, whatever APTGPU_LIB says; the probe build is
     selected in code (use_library), before the first load, and announced on stderr."""

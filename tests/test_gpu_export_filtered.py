@@ -175,3 +175,20 @@ def test_resample_tool_steps_and_flag(ow, in_rate, out_rate, flag):
     assert apt.resample_wav(None, s, data, None, out_rate) == want
     if flag and l > 1:
         assert want != ow.resample_wav(data, out_rate, s.wav_resample_atten, s.wav_resample_delta_freq)
+
+
+@pytest.mark.parametrize("flag", [False, True])
+def test_first_resample_with_l_equal_1_delivers_the_filtered_signal(oracle, flag):
+    """decode() of a 24 960 Hz recording: the first resample is the l == 1 branch (filter + decimate, dsp.rs:106-116),
+    whose "resample_filtered" step carries the filtered signal at the input rate whatever the flag says (the flag only
+    matters inside Context::step, context.rs:157).  Until round 6 decode_host never delivered it (advisor, round 5)."""
+    x = synth_apt(24960, 8, 77)
+    got = []
+    c = apt.Context(step_callback=lambda i, v, d, r: got.append((i, np.array(d, copy=True), r)), device=0)
+    rows = apt.decode(c, apt.Settings(export_wav=True, export_resample_filtered=flag), x, apt.Rate.hz(24960), True)
+    want_rows, st = oracle.decode(x, 24960, True, want_steps=True, export_resample_filtered=flag)
+    assert_bitexact(rows, want_rows)
+    assert [g[0] for g in got][:4] == ["input", "resample_filter", "resample_filtered", "resample_decimated"]
+    first = [g for g in got if g[0] == "resample_filtered"][0]
+    assert first[2] == 24960 and first[1].size == x.size
+    assert_bitexact(first[1], st["expanded1"], "filtered signal of the l == 1 branch")

@@ -4,5 +4,5 @@ for line in sys.stdin:
     if not line.startswith("{"):
         continue
     d = json.loads(line)
-    print(d["value"], d["ms_per_step"], d["roofline"]["kernel_avg_ms"], d["pipeline"]["kernels_ms"],
+    print(d["value"], d["ms_per_step"], d["roofline"]["kernel_avg_ms"], d["pipeline"].get("kernels_span_in_pipeline_ms", d["pipeline"].get("kernels_ms")),
           d["config"].get("picker"), d.get("parity"))
