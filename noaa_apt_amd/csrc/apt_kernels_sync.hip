@@ -708,8 +708,13 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
     auto stamp = [&](int k) {
         if (tid == 0) flags[8 + k] = static_cast<uint32_t>(__builtin_readcyclecounter() - t_begin);
     };
+    // finer stamps of the closure-free path (flags[16 ..]: tools/orbit_stamps.py prints them)
+    auto fine = [&](int k) {
+        if (tid == 0) flags[16 + k] = static_cast<uint32_t>(__builtin_readcyclecounter() - t_begin);
+    };
 
     const uint64_t kc64 = n_corr ? (n_corr - 1) / spr : 0;  // cells that can hold a start: 2 .. kc
+    const uint32_t flags7 = flags[7];  // (read here, beside flags[0]: the result record's writer would wait a round trip for it)
     bool walk = force_walk == 1 || flags[0] != 0 || n_corr == 0 || gq.work_len >= (1ull << 31);
     const uint32_t kc = static_cast<uint32_t>(kc64);
 
@@ -775,22 +780,49 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
     // below takes one global round trip per level: 18 and 34 levels for 2 of the bench's 8 recordings).  Needs
     // nodes < 65535 and (chunks + entries) * 4 + nodes * 2 + cells * 2 bytes of LDS; else the closure path runs.
     bool all_done = false;
+    bool peaks_done = false;  // ... and the peak list written from LDS already (round 6)
     uint32_t n_all = 0;
+    fine(0);  // arguments, slot pointers and the overflow flag are here
     if (!walk && alg == 1) {
         const uint32_t lds_bytes = lds_entries * 2u;
         uint32_t *s_pref = reinterpret_cast<uint32_t *>(lds_orbit);  // [n_chunks + 1] entries before chunk ch
         bool ok = (n_chunks + 1u) * 4u <= lds_bytes;                 // (uniform)
         uint32_t n_ent = 0;
+        // a contiguous run of chunks per thread.  Round 6: where that is at most kPre chunks (recordings up to 18 minutes
+        // at 1024 threads) their entry counts AND their first sixteen entries are fetched in ONE round trip — the
+        // addresses do not depend on the counts — where the scan and the gather below used to take three in a row
+        constexpr uint32_t kPre = 2;
+        const uint32_t cpt = (n_chunks + NT - 1) / NT;
+        const uint32_t c0 = static_cast<uint32_t>(tid) * cpt;
+        const bool pre = cpt <= kPre;  // (uniform)
+        uint32_t cnt_r[kPre] = {};
+        uint4 ent_r[kPre][4] = {};
+        uint32_t run_r[kPre] = {};
         if (ok) {
-            // exclusive scan of the chunks' entry counts: a contiguous run of chunks per thread
-            const uint32_t cpt = (n_chunks + NT - 1) / NT;
-            const uint32_t c0 = static_cast<uint32_t>(tid) * cpt;
             uint32_t local = 0;
-            for (uint32_t j = 0; j < cpt; ++j) {
-                const uint32_t ch = c0 + j;
-                if (ch < n_chunks) {
-                    const uint32_t c = slot_cnt[ch];
-                    local += c < kSlotCap ? c : kSlotCap;
+            if (pre) {
+#pragma unroll
+                for (uint32_t j = 0; j < kPre; ++j) {
+                    const uint32_t ch = c0 + j;
+                    if (j < cpt && ch < n_chunks) {
+                        const uint4 *src = reinterpret_cast<const uint4 *>(slot_nt + static_cast<uint64_t>(ch) * kSlotCap);
+                        cnt_r[j] = slot_cnt[ch];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ent_r[j][e] = src[e];
+                    }
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < kPre; ++j) {
+                    cnt_r[j] = cnt_r[j] < static_cast<uint32_t>(kSlotCap) ? cnt_r[j] : static_cast<uint32_t>(kSlotCap);
+                    local += cnt_r[j];
+                }
+            } else {
+                for (uint32_t j = 0; j < cpt; ++j) {
+                    const uint32_t ch = c0 + j;
+                    if (ch < n_chunks) {
+                        const uint32_t c = slot_cnt[ch];
+                        local += c < kSlotCap ? c : kSlotCap;
+                    }
                 }
             }
             uint32_t incl = local;
@@ -804,46 +836,125 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
             uint32_t before = 0;
             for (int wq = 0; wq < wave; ++wq) before += s_wtot[wq];
             uint32_t run = before + incl - local;
-            for (uint32_t j = 0; j < cpt; ++j) {
-                const uint32_t ch = c0 + j;
-                if (ch < n_chunks) {
-                    s_pref[ch] = run;
-                    const uint32_t c = slot_cnt[ch];
-                    run += c < kSlotCap ? c : kSlotCap;
+            if (pre) {
+#pragma unroll
+                for (uint32_t j = 0; j < kPre; ++j) {
+                    const uint32_t ch = c0 + j;
+                    run_r[j] = run;
+                    if (j < cpt && ch < n_chunks) s_pref[ch] = run;
+                    run += cnt_r[j];
+                }
+            } else {
+                for (uint32_t j = 0; j < cpt; ++j) {
+                    const uint32_t ch = c0 + j;
+                    if (ch < n_chunks) {
+                        s_pref[ch] = run;
+                        const uint32_t c = slot_cnt[ch];
+                        run += c < kSlotCap ? c : kSlotCap;
+                    }
                 }
             }
             if (tid == NT - 1) s_pref[n_chunks] = run;  // the last thread's run ends at the total
             __syncthreads();
             n_ent = s_pref[n_chunks];
+            fine(1);  // counts and entries fetched, counts scanned
         }
         n_all = base_d + n_ent;
         const uint32_t path_cap_a = kc + 2;
-        // LDS: s_pref | s_ent [n_ent] (uint32; the second jump table lies over it once the successors are known) |
-        // la [n_all + 1] | pth [path_cap]
-        const uint64_t need = 4ull * (n_chunks + 1u) + 4ull * n_ent + 2ull * (n_all + 2u) + 2ull * path_cap_a + 8u;
-        ok = ok && n_ent > 0 && n_all < 0xFFFFu && 2ull * (n_all + 2u) <= 4ull * n_ent && need <= lds_bytes;
+        // LDS: s_pref | s_ent [n_ent] (uint32; the pruned jump tables — or the second full one — lie over it once the
+        // successors are known) | la [n_all + 2] | pth [path_cap] | nid [n_all + 2] (all uint16)
+        const uint32_t la_len = (n_all + 2u) & ~1u, pth_len = (path_cap_a + 1u) & ~1u;
+        const uint64_t need = 4ull * (n_chunks + 1u) + 4ull * n_ent + 2ull * la_len + 2ull * pth_len + 2ull * la_len + 8u;
+        ok = ok && n_ent > 0 && n_all < 0xFFFEu && 2ull * (n_all + 2u) <= 4ull * n_ent && need <= lds_bytes;
         if (ok) {
             uint32_t *s_ent = s_pref + (n_chunks + 1);
             uint16_t *la = reinterpret_cast<uint16_t *>(s_ent + n_ent);
-            uint16_t *pth = la + ((n_all + 2u) & ~1u);
+            uint16_t *pth = la + la_len;
+            uint16_t *nid = pth + pth_len;
             uint16_t *lb = reinterpret_cast<uint16_t *>(s_ent);
             const uint16_t ENDC = static_cast<uint16_t>(n_all);
             // the node terminals of the whole recording, in order
-            for (uint32_t ch = tid; ch < n_chunks; ch += NT) {
-                const uint32_t c = slot_cnt[ch];
-                const uint32_t lim = c < kSlotCap ? c : kSlotCap;
-                const uint32_t at = s_pref[ch];
-                const uint4 *src = reinterpret_cast<const uint4 *>(slot_nt + static_cast<uint64_t>(ch) * kSlotCap);
-                for (uint32_t k4 = 0; 4 * k4 < lim; ++k4) {
-                    const uint4 v = src[k4];
-                    const uint32_t vals[4] = {v.x, v.y, v.z, v.w};
+            if (pre) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (4 * k4 + t < lim) s_ent[at + 4 * k4 + t] = vals[t];
+                for (uint32_t j = 0; j < kPre; ++j) {
+                    const uint32_t ch = c0 + j;
+                    if (j < cpt && ch < n_chunks) {
+                        const uint32_t lim = cnt_r[j], at = run_r[j];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t vals[4] = {ent_r[j][e].x, ent_r[j][e].y, ent_r[j][e].z, ent_r[j][e].w};
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                if (4u * e + t < lim) s_ent[at + 4 * e + t] = vals[t];
+                        }
+                        if (lim > 16u) {  // (rare: more than sixteen node terminals in 128 groups)
+                            const uint4 *src = reinterpret_cast<const uint4 *>(slot_nt + static_cast<uint64_t>(ch) * kSlotCap);
+                            for (uint32_t k4 = 4; 4 * k4 < lim; ++k4) {
+                                const uint4 v = src[k4];
+                                const uint32_t vals[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                                for (int t = 0; t < 4; ++t)
+                                    if (4 * k4 + t < lim) s_ent[at + 4 * k4 + t] = vals[t];
+                            }
+                        }
+                    }
+                }
+            } else {
+                for (uint32_t ch = tid; ch < n_chunks; ch += NT) {
+                    const uint32_t c = slot_cnt[ch];
+                    const uint32_t lim = c < kSlotCap ? c : kSlotCap;
+                    const uint32_t at = s_pref[ch];
+                    const uint4 *src = reinterpret_cast<const uint4 *>(slot_nt + static_cast<uint64_t>(ch) * kSlotCap);
+                    for (uint32_t k4 = 0; 4 * k4 < lim; ++k4) {
+                        const uint4 v = src[k4];
+                        const uint32_t vals[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (4 * k4 + t < lim) s_ent[at + 4 * k4 + t] = vals[t];
+                    }
                 }
             }
             __syncthreads();
-            // successor of every node (ids: 0 root, 1 .. n_grid grid cells 2 .. kc, base_d + list index)
+            fine(2);  // list in LDS
+            // first node terminal at or after sv, from the list in LDS: a binary search inside sv's chunk (the list is in
+            // position order; s_pref gives the chunk's run: <= 64 entries, ten on recordings) — a handful of instructions per
+            // step.  (Round 5 walked the chunk entry by entry from its first one, 46 k cycles for a ten-minute recording on
+            // this one CU; counting sixteen entries at a time without a dependent chain took 29 k: 150 VALU instructions
+            // per node — the phase is bound by the CU's issue slots, not by LDS latency.)  A tagged (NaN) entry only
+            // matches its own position.
+            auto lds_lower_bound = [&](uint32_t sv) -> uint32_t {  // first list index whose position is >= sv
+                const uint32_t c = sv / kChunkSpan;
+                uint32_t lo = s_pref[c], hi = s_pref[c + 1];
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((s_ent[mid] & kPosMask) < sv) lo = mid + 1; else hi = mid;
+                }
+                return lo;
+            };
+            auto lds_match_from = [&](uint32_t j, uint32_t sv, uint32_t *uval) -> uint32_t {  // (every entry from j on is >= sv)
+                for (; j < n_ent; ++j) {
+                    const uint32_t e = s_ent[j];
+                    const uint32_t pos = e & kPosMask;
+                    if (!(e & kNanStartTag) || pos == sv) { *uval = pos; return j; }
+                }
+                *uval = nc32 - 1;  // cannot happen (fact 3)
+                return n_ent - 1;
+            };
+            auto lds_first_terminal = [&](uint32_t sv, uint32_t *uval) -> uint32_t { return lds_match_from(lds_lower_bound(sv), sv, uval); };
+            auto successor = [&](uint32_t cell, uint32_t u, uint32_t j) -> uint32_t {
+                const uint32_t a = u + md + 1;
+                const uint32_t b = (cell + 1) * spr;
+                const uint32_t s2 = a > b ? a : b;
+                return s2 < nc32 ? ((a >= b) ? base_d + j : cell) : n_all;  // grid(cell+1) has id `cell`; n_all: END
+            };
+            // successor of every node (ids: 0 root, 1 .. n_grid grid cells 2 .. kc, base_d + list index), one search each, the
+            // nodes dealt round-robin.  (Measured, cycles of this phase for a ten-minute recording: entry-by-entry walk from
+            // the chunk's first entry 46 k (round 5); sixteen entries at a time, counted without a dependent chain, 29 k — 150
+            // VALU instructions per node; runs of consecutive list nodes per thread with a carried lower bound 40 k — one
+            // long dependent chain per thread; this form 21 k.)
+            const uint32_t npt = (n_all + NT - 1) / NT;
+            const uint32_t i_lo = static_cast<uint32_t>(tid) * npt;
+            const uint32_t i_hi = i_lo + npt < n_all ? i_lo + npt : n_all;
             for (uint32_t i = tid; i < n_all; i += NT) {
                 uint32_t cell, sv;
                 if (i == 0) { cell = 1; sv = 0; }
@@ -851,35 +962,179 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
                 else { sv = (s_ent[i - base_d] & kPosMask) + md + 1; cell = div_spr(sv); }
                 uint32_t nx = n_all;  // END
                 if (sv < nc32) {
-                    // first node terminal at or after sv (a tagged entry only matches its own position)
-                    uint32_t j = s_pref[sv / kChunkSpan];
-                    uint32_t u = nc32 - 1;
-                    for (; j < n_ent; ++j) {
-                        const uint32_t e = s_ent[j];
-                        const uint32_t pos = e & kPosMask;
-                        if (pos >= sv && (!(e & kNanStartTag) || pos == sv)) { u = pos; break; }
-                    }
-                    if (j >= n_ent) j = n_ent - 1;  // cannot happen (fact 3)
-                    const uint32_t a = u + md + 1;
-                    const uint32_t b = (cell + 1) * spr;
-                    const uint32_t s2 = a > b ? a : b;
-                    if (s2 < nc32) nx = (a >= b) ? base_d + j : cell;  // grid(cell+1) has id `cell`
+                    uint32_t u;
+                    const uint32_t j = lds_first_terminal(sv, &u);
+                    nx = successor(cell, u, j);
                 }
                 la[i] = static_cast<uint16_t>(nx);
             }
             if (tid == 0) { la[n_all] = ENDC; pth[0] = 0; }
+            for (uint32_t i = tid; i <= n_all; i += NT) nid[i] = 0;
             __syncthreads();
             stamp(0);  // successors known
-            if (tid == 0) lb[n_all] = ENDC;  // (over s_ent: dead from here on)
-            for (uint32_t span = 1; span < path_cap_a; span <<= 1) {
-                for (uint32_t mI = tid; mI < span && mI + span < path_cap_a; mI += NT) pth[mI + span] = la[pth[mI]];
-                for (uint32_t i = tid; i < n_all; i += NT) lb[i] = la[la[i]];
-                __syncthreads();
-                uint16_t *t = la; la = lb; lb = t;
+            // ---- round 6: only a node that is SOME node's successor (or the root) can lie on the orbit, and recordings
+            // are confluent — most of a row's ten or so candidate starts lead to the same next start — so the doubling
+            // below runs over the few nodes with a predecessor, renumbered densely, not over all of them (its cost is
+            // LDS gathers: nodes x rounds).
+            for (uint32_t i = tid; i < n_all; i += NT) {
+                const uint16_t t = la[i];
+                if (t != ENDC) nid[t] = 1;  // (the same value from every writer)
             }
+            if (tid == 0) nid[0] = 1;
+            __syncthreads();
+            uint32_t n2 = 0;
+            {
+                uint32_t local = 0;
+                for (uint32_t i = i_lo; i < i_hi; ++i) local += nid[i];
+                uint32_t incl = local;
+                const int ln = tid & 63;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(incl, d, 64);
+                    if (ln >= d) incl += o;
+                }
+                __syncthreads();  // (s_wtot: every wave has read the entry scan's totals)
+                if (ln == 63) s_wtot[wave] = incl;
+                __syncthreads();
+                uint32_t before = 0;
+                for (int wq = 0; wq < NT / 64; ++wq) {
+                    if (wq < wave) before += s_wtot[wq];
+                    n2 += s_wtot[wq];
+                }
+                uint32_t k = before + incl - local;
+                for (uint32_t i = i_lo; i < i_hi; ++i) nid[i] = nid[i] ? static_cast<uint16_t>(k++) : static_cast<uint16_t>(0xFFFFu);
+            }
+            __syncthreads();
+            fine(3);  // nodes with a predecessor numbered
+            const uint32_t l2_len = (n2 + 2u) & ~1u;
+            // (uniform) the three pruned tables behind everything else, so that the list stays readable: the path's starts and
+            // terminals are then looked up in LDS too and the peak list below is written from LDS (path arrays over `la`)
+            const bool fastp = need + 6ull * l2_len <= lds_bytes && 12ull * path_cap_a <= 2ull * la_len;
+            const bool pruned = 3ull * 2ull * l2_len <= 4ull * n_ent;  // (uniform) else: three tables over s_ent
+            if (fastp) {
+                uint16_t *la2 = nid + la_len, *lb2 = la2 + l2_len, *orig = lb2 + l2_len;
+                const uint16_t END2 = static_cast<uint16_t>(n2);
+                for (uint32_t i = i_lo; i < i_hi; ++i) {
+                    const uint16_t me = nid[i];
+                    if (me != 0xFFFFu) {
+                        const uint16_t t = la[i];
+                        la2[me] = t == ENDC ? END2 : nid[t];  // (a successor has a predecessor: it is numbered)
+                        orig[me] = static_cast<uint16_t>(i);
+                    }
+                }
+                if (tid == 0) { la2[n2] = END2; lb2[n2] = END2; }  // (pth[0] = 0: the root is the first numbered node)
+                __syncthreads();
+                // path[m + q 4^r] = J^q[path[m]], q = 1 .. 3;  J <- J^4: half the rounds (and barriers) of plain doubling
+                for (uint32_t span = 1; span < path_cap_a; span <<= 2) {
+                    for (uint32_t mI = tid; mI < span && mI + span < path_cap_a; mI += NT) {
+                        const uint16_t t1 = la2[pth[mI]], t2 = la2[t1], t3 = la2[t2];
+                        pth[mI + span] = t1;
+                        if (mI + 2 * span < path_cap_a) pth[mI + 2 * span] = t2;
+                        if (mI + 3 * span < path_cap_a) pth[mI + 3 * span] = t3;
+                    }
+                    // (four entries per thread and pass, their four-deep chains side by side: the phase is LDS latency)
+                    for (uint32_t i = tid; i < n2; i += 4 * NT) {
+                        uint16_t t[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = la2[i + e * NT < n2 ? i + e * NT : n2];
+#pragma unroll
+                        for (int d = 0; d < 3; ++d)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) t[e] = la2[t[e]];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (i + e * NT < n2) lb2[i + e * NT] = t[e];
+                    }
+                    __syncthreads();
+                    uint16_t *t = la2; la2 = lb2; lb2 = t;
+                }
+                if (tid == 0) flags[13] = n2;
+                fine(4);  // orbit known
+                // the path's starts, cells and terminals -> LDS (over `la`: dead)
+                uint32_t *p_sv = reinterpret_cast<uint32_t *>(la), *p_cell = p_sv + path_cap_a, *p_u = p_cell + path_cap_a;
+                for (uint32_t k = tid; k < path_cap_a; k += NT) {
+                    const uint16_t q = pth[k];
+                    uint32_t sv = 0xFFFFFFFFu, cell = 0, u = 0;
+                    if (q != END2) {
+                        const uint32_t i = orig[q];
+                        if (i == 0) { cell = 1; sv = 0; }
+                        else if (i < base_d) { cell = i + 1; sv = cell * spr; }
+                        else { sv = (s_ent[i - base_d] & kPosMask) + md + 1; cell = div_spr(sv); }
+                        if (sv < nc32) (void)lds_first_terminal(sv, &u);
+                    }
+                    p_sv[k] = sv;
+                    p_cell[k] = cell;
+                    p_u[k] = u;
+                }
+                if (tid == 0) { s_plen = 1; s_fit = 0ull; }
+                __syncthreads();
+                stamp(1);  // orbit extracted
+                unsigned long long fit_l = 0;
+                for (uint32_t k = tid; k < path_cap_a; k += NT) {
+                    const uint32_t sv = p_sv[k];
+                    if (sv == 0xFFFFFFFFu) continue;
+                    const uint32_t u = p_u[k];
+                    const bool is_last = (k + 1 >= path_cap_a) || p_sv[k + 1] == 0xFFFFFFFFu;
+                    if (k == 0) {
+                        if (peaks_cap > 0) peaks[0] = u;
+                        if (!is_last && u + spr < wl32) ++fit_l;
+                        if (is_last) s_plen = 1;
+                        continue;
+                    }
+                    const uint32_t c_prev = (k - 1 == 0) ? 1u : p_cell[k - 1];  // the root leaves one entry
+                    const uint32_t c = p_cell[k];                               // = s / spr for k >= 1
+                    for (uint32_t qv = c_prev; qv + 1 < c; ++qv)
+                        if (qv < peaks_cap) peaks[qv] = sv;
+                    if (c - 1 < peaks_cap) peaks[c - 1] = u;
+                    if (sv + spr < wl32) fit_l += c - c_prev - 1;
+                    if (!is_last && u + spr < wl32) ++fit_l;  // the last peak is dropped
+                    if (is_last) s_plen = c;
+                }
+                // (one LDS atomic per wave: a thousand of them on one address serialise — seven microseconds)
+                {
+                    uint32_t f32v = static_cast<uint32_t>(fit_l);  // (< 2^32: rows of one recording)
+                    for (int d = 32; d >= 1; d >>= 1) f32v += __shfl_down(f32v, d, 64);
+                    if ((tid & 63) == 0 && f32v) atomicAdd(&s_fit, static_cast<unsigned long long>(f32v));
+                }
+                __syncthreads();
+                peaks_done = true;
+            } else if (pruned) {
+                uint16_t *la2 = reinterpret_cast<uint16_t *>(s_ent), *lb2 = la2 + l2_len, *orig = lb2 + l2_len;
+                const uint16_t END2 = static_cast<uint16_t>(n2);
+                for (uint32_t i = i_lo; i < i_hi; ++i) {
+                    const uint16_t me = nid[i];
+                    if (me != 0xFFFFu) {
+                        const uint16_t t = la[i];
+                        la2[me] = t == ENDC ? END2 : nid[t];  // (a successor has a predecessor: it is numbered)
+                        orig[me] = static_cast<uint16_t>(i);
+                    }
+                }
+                if (tid == 0) { la2[n2] = END2; lb2[n2] = END2; }  // (pth[0] = 0: the root is the first numbered node)
+                __syncthreads();
+                for (uint32_t span = 1; span < path_cap_a; span <<= 1) {
+                    for (uint32_t mI = tid; mI < span && mI + span < path_cap_a; mI += NT) pth[mI + span] = la2[pth[mI]];
+                    for (uint32_t i = tid; i < n2; i += NT) lb2[i] = la2[la2[i]];
+                    __syncthreads();
+                    uint16_t *t = la2; la2 = lb2; lb2 = t;
+                }
+                for (uint32_t k = tid; k < path_cap_a; k += NT) {
+                    const uint16_t q = pth[k];
+                    pth[k] = q == END2 ? ENDC : orig[q];
+                }
+                __syncthreads();
+            } else {
+                if (tid == 0) lb[n_all] = ENDC;  // (over s_ent: dead from here on)
+                for (uint32_t span = 1; span < path_cap_a; span <<= 1) {
+                    for (uint32_t mI = tid; mI < span && mI + span < path_cap_a; mI += NT) pth[mI + span] = la[pth[mI]];
+                    for (uint32_t i = tid; i < n_all; i += NT) lb[i] = la[la[i]];
+                    __syncthreads();
+                    uint16_t *t = la; la = lb; lb = t;
+                }
+            }
+            if (tid == 0 && !fastp) flags[13] = n2;  // nodes with a predecessor (diagnostics)
+            if (!fastp) fine(4);  // orbit known (LDS ids)
             // the path in the kernel's node ids (base_d + chunk * kSlotCap + k for list entries), and the terminal
             // each of its nodes reaches — what the peak-list code below reads
-            for (uint32_t k = tid; k < path_cap_a; k += NT) {
+            for (uint32_t k = tid; !fastp && k < path_cap_a; k += NT) {
                 const uint32_t i = pth[k];
                 uint32_t v = END;
                 if (i != ENDC) {
@@ -976,7 +1231,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
             flags[1] = 1u;  // report which path ran
             flags[0] = 0u;  // re-arm the overflow flag for the next decode
             flags[5] = 0u;
-            flags[11] = flags[7];  // candidates k_sync_words settled with exact window maxima; re-armed
+            flags[11] = flags7;  // candidates k_sync_words settled with exact window maxima; re-armed
             flags[7] = 0u;
         }
         return;
@@ -1050,14 +1305,16 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         uint32_t *t = ja; ja = jb; jb = t;
     }
     }  // !direct && !in_lds
-    stamp(1);  // orbit extracted
+    if (!peaks_done) stamp(1);  // orbit extracted
 
     // ---- peak list: path[k] (k >= 1) starts at s in cell c; pushes fill
     // peaks[cell(prev) .. c-2] with s and peaks[c-1] with u = firstT(s)
+    if (!peaks_done) {
     if (tid == 0) { s_plen = 1; s_fit = 0ull; }
     __syncthreads();
+    }
     unsigned long long fit_local = 0;
-    for (uint32_t k = tid; k < path_cap; k += NT) {
+    for (uint32_t k = tid; !peaks_done && k < path_cap; k += NT) {
         const uint32_t v = gld(w_path + k);
         if (v == END) continue;
         uint32_t cell;
@@ -1081,8 +1338,14 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         if (!is_last && u + spr < wl32) ++fit_local;  // the last peak is dropped
         if (is_last) s_plen = c;
     }
-    atomicAdd(&s_fit, fit_local);
+    if (!peaks_done) {
+    {
+        uint32_t f32v = static_cast<uint32_t>(fit_local);
+        for (int d = 32; d >= 1; d >>= 1) f32v += __shfl_down(f32v, d, 64);
+        if ((tid & 63) == 0 && f32v) atomicAdd(&s_fit, static_cast<unsigned long long>(f32v));
+    }
     __syncthreads();
+    }
     if (tid == 0) {
         const uint32_t len = s_plen;
         const bool few = len < 5;  // decode.rs:112-118
@@ -1102,7 +1365,7 @@ k_sync_orbit_global(const CallArgs call, const SlotPtrs *__restrict__ slots, uin
         // orbit: 1 read off directly, 2 doubling in LDS over the visited nodes, 0 the same through L2, 3 doubling over all nodes (alg 1)
         flags[6] = all_done ? 3u : direct ? 1u : (in_lds ? 2u : 0u);
         if (all_done) flags[12] = 0u;  // no breadth-first levels
-        flags[11] = flags[7];  // candidates k_sync_words settled with exact window maxima; re-armed
+        flags[11] = flags7;  // candidates k_sync_words settled with exact window maxima; re-armed
         flags[7] = 0u;
     }
     stamp(2);  // peaks written

@@ -186,7 +186,9 @@ def test_first_resample_with_l_equal_1_delivers_the_filtered_signal(oracle, flag
     got = []
     c = apt.Context(step_callback=lambda i, v, d, r: got.append((i, np.array(d, copy=True), r)), device=0)
     rows = apt.decode(c, apt.Settings(export_wav=True, export_resample_filtered=flag), x, apt.Rate.hz(24960), True)
-    want_rows, st = oracle.decode(x, 24960, True, want_steps=True, export_resample_filtered=flag)
+    want_rows = oracle.decode(x, 24960, True, export_resample_filtered=flag)
+    # (the oracle hands out the "resample_filtered" signals with the flag set; at l == 1 the flag changes nothing else)
+    _, st = oracle.decode(x, 24960, True, want_steps=True, export_resample_filtered=True)
     assert_bitexact(rows, want_rows)
     assert [g[0] for g in got][:4] == ["input", "resample_filter", "resample_filtered", "resample_decimated"]
     first = [g for g in got if g[0] == "resample_filtered"][0]
