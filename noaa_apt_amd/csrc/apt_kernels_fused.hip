@@ -179,10 +179,12 @@ bool fused_fast_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint
 // ---- kModeStrictPad: the strict SPLIT kernels compiled for a tap-count bound (apt_kernels_fused_launch.hpp)
 uint32_t fused_pad_t1(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
 {
-    if (l != 13 || t2 != 37 || pw != 3 || (t1 & 1u) == 0) return 0;  // (Kaiser lengths are odd: filters.rs:164-167)
-    if (m == 50 && t1 <= static_cast<uint32_t>(kPadT1Max48k)) return kPadT1Max48k;
-    if (m == 100 && t1 <= static_cast<uint32_t>(kPadT1Max96k)) return kPadT1Max96k;
-    return 0;
+    if (l != 13 || (t1 & 1u) == 0) return 0;  // (Kaiser lengths are odd: filters.rs:164-167)
+    uint32_t bound = 0;
+    if (t2 == 37 && pw == 3) bound = m == 50 ? kPadT1Max48k : m == 100 ? kPadT1Max96k : 0;           // standard profile
+    else if (t2 == 61 && pw == 5) bound = m == 30 ? kPadT1Max48kSlow : m == 60 ? kPadT1Max96kSlow : 0;  // slow profile
+    else if (t2 == 43 && pw == 4) bound = m == 75 ? kPadT1Max96kFastp : 0;                            // fast profile, 96 kHz
+    return t1 <= bound ? bound : 0;
 }
 
 // ---- kModeMfma: the FIRs as banded Toeplitz products on the matrix cores (apt_kernels_fused_launch.hpp)
@@ -266,7 +268,11 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
     if (mode == kModeStrictPad) {
         if (fused_pad_t1(l, m, t1, t2, pw) == 0) return false;
         if (m == 50) pcm16 ? fused_launch_48k_pad_i16(a) : fused_launch_48k_pad_f32(a);
-        else pcm16 ? fused_launch_96k_pad_i16(a) : fused_launch_96k_pad_f32(a);
+        else if (m == 100) pcm16 ? fused_launch_96k_pad_i16(a) : fused_launch_96k_pad_f32(a);
+        else if (m == 30) pcm16 ? fused_launch_48k_slow_pad_i16(a) : fused_launch_48k_slow_pad_f32(a);
+        else if (m == 60) pcm16 ? fused_launch_96k_slow_pad_i16(a) : fused_launch_96k_slow_pad_f32(a);
+        else if (m == 75 && !pcm16) fused_launch_96k_fastp_pad_f32(a);
+        else return false;
         return true;
     }
     if (mode == kModeMfma) {

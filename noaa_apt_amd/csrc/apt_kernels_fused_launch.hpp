@@ -30,8 +30,11 @@ constexpr int kModeMfma = 3;
 constexpr int kModeStrictPad = 4;
 // FusedGeom's variant argument for a mode
 constexpr int fused_geom_var(int mode) { return mode == kModeF16Taps ? 1 : mode == kModeMfma ? 2 : mode == kModeStrictPad ? 3 : 0; }
-// tap counts the padded strict instantiations are compiled for (83 / 165 taps per branch; stock: 74 / 148)
+// tap counts the padded strict instantiations are compiled for, about an eighth above the stock profiles' counts
+// (standard 48 / 96 kHz: 83 / 165 taps per branch, stock 74 / 148; slow 48 / 96 kHz: 241 / 481, stock 215 / 429; fast
+// profile at 96 kHz: 56, stock 50)
 constexpr int kPadT1Max48k = 1079, kPadT1Max96k = 2145;
+constexpr int kPadT1Max48kSlow = 3133, kPadT1Max96kSlow = 6253, kPadT1Max96kFastp = 727;
 // tap counts the MFMA instantiations are compiled for (window of a tile's last branch + taps per branch <= K = 128 / 256)
 constexpr int kMfmaT1Max48k = 1053, kMfmaT1Max96k = 2119;
 
@@ -105,6 +108,11 @@ void fused_launch_48k_pad_f32(const FusedLaunch &a);
 void fused_launch_48k_pad_i16(const FusedLaunch &a);
 void fused_launch_96k_pad_f32(const FusedLaunch &a);
 void fused_launch_96k_pad_i16(const FusedLaunch &a);
+void fused_launch_48k_slow_pad_f32(const FusedLaunch &a);
+void fused_launch_48k_slow_pad_i16(const FusedLaunch &a);
+void fused_launch_96k_slow_pad_f32(const FusedLaunch &a);
+void fused_launch_96k_slow_pad_i16(const FusedLaunch &a);
+void fused_launch_96k_fastp_pad_f32(const FusedLaunch &a);  // (odd m: f32 input only, as the exact-count kernel)
 // 48 kHz at the slow profile (13 / 30, 2783 taps; 61-tap low-pass, pixel width 5): the same SPLIT form
 void fused_launch_48k_slow_f32(const FusedLaunch &a);
 void fused_launch_48k_slow_i16(const FusedLaunch &a);

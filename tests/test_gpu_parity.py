@@ -984,6 +984,28 @@ TUNED = [(48000, dict(resample_atten=29.0)), (48000, dict(resample_atten=31.0)),
          (96000, dict(resample_delta_freq=1100.0)), (48000, dict(resample_cutout=5200.0))]
 
 
+TUNED_PROFILES = [(48000, "slow", dict(resample_atten=41.0)), (48000, "slow", dict(resample_delta_freq=520.0)),
+                  (96000, "slow", dict(resample_atten=39.0)), (96000, "fast", dict(resample_atten=31.0)),
+                  (96000, "fast", dict(resample_delta_freq=2900.0))]
+
+
+@pytest.mark.parametrize("rate,profile,kw", TUNED_PROFILES)
+def test_tuned_settings_of_the_other_profiles(ctx, oracle, rate, profile, kw):
+    """The slow profile at 48 / 96 kHz and the fast profile at 96 kHz (l = 13: the SPLIT kernels) with a tuned filter."""
+    s = apt.Settings.profile(profile)
+    for k, v in kw.items():
+        setattr(s, k, v)
+    os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                       "resample_cutout", "demodulation_atten")}
+    x = synth_apt(rate, 12, seed=54)
+    for sync in (True, False):
+        want, st = oracle.decode(x, rate, sync, settings=os_, want_steps=True)
+        got, stats = apt.decode(ctx, s, x, apt.Rate.hz(rate), sync, return_stats=True)
+        assert stats.n_resample_taps == st["resample_filter"].size and stats.n_resample_taps not in (2783, 5565, 639)
+        assert stats.fused == 1, (rate, profile, kw, stats.n_resample_taps)
+        assert_bitexact(got, want, f"tuned {rate} {profile} {kw} sync={sync}")
+
+
 @pytest.mark.parametrize("rate,kw", TUNED)
 @pytest.mark.parametrize("sync", [True, False])
 def test_tuned_settings_stay_on_the_specialised_kernel(ctx, oracle, rate, kw, sync):
