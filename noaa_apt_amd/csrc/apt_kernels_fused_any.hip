@@ -51,7 +51,9 @@ struct Candidate {
     int nthr, kpt;
 };
 // most resident waves per CU first (LDS permitting), then the larger tile
-constexpr Candidate kCandidates[] = {{256, 8}, {1024, 8}, {1024, 4}};
+// (round 6: {256, 4} — a tile of 1024 work samples — for input rates beyond seventeen times the work rate's 1 / l share:
+// 250 kHz SDR recordings, whose 2048-sample tile needs more input than the LDS holds, ran the unfused kernels)
+constexpr Candidate kCandidates[] = {{256, 8}, {1024, 8}, {1024, 4}, {256, 4}};
 
 bool make_geom(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, int nthr, int kpt, bool table_in_global,
                AnyGeom *out, size_t *lds_bytes)
@@ -67,6 +69,10 @@ bool make_geom(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, in
     g.pulse = 2 * pw;
     g.kt = static_cast<uint32_t>(nthr * kpt);
     if (38 * pw > 256) return false;  // sign bitmap
+    // 32-bit in-tile index math: (tile outputs + look-ahead) * m + l must stay below 2^31 (per launch shape since round 6:
+    // the old blanket test for the largest tile sent every rate above 170 kHz that is coprime to the work rate to the
+    // unfused kernels)
+    if ((static_cast<uint64_t>(g.kt) + 4096u) * m + l > 0x7fffffffull) return false;
     g.pre = (t2 + 2 * static_cast<uint32_t>(kpt) + static_cast<uint32_t>(kpt) - 1) / static_cast<uint32_t>(kpt) *
             static_cast<uint32_t>(kpt);  // multiple of KPT (and of 4)
     if (g.kt < g.pre + g.g + kGS) return false;
@@ -136,8 +142,6 @@ bool choose(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, Candi
 bool fused_any_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
 {
     if (l == 0 || m == 0 || t1 == 0 || t2 == 0 || pw == 0) return false;
-    // 32-bit in-tile index math: (tile outputs) * m + l must stay far below 2^32
-    if (static_cast<uint64_t>(8192 + 4096) * m + l > 0x7fffffffull) return false;
     Candidate c;
     AnyGeom g;
     size_t lds;
@@ -183,6 +187,8 @@ bool fused_any_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uin
         fused_any_launch_1024x8(s, call, d_slots, max_w, pcm16, table, h2, h2p, cosphi2, sinphi, inv_sinphi, want_gm, g, lds, prof);
     else if (c.nthr == 1024 && c.kpt == 4)
         fused_any_launch_1024x4(s, call, d_slots, max_w, pcm16, table, h2, h2p, cosphi2, sinphi, inv_sinphi, want_gm, g, lds, prof);
+    else if (c.nthr == 256 && c.kpt == 4)
+        fused_any_launch_256x4(s, call, d_slots, max_w, pcm16, table, h2, h2p, cosphi2, sinphi, inv_sinphi, want_gm, g, lds, prof);
     else
         return false;
     return true;

@@ -28,5 +28,6 @@ struct AnyGeom {
 void fused_any_launch_256x8(APT_ANY_SHAPE_ARGS);
 void fused_any_launch_1024x8(APT_ANY_SHAPE_ARGS);
 void fused_any_launch_1024x4(APT_ANY_SHAPE_ARGS);
+void fused_any_launch_256x4(APT_ANY_SHAPE_ARGS);
 
 }  // namespace apt::gpu

@@ -3,9 +3,9 @@
 decode() at rates a sound card never writes — SDR front ends (60 000 / 192 000 / 250 000 Hz), rates coprime to the
 work rate (44 101 Hz: l = 12 480, ~0.84 M resampler taps), rates just under the RateOverflow edge of dsp.rs:82-91
 (in * l still fits u32) and just over it, and rates drawn from a seeded generator — at the three stock profiles,
-sync and no-sync, bit for bit against the oracle.  Every case records which kernel path served it
-(stats.fused) and what a decode cost; `APTGPU_RATES_REPORT=<file>` appends the table
-"rate -> l / m / taps -> kernel path -> ms" (profiles/r06_rates.txt is one run of it).
+sync and no-sync, bit for bit against the oracle.  Every case checks that a documented kernel path served it
+(stats.fused); `APTGPU_RATES_REPORT=<file>` appends "rate -> l / m / taps -> kernel path -> one-shot ms" (host time
+included).  The table on device time — profiles/r06_rates.txt — is tools/rate_timing.py over the same rates.
 
 Tolerance: NONE (strict mode; uint32 views compared).
 """

@@ -54,6 +54,8 @@ done
 (cd $R && python bench.py --no-extras --mode fast --seconds 900 --batch 32 --inputs 32 --steps 12 --warmup 2 > $O/bench_config4_share_fast.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --rate 96000 --seconds 3600 --batch 1 --inputs 2 --steps 20 --warmup 3 > $O/bench_config3.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --mode fp16taps > $O/bench_fp16taps.json 2>> $O/bench_strict.err)
+# APTGPU_MODE_FAST with the resampler on the matrix cores (kModeMfma) at the stock tap count: the A/B of round 6
+(cd $R && APTGPU_FAST_MFMA=1 python bench.py --no-extras --no-cpu-baseline --mode fast > $O/bench_fast_mfma.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --batch 1 > $O/bench_strict_batch1.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --config4 > $O/bench_config4.json 2>> $O/bench_strict.err)
 (cd $R && python bench.py --no-extras --rate 44100 > $O/bench_44100.json 2>> $O/bench_strict.err)
