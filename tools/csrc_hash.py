@@ -28,12 +28,26 @@ _GROUPS = {
 }
 
 
+def _makefile_flags(path):
+    """What of the Makefile decides how a kernel is compiled: the compiler, the architecture and the flags — not the list of
+    translation units (round 6: adding an instantiation file used to invalidate every group's profiles)."""
+    keep = []
+    with open(path, "rb") as f:
+        for line in f.read().splitlines():
+            if line.startswith((b"HIPCC", b"ARCH", b"CXXFLAGS")) or b"$(HIPCC)" in line:
+                keep.append(line)
+    return b"\n".join(keep)
+
+
 def _hash(root, keep):
     d = os.path.join(root, "noaa_apt_amd", "csrc")
     h = hashlib.sha256()
     for name in sorted(os.listdir(d)):
         if keep(name):
             h.update(name.encode())
+            if name == "Makefile":
+                h.update(_makefile_flags(os.path.join(d, name)))
+                continue
             with open(os.path.join(d, name), "rb") as f:
                 h.update(f.read())
     return h.hexdigest()[:16]
