@@ -1064,3 +1064,44 @@ def test_padded_kernel_on_the_stock_tap_counts_and_non_finite_samples(oracle, mo
     assert_bitexact(d_out[:res.n_out].cpu().numpy(), want, "padded, PCM16")
     plan.close()
     apt.cache_clear()
+
+
+def _random_tunings(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        out.append(dict(resample_atten=float(np.round(rng.uniform(20.0, 42.0), 1)),
+                        resample_delta_freq=float(np.round(rng.uniform(650.0, 1600.0))),
+                        resample_cutout=float(np.round(rng.uniform(4200.0, 5400.0)))))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["strict", "fast"])
+@pytest.mark.parametrize("rate", [48000, 96000])
+def test_random_tunings_of_the_standard_profile(oracle, rate, mode):
+    """Seeded random (attenuation, transition width, cutout) triples around the standard profile: tap counts on both
+    sides of the padded kernels' bounds (1079 / 2145) and of the matrix-core kernel's (1053 / 2119) — whichever kernel the
+    plan lands on, strict mode is bit-exact and fast mode inside its tolerance; a count above every bound takes the
+    run-time kernel (stats.fused == 2)."""
+    from test_gpu_fast import check_tolerance, decode_on_plan
+    seen = set()
+    for kw in _random_tunings(7, 600 + rate // 1000):
+        s = apt.Settings(**kw)
+        os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                           "resample_cutout", "demodulation_atten")}
+        x = synth_apt(rate, 11, seed=int(kw["resample_delta_freq"]))
+        want, st = oracle.decode(x, rate, True, settings=os_, want_steps=True)
+        t1 = st["resample_filter"].size
+        bound = 1079 if rate == 48000 else 2145
+        if mode == "strict":
+            got, stats = apt.decode(apt.Context(device=0), s, x, apt.Rate.hz(rate), True, return_stats=True)
+            assert stats.n_resample_taps == t1
+            assert stats.fused == (1 if t1 <= bound else 2), (kw, t1, stats.fused)
+            assert_bitexact(got, want, f"random tuning {rate} {kw} ({t1} taps)")
+            seen.add(stats.fused)
+        else:
+            rows, pos, res, fused = decode_on_plan(x, rate, apt.MODE_FAST, settings=s)
+            assert fused == (1 if t1 <= bound else 2) and res.status == 0, (kw, t1, fused)
+            check_tolerance(rows, pos, want, st["sync_pos"], f"random tuning, fast mode, {rate} {kw} ({t1} taps)")
+            seen.add(fused)
+    assert seen == {1, 2}, seen  # the draw covers both sides of the bound
