@@ -393,6 +393,14 @@ def main():
             step()
         ktimes = plan.collect_timing()
         plan.enable_timing(0)
+        # what the power manager does meanwhile (every rank, its own device): the SMU's accumulators read before and after
+        # a window of pipelined steps — no thread beside it — and a sampled loop of the same steps behind it.  The first
+        # snapshot is taken HERE, before the settle and warm-up steps, not between the warm-up's synchronize and t0 (round
+        # 6: a gpu_metrics read takes milliseconds; with the GPU drained the package's power average relaxes meanwhile and
+        # the K timed steps start on the controller's transient — 0.850-0.855 ms per step in the driver's 20-step shape
+        # against 0.836-0.839 without the read, profiles/r06_bench_steps20_snapshot_ab.txt).  The window is therefore
+        # settle + W + K steps of the same loop (`power.window`), and joules per call is its energy over that many calls.
+        snap0 = smu.snapshot() if smu is not None else None
         for _ in range(args.settle_steps):
             step()
 
@@ -400,11 +408,6 @@ def main():
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
-        # what the power manager does meanwhile (every rank, its own device): the SMU's accumulators read before and after
-        # the timed region — no thread beside it — and a sampled loop of the same steps behind it.  The first snapshot is
-        # taken BEFORE the barrier: its latency varies from call to call, and between barrier and t0 it would skew the
-        # ranks' starts (the job's time is the slowest rank's).
-        snap0 = smu.snapshot() if smu is not None else None
         # timed region: HIP events bracket the dominant kernel of every 8th step (the markers
         # serialise the stream for ~6 us each; sampling keeps the measurement live but cheap)
         plan.enable_timing(0 if args.no_kernel_timing else 1)
@@ -422,9 +425,12 @@ def main():
         plan.enable_timing(0)
         power = None
         if smu is not None:
-            power = {"source": "amd-smi gpu_metrics, per rank (this object: rank 0's device): energy and throttler-residency accumulators read before / after the timed "
-                               "region; socket power and per-XCD gfx clocks sampled every 2 ms during the loop behind it",
-                     "timed_region": smu.between(snap0, smu.snapshot())}
+            power = {"source": "amd-smi gpu_metrics, per rank (this object: rank 0's device): energy and throttler-residency accumulators read before the settle + "
+                               "warm-up steps and after the timed steps (`window`: all of them, the same pipelined loop; nothing is read between the warm-up's "
+                               "synchronize and t0); socket power and per-XCD gfx clocks sampled every 2 ms during the loop behind it",
+                     "window": smu.between(snap0, smu.snapshot())}
+            if power["window"] is not None:
+                power["window"]["steps"] = args.settle_steps + args.warmup + args.steps
             if smu.available:
                 # the same loop again for ~0.4 s under the sampler, the first 0.1 s left out: what the pipeline looks like
                 # to the power manager once it has settled
@@ -634,12 +640,12 @@ def main():
     except Exception as e:  # noqa: BLE001
         aff = {"error": str(e)}
     settled = (power or {}).get("settled") or {}
-    timed = (power or {}).get("timed_region") or {}
+    timed = (power or {}).get("window") or {}
     mine = {"rank": rank, "device": local_rank, "ms_per_step": round(1e3 * (t_local - t0) / args.steps, 5),
             "socket_w": (settled.get("socket_w") or {}).get("mean"),
             "gfxclk_mhz": (settled.get("gfxclk_mhz") or {}).get("mean_over_xcds"),
-            "joules_per_call": (round(timed["socket_w_mean"] * timed["window_s"] / args.steps, 4)
-                                if timed.get("socket_w_mean") and timed.get("window_s") else None),
+            "joules_per_call": (round(timed["socket_w_mean"] * timed["window_s"] / timed["steps"], 4)
+                                if timed.get("socket_w_mean") and timed.get("window_s") and timed.get("steps") else None),
             "pci": aff.get("pci"), "numa_node": aff.get("numa_node"),
             "cpus_allowed": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
     per_rank = [mine]
@@ -748,7 +754,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5),
-            "joules_per_call": mine["joules_per_call"],  # socket energy accumulator over the timed region / K: rank 0's device (every rank's: per_rank)
+            "joules_per_call": mine["joules_per_call"],  # socket energy accumulator over `power.window` (settle + W + K pipelined steps) / that many calls: rank 0's device (every rank's: per_rank)
             "per_rank": per_rank,
             "higher_is_better": True,
             "scaling": "weak",
