@@ -169,7 +169,14 @@ struct TableGeom {
     // PHASE mode: the thread -> branch-slot assignment (fused_phase_table): `nperm` lists of `nthr` uint32 entries at
     // float offset `perm_off` of the table buffer, list (tile % nperm) for a tile; an entry >= step_r marks an idle thread
     uint32_t nthr, perm_off, nperm;
-    uint32_t nq;               // PHASE mode: branches per thread (1, 2, 4, 8); step_r / nq threads of a workgroup have work
+    uint32_t nq;               // PHASE mode: branches per thread (1, 2, 4, 8, 16)
+    // PHASE mode: the slot stride — a thread with list entry u < sq holds the slots u + q sq (q < nq) that are < step_r.
+    // nq == 1: sq = step_r.  nq == 4 (standard and slow profile), 8: sq = nthr (round 6: every thread has work and only the LAST slots of some threads
+    // do not exist — l = 832: four slots for threads 0-63, three for the others, 13 wave-branches per tile instead of the 16
+    // of sq = step_r / nq = 208, whose fourth wave ran every branch for 16 lanes: 2-3 % on the front end, not the 5 % the
+    // instruction count promised — these kernels wait more than they issue, profiles/r06_phase_balanced_ab.txt).  Else
+    // sq = step_r / nq (no gain / a loss measured).  APTGPU_PHASE_BALANCED=0 / 1 forces one form for every nq.
+    uint32_t sq;
     uint32_t stream;           // PHASE mode: taps streamed from the table (filters too long for the registers), rows padded to 16
     // PHASE mode, exact != 0 (the tile phases repeat with a period nperm = 1 << perm_shift <= 8): list (tile % nperm) is
     // built for that tile's phase, and everything a tile derives from its index by division is tabulated — per phase r the

@@ -451,6 +451,15 @@ bool phase_geom(uint32_t threads, uint32_t nq, uint32_t l, uint32_t m, uint32_t 
     if ((tile + stride - 1) / stride > std::max(1u, kPhaseOutputs / nq)) return false;
     g.step_r = stride;
     g.step_q = static_cast<uint32_t>(static_cast<uint64_t>(stride) * m / l);  // exact: l divides stride
+    // slot stride (TableGeom::sq): four / eight branches per thread — every thread takes slots, `threads` apart, and the
+    // slots >= l do not exist; else l / nq slots of nq branches each (A/B switch, plan creation: APTGPU_PHASE_BALANCED=0 / 1)
+    {
+        const char *bal = std::getenv("APTGPU_PHASE_BALANCED");
+        // (default: where it measured faster — profiles/r06_phase_balanced_ab.txt: four branches at the standard and slow
+        // profiles, eight at the fast one; not the fast profile's four (44 100 Hz) and sixteen, not two branches)
+        const bool balanced = (bal && (bal[0] == '0' || bal[0] == '1')) ? bal[0] == '1' : ((nq == 4 && t2 != 43) || nq == 8);
+        g.sq = nq == 1 ? stride : (balanced ? threads : stride / nq);
+    }
     // paired input tile: kPhaseOutputs / nq / 2 regions of off_x f2 entries — a branch's window starts at most
     // step_q + 4 entries into its region and is per_phase long
     g.off_x = g.step_q + per_phase + 8;
@@ -539,8 +548,15 @@ void fused_phase_table(const TableGeom &g, uint32_t t2, uint32_t pw, const float
     (void)t1;
     const PhaseTile pt = phase_tile(g.nthr, t2, pw);
     const uint32_t nq = g.nq ? g.nq : 1u;
-    const uint32_t S = g.step_r / nq;                  // slots: threads with work
+    const uint32_t S = g.sq;                           // slot stride = threads with work; thread slot u holds u + q S < step_r
     const uint32_t NH = 2 * ((S + 63) / 64);           // half-waves of the waves with work (the other waves skip stage 1's arithmetic)
+    // does slot u's branch q exist?  (nq == 1: S = step_r, always; S = step_r / nq: always; S = threads: not the last ones)
+    auto exists = [&](uint32_t u, uint32_t q) -> bool { return u + q * S < g.step_r; };
+    auto branches_of = [&](uint32_t u) -> uint32_t {
+        uint32_t n = 0;
+        for (uint32_t q = 0; q < nq; ++q) n += exists(u, q) ? 1u : 0u;
+        return n;
+    };
     const char *ident = std::getenv("APTGPU_PHASE_IDENTITY");  // A/B switch: slot = thread, as until round 4
     std::vector<uint32_t> list(g.nthr), ident_list(g.nthr);
     for (uint32_t t = 0; t < g.nthr; ++t) ident_list[t] = t < S ? t : 0xFFFFFFFFu;
@@ -549,7 +565,8 @@ void fused_phase_table(const TableGeom &g, uint32_t t2, uint32_t pw, const float
         int64_t rb = (k0 * static_cast<int64_t>(g.m)) % static_cast<int64_t>(l);
         if (rb < 0) rb += l;
         // window start of slot u's branch q: its entry in a region, and that mod the 32 entry positions of the LDS banks
-        auto ent = [&](uint32_t u, uint32_t q) -> uint32_t {
+        auto ent = [&](uint32_t u, uint32_t q) -> uint32_t {  // (a slot that does not exist reads entry 0: every such lane the same one)
+            if (!exists(u, q)) return 0u;
             return static_cast<uint32_t>((static_cast<uint64_t>(rb) + static_cast<uint64_t>(u + q * S) * g.m + l - 1) / l);
         };
         auto res = [&](uint32_t u, uint32_t q) -> uint32_t { return ent(u, q) & 31u; };
@@ -592,17 +609,34 @@ void fused_phase_table(const TableGeom &g, uint32_t t2, uint32_t pw, const float
         // greedy: slots of the largest residue classes (of branch 0) first, each to the half-wave where it adds the
         // fewest extra passes over all its branches; among equals, to the one where it meets the fewest rivals, then
         // to the emptiest
+        // Slots with more branches first, into the first half-waves: a wave runs a branch when ANY of its lanes has it, so
+        // the slots that have the last branch are kept together (l = 832: slots 0-63 in wave 0; a slot of another class
+        // only lands in a class's half-waves when its own are full — results do not depend on the lists).
         std::vector<uint32_t> order(S);
         std::vector<uint32_t> csize(32, 0);
         for (uint32_t u = 0; u < S; ++u) ++csize[res(u, 0)];
         for (uint32_t u = 0; u < S; ++u) order[u] = u;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return csize[res(a, 0)] > csize[res(b, 0)]; });
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            const uint32_t na = branches_of(a), nb = branches_of(b);
+            return na != nb ? na > nb : csize[res(a, 0)] > csize[res(b, 0)];
+        });
+        std::vector<uint32_t> first_hw(nq + 1, 0);  // first half-wave of the slots with n branches
+        {
+            uint32_t before = 0;
+            for (uint32_t nbr = nq; nbr >= 1; --nbr) {
+                first_hw[nbr] = before / 32u;
+                for (uint32_t u = 0; u < S; ++u) before += branches_of(u) == nbr ? 1u : 0u;
+            }
+        }
         std::vector<std::vector<uint32_t>> half(NH);
         std::vector<uint32_t> hextra(static_cast<size_t>(NH) * nq, 0);
         for (uint32_t u : order) {
             uint32_t best = 0;
             uint64_t best_key = ~0ull;
-            for (uint32_t h = 0; h < NH; ++h) {
+            const uint32_t h_lo = first_hw[branches_of(u)];
+            bool room = false;
+            for (uint32_t h = h_lo; h < NH; ++h) room = room || half[h].size() < 32;
+            for (uint32_t h = room ? h_lo : 0u; h < NH; ++h) {
                 if (half[h].size() >= 32) continue;
                 uint32_t add = 0, mult = 0;
                 for (uint32_t q = 0; q < nq; ++q) {
@@ -635,9 +669,9 @@ void fused_phase_table(const TableGeom &g, uint32_t t2, uint32_t pw, const float
         std::vector<uint32_t> cp(static_cast<size_t>(g.nthr) * nq, 0u);
         for (uint32_t t = 0; t < g.nthr; ++t)
             for (uint32_t q = 0; q < nq; ++q) {
-                const uint32_t u = chosen[t] < S ? chosen[t] : 0u;
-                const uint64_t v = static_cast<uint64_t>(rb) + static_cast<uint64_t>(u + q * S) * g.m;
-                const uint64_t c = (v + l - 1) / l, ph = c * l - v;
+                const bool have = chosen[t] < S && exists(chosen[t], q);  // (else: window start 0, branch 0 — read, never stored)
+                const uint64_t v = static_cast<uint64_t>(rb) + static_cast<uint64_t>(have ? chosen[t] + q * S : 0u) * g.m;
+                const uint64_t c = have ? (v + l - 1) / l : 0u, ph = have ? c * l - v : 0u;
                 cp[static_cast<size_t>(t) * nq + q] = static_cast<uint32_t>(c) | (static_cast<uint32_t>(ph) << 16);
             }
         std::memcpy(table + g.cp_off + static_cast<size_t>(r) * g.nthr * nq, cp.data(), cp.size() * sizeof(uint32_t));
@@ -648,7 +682,8 @@ void fused_phase_table(const TableGeom &g, uint32_t t2, uint32_t pw, const float
                     for (uint32_t t = 0; t < g.nthr; ++t) {
                         const uint32_t ph = cp[static_cast<size_t>(t) * nq + q] >> 16;
                         float *dst = table + g.tt_off + (((static_cast<size_t>(r) * nq + q) * (tpp / 4) + e) * g.nthr + t) * 4;
-                        for (uint32_t k = 0; k < 4; ++k) dst[k] = chosen[t] < S ? table[static_cast<size_t>(ph) * tpp + 4 * e + k] : 0.f;
+                        const bool have = chosen[t] < S && exists(chosen[t], q);
+                        for (uint32_t k = 0; k < 4; ++k) dst[k] = have ? table[static_cast<size_t>(ph) * tpp + 4 * e + k] : 0.f;
                     }
         }
     }

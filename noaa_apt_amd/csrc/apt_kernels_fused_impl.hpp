@@ -429,7 +429,9 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         const cprm_tab_ptr tp = (cprm_tab_ptr)(prm);
         const uint32_t gl = tp->tab.l, gm_ = tp->tab.m, tpp = tp->tab.tpp;
         const uint32_t S = tp->tab.step_r, dq = tp->tab.step_q;  // stride of a branch's outputs; S*m / l input samples
-        const uint32_t SQ = NQ == 1 ? S : S / static_cast<uint32_t>(NQ);  // slots = threads with work
+        // slot stride = threads with work: thread slot u holds the slots u + q SQ that are < S (TableGeom::sq — S, S / NQ, or
+        // the workgroup's threads)
+        const uint32_t SQ = NQ == 1 ? S : tp->tab.sq;
         const uint32_t ZR = tp->tab.off_x;                        // f2 entries per region of the paired tile
         const uint32_t jl_a = tp->tab.jl_a, jl_b = tp->tab.jl_b;
         const XT *__restrict__ x = static_cast<const XT *>(call.rec[ri].x);
@@ -463,6 +465,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         const uint32_t lidx = rsel * static_cast<uint32_t>(kFusedThreads) + static_cast<uint32_t>(tid);
         const uint32_t u_slot = reinterpret_cast<const uint32_t *>(tp->table + tp->tab.perm_off)[lidx];
         const bool act = u_slot < SQ;
+        // which of the thread's slots exist (the last ones of some threads do not where SQ NQ > S: their branch is skipped
+        // by a wave none of whose lanes has it, and computed on window 0 / branch 0 and dropped by a lane beside one that has)
+        bool vq[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) vq[q] = act && (NQ == 1 || u_slot + static_cast<uint32_t>(q) * SQ < S);
         uint32_t cq[NQ], phq[NQ];
         if (exact) {
             typedef uint32_t uq __attribute__((ext_vector_type(NQ)));
@@ -482,7 +489,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         } else {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const uint32_t v = rb + ((act ? u_slot : 0u) + static_cast<uint32_t>(q) * SQ) * gm_;
+                const uint32_t v = rb + (vq[q] ? u_slot + static_cast<uint32_t>(q) * SQ : 0u) * gm_;
                 cq[q] = (v + gl - 1) / gl;
                 phq[q] = cq[q] * gl - v;
             }
@@ -602,6 +609,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         if (act) {
             static_for<0, NQ>([&](auto qq) {
             constexpr int q = decltype(qq)::value;
+            // (a slot that exists for no lane of the wave — then neither do the later ones: nothing waits for the tap
+            // segments this branch's loop would have requested)
+            if constexpr (NQ > 1) {
+                if (__builtin_amdgcn_ballot_w64(vq[q]) == 0ull) return;
+            }
             const f2 *zw[NREG];  // window of the branch's output pair (2jj, 2jj+1)
 #pragma unroll
             for (int jj = 0; jj < NREG; ++jj) zw[jj] = Z + jj * ZR + (xrel0 + cq[q]);
@@ -734,13 +746,16 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             const bool plain = interior && static_cast<uint32_t>(NST) * S <= static_cast<uint32_t>(Gm::TILE_K);
             if (plain) {
 #pragma unroll
-                for (int q = 0; q < NQ; ++q)
+                for (int q = 0; q < NQ; ++q) {
+                    if (!vq[q]) continue;
 #pragma unroll
                     for (int a = 0; a < NST; ++a)
                         P[static_cast<int>(u_slot + static_cast<uint32_t>(q) * SQ) + a * static_cast<int>(S)] = (a & 1) ? acc[q][a / 2].y : acc[q][a / 2].x;
+                }
             } else {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
+                if (!vq[q]) continue;
 #pragma unroll
                 for (int a = 0; a < NST; ++a) {
                     const int idx = static_cast<int>(u_slot + static_cast<uint32_t>(q) * SQ) + a * static_cast<int>(S);

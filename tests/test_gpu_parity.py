@@ -420,6 +420,32 @@ def test_phase_stage1_table_switches_bitexact(oracle, monkeypatch, rate, seconds
     assert_bitexact(got, want, f"phase stage 1 with {switch} at {rate} Hz, {profile}")
 
 
+@pytest.mark.parametrize("rate,seconds,profile", [
+    (11025, 30, "standard"), (22050, 20, "standard"), (8000, 30, "standard"),   # l = 832 (nq 4), 416 (2), 39 (1: untouched)
+    (13000, 25, "standard"), (9600, 25, "standard"),                               # l = 24 / 13 ... whatever the plan picks
+    (44100, 14, "fast"), (22050, 20, "fast"), (11025, 30, "fast"),                 # l = 832 (4), 1664 (8), 3328 (16)
+    (11025, 30, "slow"), (22050, 20, "slow"),                                      # streamed taps, nq 4 / 2
+])
+@pytest.mark.parametrize("balanced", ["0", "1"])
+def test_phase_stage1_slot_stride_bitexact(oracle, monkeypatch, rate, seconds, profile, balanced):
+    """TableGeom::sq both ways for every number of branches per thread: l / nq slots of nq branches each
+    (APTGPU_PHASE_BALANCED=0) and one slot per thread, 256 apart, the slots >= l missing (=1: the last branch exists for
+    some threads only — skipped by a wave none of whose lanes has it, computed on window 0 / branch 0 and dropped by a lane
+    that sits beside one that has).  The same outputs from other threads: bit-identical to the oracle either way."""
+    monkeypatch.setenv("APTGPU_PHASE_BALANCED", balanced)
+    apt.cache_clear()
+    x = synth_apt(rate, seconds, seed=rate % 79 + seconds)
+    x[x.size // 3] = np.nan  # (a non-finite sample must stay where the reference has it: no lane's garbage is ever stored)
+    s = apt.Settings.profile(profile)
+    os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                       "resample_cutout", "demodulation_atten")}
+    want = oracle.decode(x, rate, True, settings=os_)
+    got, st = apt.decode(apt.Context(device=0), s, x, apt.Rate.hz(rate), True, return_stats=True)
+    apt.cache_clear()
+    assert st.fused in (1, 2, 3, 4), (rate, profile, st.fused)
+    assert_bitexact(got, want, f"slot stride (balanced={balanced}) at {rate} Hz, {profile}")
+
+
 def test_phase_stage1_long_ragged_batched_and_pcm16(oracle):
     """Many tiles, lengths that end mid-tile / mid-group, several recordings per call, PCM16 payloads at
     odd 2-byte offsets, non-finite samples, and the fast mode's tolerance — all at 44 100 Hz."""
