@@ -143,6 +143,9 @@ void fused_branch_taps(uint32_t l, uint32_t m, const float *coeff, uint32_t t1, 
 // kModeStrictPad (mode 4 of fused_front_end): the tap-count bound of the padded strict kernel that serves (l, m, t1, t2, pw),
 // or 0 where there is none (then t1 must match a kernel exactly: fused_supported)
 uint32_t fused_pad_t1(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw);
+// kModeStrictPad2: the low-pass bound of the padded kernel when t2 is not the profile's own (a tuned demodulation_atten:
+// h2 / h2p must then be laid out for that many taps, zeros behind the filter's last), else 0
+uint32_t fused_pad_t2(uint32_t l, uint32_t m, uint32_t t2, uint32_t pw);
 int fused_chunk_of(uint32_t m, bool fast);  // window samples per stage-1 chunk of the specialised kernel for (m, strict / fast)
 // host: stage-3 tap pairs h2p[k] = (h2[k-1], h2[k]), k = 0 .. t2  (2*(t2+1) floats)
 void fused_lowpass_pairs(const float *h2, uint32_t t2, float *h2p);
@@ -206,6 +209,7 @@ struct FusedParams {
     // kModeMfma: the plain resampler taps and their count (the scalar path of tiles that hold a non-finite sample)
     const float *coeff;
     uint32_t t1;
+    uint32_t t2;            // kModeStrictPad2: the low-pass filter's own tap count (h2 / h2p are padded to kPadT2Max)
 };
 // One launch over the recordings of `call`: x -> F (slot's filtered buffer) and, if prm->want_gm, the
 // per-group maxima of the sync cross-correlation.  Returns false if no specialisation matches.

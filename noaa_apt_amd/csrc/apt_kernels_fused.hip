@@ -177,11 +177,19 @@ bool fused_fast_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint
 }
 
 // ---- kModeStrictPad: the strict SPLIT kernels compiled for a tap-count bound (apt_kernels_fused_launch.hpp)
+// kModeStrictPad2: the low-pass bound of the instantiation that serves a low-pass of t2 taps other than the profile's
+// (a tuned demodulation_atten), or 0 — the standard profile's work-rate stages at 48 / 96 kHz
+uint32_t fused_pad_t2(uint32_t l, uint32_t m, uint32_t t2, uint32_t pw)
+{
+    if (l != 13 || pw != 3 || (m != 50 && m != 100)) return 0;
+    if ((t2 & 1u) == 0 || t2 == 37 || t2 > static_cast<uint32_t>(kPadT2Max)) return 0;
+    return static_cast<uint32_t>(kPadT2Max);
+}
 uint32_t fused_pad_t1(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw)
 {
     if (l != 13 || (t1 & 1u) == 0) return 0;  // (Kaiser lengths are odd: filters.rs:164-167)
     uint32_t bound = 0;
-    if (t2 == 37 && pw == 3) bound = m == 50 ? kPadT1Max48k : m == 100 ? kPadT1Max96k : 0;           // standard profile
+    if ((t2 == 37 || fused_pad_t2(l, m, t2, pw) != 0) && pw == 3) bound = m == 50 ? kPadT1Max48k : m == 100 ? kPadT1Max96k : 0;  // standard profile
     else if (t2 == 61 && pw == 5) bound = m == 30 ? kPadT1Max48kSlow : m == 60 ? kPadT1Max96kSlow : 0;  // slow profile
     else if (t2 == 43 && pw == 4) bound = m == 75 ? kPadT1Max96kFastp : 0;                            // fast profile, 96 kHz
     return t1 <= bound ? bound : 0;
@@ -267,6 +275,10 @@ bool fused_front_end(hipStream_t s, uint32_t l, uint32_t m, uint32_t t1, uint32_
     const FusedLaunch a{s, &call, d_prm, max_w, 0, lds_pad};
     if (mode == kModeStrictPad) {
         if (fused_pad_t1(l, m, t1, t2, pw) == 0) return false;
+        if (fused_pad_t2(l, m, t2, pw) != 0) {  // the low-pass length a bound too (kModeStrictPad2)
+            if (m == 50) pcm16 ? fused_launch_48k_pad2_i16(a) : fused_launch_48k_pad2_f32(a);
+            else pcm16 ? fused_launch_96k_pad2_i16(a) : fused_launch_96k_pad2_f32(a);
+        } else
         if (m == 50) pcm16 ? fused_launch_48k_pad_i16(a) : fused_launch_48k_pad_f32(a);
         else if (m == 100) pcm16 ? fused_launch_96k_pad_i16(a) : fused_launch_96k_pad_f32(a);
         else if (m == 30) pcm16 ? fused_launch_48k_slow_pad_i16(a) : fused_launch_48k_slow_pad_f32(a);

@@ -1,0 +1,9 @@
+// apt_kernels_fused_48k_pad2_f32.hip — one instantiation of k_fused (see apt_kernels_fused_impl.hpp): the strict SPLIT kernel
+// compiled for a bound on the resampler's tap count AND on the low-pass length (kModeStrictPad2: zero-padded tables).
+#include "apt_kernels_fused_impl.hpp"
+
+namespace apt::gpu {
+
+void fused_launch_48k_pad2_f32(const FusedLaunch &a) { launch_fused_args<13, 50, kPadT1Max48k, kPadT2Max, 3, 256, kModeStrictPad2, float>(a); }
+
+}  // namespace apt::gpu

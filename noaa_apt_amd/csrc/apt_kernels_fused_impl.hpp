@@ -63,6 +63,11 @@ namespace {
 #ifndef APT_MFMA_WAVES
 #define APT_MFMA_WAVES 4
 #endif
+// waves per SIMD the kModeStrictPad2 kernels are compiled for (the 45-tap low-pass's window does not fit the 80 registers
+// of six: eleven of them spilled inside stage 3)
+#ifndef APT_PAD2_WAVES
+#define APT_PAD2_WAVES 5
+#endif
 // Halo threads of a tile (FusedGeom::kPreThreads / kPostThreads).  The low-pass and the envelope need T2 + 1 = 38 work
 // samples of history, the correlation G - 1 = 113 of look-ahead: 3 + 9 threads of 13 samples in the specialised
 // kernels (round 2: 4 + 12 — a whole group of four either side; 244 instead of 240 of 256 threads own samples, 116
@@ -163,7 +168,10 @@ struct FusedGeom {
     static constexpr int AB_OFF = COMPACT4 ? (((OWN_K / (4 * L) + 2) * 12 + 3) & ~3) : D_OFF + Q_FLOATS;
     static_assert(!COMPACT4 || AB_OFF + NTHR + 8 <= D_OFF, "|F| sums and partial maxima both fit the dead F region");
     static constexpr int W_LDS_FLOATS = D_OFF + Q_FLOATS + (COMPACT4 ? 0 : NTHR);  // what the work-rate stages need
-    static constexpr int LDS_FLOATS = XT_LDS > W_LDS_FLOATS ? XT_LDS : W_LDS_FLOATS;
+    // (PAD: the word of kModeStrictPad2's "F not all finite" flag behind BOTH regions — it is cleared while sub-tile 0 lies
+    // in LDS and read after stage 3)
+    static constexpr int LP_FLAG_OFF = XT_LDS > W_LDS_FLOATS ? XT_LDS : W_LDS_FLOATS;
+    static constexpr int LDS_FLOATS = LP_FLAG_OFF + (PAD ? 4 : 0);
     // workgroups a CU's 160 KB of LDS hold (the specialised kernels' occupancy; at most 8 waves per SIMD)
     static constexpr int WGS_PER_CU_LDS = TABLE ? 2 : (160 * 1024) / (LDS_FLOATS * 4);
     static constexpr int WGS_PER_CU = WGS_PER_CU_LDS * NTHR > 8 * 256 ? (8 * 256) / NTHR : WGS_PER_CU_LDS;
@@ -257,6 +265,8 @@ __global__ void __launch_bounds__(NTHR, M < 0 ? ((NTHR > 512 ? 1 : NTHR > 256 ? 
                                      : M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
                                                /* specialised: as many workgroups as the CU's 160 KB of LDS hold (48 kHz SPLIT: 5, 96 kHz: 3) */
                                                : MODE == kModeMfma ? APT_MFMA_WAVES
+                                               : MODE == kModeStrictPad2 ? (FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), 3>::WGS_PER_CU < APT_PAD2_WAVES
+                                                                                ? FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), 3>::WGS_PER_CU : APT_PAD2_WAVES)
                                                : (FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), fused_geom_var(MODE)>::WGS_PER_CU * NTHR + 255) / 256)
 k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 {
@@ -276,7 +286,8 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     constexpr int kOwnThreads = Gm::kOwnThreads, kPreThreads = Gm::kPreThreads, kPostThreads = Gm::kPostThreads;
     constexpr bool F16 = MODE == kModeF16Taps;
     constexpr bool MFMA = MODE == kModeMfma;         // the FIRs on the matrix cores; everything else as kModeFast
-    constexpr bool PAD = MODE == kModeStrictPad;     // strict arithmetic, T1 a bound (zero-padded table)
+    constexpr bool PADLP = MODE == kModeStrictPad2;  // ... and T2 a bound too (zero-padded low-pass tables)
+    constexpr bool PAD = MODE == kModeStrictPad || PADLP;  // strict arithmetic, T1 a bound (zero-padded table)
     constexpr bool FAST = MODE == kModeFast || MFMA;
     extern __shared__ float lds[];
     float *P = lds;                  // x tile -> R -> F
@@ -1350,6 +1361,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         if constexpr (PAD && sizeof(XT) == 4) {
             if (tid == 0) *pad_flag = 0u;
         }
+        // kModeStrictPad2: "this tile's F values are not all finite" (a word behind everything else in LDS; set after
+        // stage 3, read behind the barrier that follows it)
+        if constexpr (PADLP && sizeof(XT) == 4) {
+            if (tid == 0) reinterpret_cast<uint32_t *>(lds)[Gm::LP_FLAG_OFF] = 0u;
+        }
         // sub-tile 0 is in LDS; sub-tile 1's loads are in flight under its stage 1
         XReg xr1[NXR];
         load_tile(ri, tile, 1, xr1);
@@ -1702,7 +1718,37 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     APT_MARK("BEGIN f_to_lds");
 #pragma unroll
     for (int b = 0; b < L; ++b) P[tid * L + b] = f[b];  // R is dead: P now holds F
+    if constexpr (PADLP && sizeof(XT) == 4) {
+        // 0 * inf / 0 * NaN behind the low-pass's last tap (the reference stops at it): any non-finite F of a thread whose
+        // window lies inside the tile sends the tile to the run-time loop below.  (PCM16 input: the envelope is finite.)
+        float chk = 0.f;
+#pragma unroll
+        for (int b = 0; b < L; ++b) chk = chk + f[b];
+        if (tid >= kPreThreads && (__float_as_uint(chk) & 0x7F800000u) == 0x7F800000u)
+            reinterpret_cast<uint32_t *>(lds)[Gm::LP_FLAG_OFF] = 1u;
+    }
     __syncthreads();
+    if constexpr (PADLP && sizeof(XT) == 4) {
+        if (reinterpret_cast<const uint32_t *>(lds)[Gm::LP_FLAG_OFF] != 0u) {
+            // (workgroup-uniform; never on recordings) the reference's loop over the filter's own taps (dsp.rs:396-404),
+            // from D, which still lies in Q
+            const uint32_t t2r = late->t2;
+#pragma unroll
+            for (int b = 0; b < L; ++b) f[b] = 0.f;
+#pragma unroll 1
+            for (uint32_t j = 0; j < t2r; ++j) {
+                const float hj = h2[j];
+#pragma unroll
+                for (int b = 0; b < L; ++b) {
+                    const int qi = tid * L + b - static_cast<int>(j);
+                    if (kt + b > static_cast<int>(j) && qi >= 0) f[b] = f[b] + Q[qi] * hj;
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < L; ++b) P[tid * L + b] = f[b];
+            __syncthreads();
+        }
+    }
     APT_MARK("END f_to_lds");
     if constexpr (APT_FUSED_STOP == 4) return;
     // owned F -> HBM, coalesced 16-byte stores

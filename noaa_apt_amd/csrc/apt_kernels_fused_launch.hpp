@@ -28,8 +28,19 @@ constexpr int kModeMfma = 3;
 // again sample by sample from HBM, in the reference's order.  default_settings.toml:108-140 is a user-editable file:
 // a tuned resample_atten / resample_delta_freq changes the tap count, and until round 6 such a plan fell to k_fused_any.
 constexpr int kModeStrictPad = 4;
+// kModeStrictPad2 (round 6): kModeStrictPad whose LOW-PASS length is a bound too (T2 = kPadT2Max: h2 / h2p hold zeros behind
+// the filter's last tap — the taps an output meets last, since stage 3 walks them in ascending order — and a tile whose F
+// values are not all finite is filtered again from D in LDS with the run-time tap count).  demodulation_atten is as
+// user-editable as the resampler's settings (default_settings.toml:116) and moves the Kaiser length of the low-pass
+// (25 dB: 37 taps; 24: 35; 26: 39): until this mode such a plan fell to k_fused_any, 7 x the stock step at 48 kHz.
+constexpr int kModeStrictPad2 = 5;
+// low-pass taps the kModeStrictPad2 instantiations are compiled for (standard profile; four pre-halo threads hold up to 51)
+constexpr int kPadT2Max = 45;
 // FusedGeom's variant argument for a mode
-constexpr int fused_geom_var(int mode) { return mode == kModeF16Taps ? 1 : mode == kModeMfma ? 2 : mode == kModeStrictPad ? 3 : 0; }
+constexpr int fused_geom_var(int mode)
+{
+    return mode == kModeF16Taps ? 1 : mode == kModeMfma ? 2 : (mode == kModeStrictPad || mode == kModeStrictPad2) ? 3 : 0;
+}
 // tap counts the padded strict instantiations are compiled for, about an eighth above the stock profiles' counts
 // (standard 48 / 96 kHz: 83 / 165 taps per branch, stock 74 / 148; slow 48 / 96 kHz: 241 / 481, stock 215 / 429; fast
 // profile at 96 kHz: 56, stock 50)
@@ -113,6 +124,11 @@ void fused_launch_48k_slow_pad_i16(const FusedLaunch &a);
 void fused_launch_96k_slow_pad_f32(const FusedLaunch &a);
 void fused_launch_96k_slow_pad_i16(const FusedLaunch &a);
 void fused_launch_96k_fastp_pad_f32(const FusedLaunch &a);  // (odd m: f32 input only, as the exact-count kernel)
+// ... and any low-pass length up to kPadT2Max as well (kModeStrictPad2): 48 / 96 kHz, standard profile
+void fused_launch_48k_pad2_f32(const FusedLaunch &a);
+void fused_launch_48k_pad2_i16(const FusedLaunch &a);
+void fused_launch_96k_pad2_f32(const FusedLaunch &a);
+void fused_launch_96k_pad2_i16(const FusedLaunch &a);
 // 48 kHz at the slow profile (13 / 30, 2783 taps; 61-tap low-pass, pixel width 5): the same SPLIT form
 void fused_launch_48k_slow_f32(const FusedLaunch &a);
 void fused_launch_48k_slow_i16(const FusedLaunch &a);

@@ -271,9 +271,11 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         const uint32_t pad_t1 = (eligible && !no_spec && !mfma_ok && (pad_env ? pad_env[0] == '1' : !exact))
                                     ? gpu::fused_pad_t1(plan->l, plan->m, t1, t2, plan->pw) : 0u;
         plan->fused_pad_t1 = 0;
+        plan->fused_pad_t2 = 0;
         if (eligible && (exact || mfma_ok || pad_t1 != 0) && !no_spec) {
             plan->fused = 1;
             plan->fused_pad_t1 = pad_t1;
+            plan->fused_pad_t2 = pad_t1 ? gpu::fused_pad_t2(plan->l, plan->m, t2, plan->pw) : 0u;  // (a tuned demodulation_atten)
         }
         // (where both the table-driven and the phase-resident stage 1 exist, the latter: since round 5 — thread assignment
         // lists, interior tile loads, pipelined taps, two / four branches per thread — it is the faster one at every rate
@@ -298,7 +300,7 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
             if (!(q && q[0] == '1') && !told.exchange(true))
                 std::fprintf(stderr,
                              "aptgpu: %u -> %u Hz with %u resample / %u low-pass taps has no compile-time specialised front end "
-                             "(those exist for up to 1079 / 2145 resample taps and 37 low-pass taps at 48 / 96 kHz); using kernel path %d "
+                             "(those exist for up to 1079 / 2145 resample taps and up to 45 low-pass taps at 48 / 96 kHz); using kernel path %d "
                              "(same results, lower throughput)\n",
                              plan->input_rate, plan->settings.work_rate, t1, t2, plan->fused);
         }
@@ -368,9 +370,16 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
             gpu::fused_branch_taps(plan->l, plan->m, plan->taps_resample.data(), t1, ch, hs.data(), t1_layout);
         }
         upload(plan->d_taps_branch, hs);
-        Signal h2p(2 * (plan->taps_lowpass.size() + 1) + 16, 0.f);
-        gpu::fused_lowpass_pairs(plan->taps_lowpass.data(), static_cast<uint32_t>(plan->taps_lowpass.size()),
-                                 h2p.data());
+        // (kModeStrictPad2: the low-pass tables laid out for the kernel's bound, zeros behind the filter's last tap)
+        Signal lp(plan->taps_lowpass);
+        if (plan->fused_pad_t2) {
+            lp.resize(plan->fused_pad_t2, 0.f);
+            Signal padded(lp);
+            padded.resize(lp.size() + 16, 0.f);
+            upload(plan->d_taps_lowpass_pad, padded);
+        }
+        Signal h2p(2 * (lp.size() + 1) + 16, 0.f);
+        gpu::fused_lowpass_pairs(lp.data(), static_cast<uint32_t>(lp.size()), h2p.data());
         upload(plan->d_taps_lowpass_pairs, h2p);
     }
 
@@ -437,8 +446,9 @@ void aptgpu_plan::upload_slot_table()
         prm.hs = d_taps_branch.ptr;
         prm.table = d_taps_any.ptr;
         prm.tab = table_geom;
-        prm.h2 = d_taps_lowpass.ptr;
+        prm.h2 = fused_pad_t2 ? d_taps_lowpass_pad.ptr : d_taps_lowpass.ptr;
         prm.h2p = d_taps_lowpass_pairs.ptr;
+        prm.t2 = static_cast<uint32_t>(taps_lowpass.size());
         prm.slots = d_slots.ptr;
         prm.cosphi2 = cosphi2;
         prm.sinphi = sinphi;

@@ -153,6 +153,7 @@ struct aptgpu_plan {
     bool fused_fast = false;  // APTGPU_MODE_FAST served by the specialised fused kernel
     bool fused_mfma = false;  // ... by its matrix-core form (kModeMfma: tuned tap counts, or APTGPU_FAST_MFMA=1)
     uint32_t fused_pad_t1 = 0;  // != 0: the strict kernel compiled for this tap-count bound serves the plan (kModeStrictPad)
+    uint32_t fused_pad_t2 = 0;  // != 0: ... and for this low-pass bound (kModeStrictPad2: d_taps_lowpass_pad, FusedParams::t2)
     // 0 unfused generic kernels, 1 compile-time specialised k_fused, 2 run-time k_fused_any,
     // 3 k_fused with the table-driven stage 1 (run-time l / m / taps, specialised work-rate stages)
     int fused = 0;
@@ -160,7 +161,7 @@ struct aptgpu_plan {
     apt::gpu::LaunchSwitches sw{};  // the A/B switches of the launch wrappers as the environment had them at plan creation
     int picker_force = 0;  // 0 parallel picker; APTGPU_FORCE_WALK=1 -> 1 (the sequential fallback)
 
-    apt::DeviceBuffer<float> d_taps_resample, d_taps_lowpass, d_one, d_taps_branch, d_taps_lowpass_pairs, d_taps_any;
+    apt::DeviceBuffer<float> d_taps_resample, d_taps_lowpass, d_one, d_taps_branch, d_taps_lowpass_pairs, d_taps_any, d_taps_lowpass_pad;
     apt::DeviceBuffer<uint16_t> d_taps_f16;  // APTGPU_MODE_FP16_TAPS
     float f16_unscale = 1.f;
     struct Slot {

@@ -1092,6 +1092,87 @@ def test_padded_kernel_on_the_stock_tap_counts_and_non_finite_samples(oracle, mo
     apt.cache_clear()
 
 
+# ------------------------------------------------------------------ a tuned demodulation_atten (kModeStrictPad2)
+DEMOD_TUNED = [(48000, dict(demodulation_atten=20.0)), (48000, dict(demodulation_atten=24.0)),
+               (48000, dict(demodulation_atten=26.0)), (48000, dict(demodulation_atten=27.5)),
+               (48000, dict(demodulation_atten=29.0)), (96000, dict(demodulation_atten=24.0)),
+               (96000, dict(demodulation_atten=28.0)), (48000, dict(demodulation_atten=26.0, resample_atten=31.0)),
+               (96000, dict(demodulation_atten=23.0, resample_delta_freq=1100.0))]
+
+
+@pytest.mark.parametrize("rate,kw", DEMOD_TUNED)
+@pytest.mark.parametrize("sync", [True, False])
+def test_tuned_demodulation_atten_stays_on_the_specialised_kernel(ctx, oracle, rate, kw, sync):
+    """demodulation_atten (default_settings.toml:116) moves the Kaiser length of the LOW-PASS (25 dB: 37 taps): such a plan
+    runs the padded strict kernel whose low-pass length is a bound too (kModeStrictPad2: up to 45 taps, zero-padded h2 /
+    h2p) — stats.fused == 1, bit-exact, alone or together with a tuned resampler (until this round: k_fused_any)."""
+    s = apt.Settings(**kw)
+    os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                       "resample_cutout", "demodulation_atten")}
+    x = synth_apt(rate, 12, seed=57)
+    want, st = oracle.decode(x, rate, sync, settings=os_, want_steps=True)
+    got, stats = apt.decode(ctx, s, x, apt.Rate.hz(rate), sync, return_stats=True)
+    assert stats.n_lowpass_taps == st["filter_filter"].size and stats.n_lowpass_taps != 37 and stats.n_lowpass_taps <= 45
+    assert stats.fused == 1, (rate, kw, stats.n_resample_taps, stats.n_lowpass_taps)
+    assert_bitexact(got, want, f"tuned {rate} {kw} sync={sync}")
+
+
+def test_tuned_demodulation_atten_non_finite_samples_pcm16_and_the_bound(oracle):
+    """kModeStrictPad2 where a zero tap of the padded low-pass meets a non-finite envelope value (0 x inf = NaN where the
+    reference, whose filter ends before it, has none: such a tile is filtered again with the run-time tap count); from the
+    first samples of a recording (the `i > j` guard of dsp.rs:396-404 with fewer taps than the kernel's bound); PCM16
+    input; several recordings per call; and a low-pass longer than the bound (47 taps: k_fused_any, same results)."""
+    c = apt.Context(device=0)
+    s = apt.Settings(demodulation_atten=24.0)
+    os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                       "resample_cutout", "demodulation_atten")}
+    for rate in (48000, 96000):
+        x = synth_apt(rate, 12, seed=58)
+        for bad in (np.nan, np.inf, -np.inf):
+            y = x.copy()
+            for i in (0, 5, 77777, 200001, 200002, y.size - 3):
+                y[i] = bad
+            y[300000:300400] = bad
+            for sync in (True, False):
+                try:
+                    want = oracle.decode(y, rate, sync, settings=os_)
+                except oracle.OracleError as e:
+                    with pytest.raises(apt.AptError) as ge:
+                        apt.decode(c, s, y, apt.Rate.hz(rate), sync)
+                    assert str(ge.value) == str(e)
+                    continue
+                got, stats = apt.decode(c, s, y, apt.Rate.hz(rate), sync, return_stats=True)
+                assert stats.fused == 1 and stats.n_lowpass_taps == 35
+                assert_same_values(got, want, f"padded low-pass {rate} {bad} sync={sync}")
+        # amplitudes whose F overflows: the same infinities, through the run-time loop
+        z = (x * np.float32(3e33)).astype(np.float32)
+        assert_same_values(apt.decode(c, s, z, apt.Rate.hz(rate), True), oracle.decode(z, rate, True, settings=os_),
+                           f"padded low-pass {rate}, overflow")
+    # PCM16 payloads, three recordings of different lengths in one call
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    recs = [synth_apt(48000, 12, seed=59), synth_apt(48000, 31, seed=60)[:48000 * 31 - 7], synth_apt(48000, 9, seed=61)]
+    plan = apt.Plan(s, apt.Rate.hz(48000), True, max_samples=max(r.size for r in recs), max_batch=3)
+    assert plan.info.fused == 1 and plan.info.n_lowpass_taps == 35
+    d_pcm = [torch.from_numpy(r.astype(np.int16)).to(dev) for r in recs]
+    cap = int(plan.info.max_rows)
+    d_out = [torch.empty(cap * 2080, dtype=torch.float32, device=dev) for _ in recs]
+    torch.cuda.synchronize()
+    specs = [apt.WavSpec(1, 16, 2, 0, 48000, 1, 0, 2 * r.size, r.size, r.size) for r in recs]
+    plan.decode_device_wav([d.data_ptr() for d in d_pcm], specs, [d.data_ptr() for d in d_out], [cap] * 3)
+    for i, (r, res) in enumerate(zip(recs, plan.results(3))):
+        assert_bitexact(d_out[i][:res.n_out].cpu().numpy(), oracle.decode(r, 48000, True, settings=os_), f"padded low-pass, PCM16 {i}")
+    plan.close()
+    # beyond the bound
+    s2 = apt.Settings(demodulation_atten=30.0)
+    os2 = dict(os_, demodulation_atten=30.0)
+    x = synth_apt(48000, 12, seed=62)
+    got, stats = apt.decode(c, s2, x, apt.Rate.hz(48000), True, return_stats=True)
+    assert stats.n_lowpass_taps > 45 and stats.fused == 2
+    assert_bitexact(got, oracle.decode(x, 48000, True, settings=os2), "low-pass beyond the padded kernel's bound")
+    apt.cache_clear()
+
+
 def _random_tunings(n, seed):
     rng = np.random.default_rng(seed)
     out = []
