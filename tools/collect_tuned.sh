@@ -17,8 +17,8 @@ import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     w = d["config"]["workload"]
-    taps = w[w.index("resample"):].split("->")[0].strip()
-    print(f"{sys.argv[2]:28s} {taps:28s} ms/step {d['ms_per_step']:.4f}  front end alone {d['roofline']['kernel_avg_ms']:.4f} ms  frac {d['roofline']['frac']:.4f}  parity: {str(d.get('parity'))[:60]}")
+    taps = w[w.index("resample"):w.index("low-pass") + 8].replace("-> AM envelope -> ", "/ ") if "resample" in w else ""
+    print(f"{sys.argv[2]:28s} {taps:46s} ms/step {d['ms_per_step']:.4f}  front end alone {d['roofline']['kernel_avg_ms']:.4f} ms  frac {d['roofline']['frac']:.4f}  parity: {str(d.get('parity'))[:60]}")
 except Exception as e:
     print(sys.argv[2], "FAILED", e)
 PY
@@ -28,6 +28,12 @@ for kv in resample_atten=29 resample_atten=31 resample_delta_freq=900 resample_d
   run ${kv}_pad APTGPU_QUIET=1 -- --set $kv
   run ${kv}_any APTGPU_QUIET=1 APTGPU_FUSED_PAD=0 -- --set $kv
 done
+# a tuned demodulation_atten moves the LOW-PASS length (37 taps at 25 dB): kModeStrictPad2 against k_fused_any
+for kv in demodulation_atten=24 demodulation_atten=26 demodulation_atten=29; do
+  run ${kv}_pad2 APTGPU_QUIET=1 -- --set $kv
+  run ${kv}_any APTGPU_QUIET=1 APTGPU_FUSED_PAD=0 -- --set $kv
+done
+run atten31_demod26_pad2 APTGPU_QUIET=1 -- --set resample_atten=31 --set demodulation_atten=26
 run fast_stock APTGPU_QUIET=1 -- --mode fast
 run fast_atten31_mfma APTGPU_QUIET=1 -- --mode fast --set resample_atten=31
 run fast_atten31_any APTGPU_QUIET=1 APTGPU_FAST_MFMA=0 APTGPU_FUSED_PAD=0 -- --mode fast --set resample_atten=31
