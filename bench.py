@@ -319,6 +319,11 @@ def main():
         if dist is not None:
             dist.barrier(group=cpu_group) if cpu_group is not None else dist.barrier()
 
+    # (the group's first collective sets its connections up — milliseconds; done here, not between the warm-up's
+    # synchronize and t0, where the GPU would sit drained meanwhile: see the SMU snapshot below)
+    job_barrier()
+    job_barrier()
+
     settings = tuned_settings(apt, args)
     rate = apt.Rate.hz(args.rate)
 

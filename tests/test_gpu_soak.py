@@ -176,3 +176,44 @@ def test_soak_decode_batch_against_oracle(oracle, seed):
     print("\nsoak-batch " + json.dumps({"seed": seed, "batches": batches, "recordings": n_rec, "mismatches": len(bad),
                                         "errors_that_matched": n_err, "seconds": round(time.perf_counter() - t0, 1)}), flush=True)
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("seed", [21])
+def test_soak_fast_mode_within_its_tolerance(oracle, seed):
+    """APTGPU_MODE_FAST over the same draw of rates and Settings (finite signals: synthetic APT, the kinds whose sync
+    positions are well defined): SURVEY.md 8(d)'s tolerance — same row count, sync positions identical on >= 99.9 % of the
+    rows and never off by more than one sample, |d px| <= 1e-4 max |px| on rows with identical position — whatever kernel
+    the plan lands on (the fast instantiations, the matrix-core kernel for tuned tap counts, strict kernels elsewhere)."""
+    from test_gpu_fast import check_tolerance, decode_on_plan
+    cases = max(4, int(os.environ.get("APT_SOAK_CASES", "40")) // 2)
+    rng = np.random.default_rng(seed)
+    t0 = time.perf_counter()
+    bad, worst, done, paths = [], 0.0, 0, {}
+    for i in range(cases):
+        c = draw_case(rng)
+        c["kind"], c["sync"] = "apt", True
+        c["seconds"] = max(c["seconds"], 9.0)
+        x = make_signal(c, synth_apt)
+        s = apt.Settings.profile(c["profile"]) if c["profile"] else apt.Settings(**c["settings"])
+        os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq", "resample_cutout",
+                                          "demodulation_atten")}
+        try:
+            want, st = oracle.decode(x, c["rate"], True, settings=os_, want_steps=True)
+        except Exception:  # noqa: BLE001 - too short / rate overflow / work_rate: the strict soak compares the errors
+            continue
+        try:
+            rows, pos, res, fused = decode_on_plan(x, c["rate"], apt.MODE_FAST, settings=s)
+            assert res.status == 0, (res.status, res.reason)
+            _, err = check_tolerance(rows, pos, want, st["sync_pos"], f"seed {seed} case {i}")
+            worst = max(worst, err)
+            paths[fused] = paths.get(fused, 0) + 1
+            done += 1
+        except AssertionError as e:
+            bad.append(f"seed {seed} case {i}: {json.dumps(c)} n={x.size}: {e}")
+        if (i + 1) % 50 == 0:
+            apt.cache_clear()
+    apt.cache_clear()
+    print("\nsoak-fast " + json.dumps({"seed": seed, "cases": done, "out_of_tolerance": len(bad), "worst_px_error_of_full_scale": worst,
+                                       "kernel_paths_stats_fused": dict(sorted(paths.items())),
+                                       "seconds": round(time.perf_counter() - t0, 1)}), flush=True)
+    assert not bad, "\n".join(bad)
