@@ -708,7 +708,10 @@ bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, uint32_t t2, ui
     if (pcm16)
         for (uint32_t i = 0; i < call.count; ++i)
             if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 1u) return false;
-    const FusedLaunch a{s, &call, d_prm, max_w, static_cast<size_t>(geom.xt)};
+    // (one branch per thread: the kernel takes the paired tile through LDS in two halves — apt_kernels_fused_launch.hpp)
+    const bool halves = phase_halves(static_cast<int>(geom.nq ? geom.nq : 1u), geom.stream != 0, static_cast<int>(geom.nthr),
+                                     static_cast<int>(t2), mode == kModeFast);
+    const FusedLaunch a{s, &call, d_prm, max_w, static_cast<size_t>(halves ? geom.xt / 2 : geom.xt)};
     const bool wide = geom.nthr == 512, huge = geom.nthr == 1024;
     if (t2 == 61 && pw == 5) {  // the slow profile's work-rate stages, streamed taps (strict instantiations only: they serve fast mode too)
         if (wide || huge || !geom.stream) return false;

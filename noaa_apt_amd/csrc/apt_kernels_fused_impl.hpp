@@ -261,7 +261,7 @@ __host__ __device__ constexpr bool sync_plus(int j)
 // that walked the tiles with a fixed grid and kept the NEXT tile's input in registers while the stages ran was measured
 // in rounds 2 and 3 and dropped: slower in every mode)
 template <int L, int M, int T1, int T2, int PW, int NTHR, typename XT, int MODE>
-__global__ void __launch_bounds__(NTHR, M < 0 ? ((NTHR > 512 ? 1 : NTHR > 256 ? 2 : (T1 == 1 ? (M == -1 ? 3 : 4) : T2 == 43 ? 4 : M == -4 ? 5 : M == -2 ? 5 : 3)) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs; the fast profile's and the streamed forms with several branches: four, <= 128; two or four branches per thread at the standard profile: five, <= 96), two 512-thread or one 1024-thread (<= 128) workgroups per CU */
+__global__ void __launch_bounds__(NTHR, M < 0 ? ((NTHR > 512 ? 1 : NTHR > 256 ? 2 : (T1 == 1 ? (M == -1 ? 3 : 4) : phase_halves(-M, false, NTHR, T2, MODE == kModeFast) ? (MODE == kModeFast ? 4 : 5) : T2 == 43 ? 4 : M == -4 ? 5 : M == -2 ? 5 : 3)) * NTHR + 255) / 256  /* phase mode: three 256-thread (<= 170 VGPRs; the fast profile's and the streamed forms with several branches: four, <= 128; two or four branches per thread at the standard profile: five, <= 96), two 512-thread or one 1024-thread (<= 128) workgroups per CU */
                                      : M == 0 ? (2 * NTHR + 255) / 256  /* table mode: two workgroups per CU */
                                                /* specialised: as many workgroups as the CU's 160 KB of LDS hold (48 kHz SPLIT: 5, 96 kHz: 3) */
                                                : MODE == kModeMfma ? APT_MFMA_WAVES
@@ -511,16 +511,24 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         // pair (two 4-byte reads would be merged by the compiler with their NEIGHBOURS in the window, and
         // the pairs rebuilt with a v_mov per sample).  The windows' overlap (~10 % at NQ = 1) is stored twice.
         f2 *Z = reinterpret_cast<f2 *>(lds);
-        {
-            // every load of the tile issued before the first LDS write (regions x rounds unrolled: a loop
-            // that waited for each round's loads cost 26 HBM latencies per tile)
-            // ceil(ZR / NTHR) at most (phase_geom: ZR <= 1024; the fast profile's long periods — 44 100 Hz: m = 2205 — 2304,
-            // with one or two regions only)
-            constexpr int ZROUNDS = (T2 == 43 && NQ > 2) ? 9 : 1024 / kFusedThreads;
-            const XT *xt0 = x + xs0;    // only dereferenced inside [x_lo, x_hi)
-            const int x_lo = rel(-xs0), x_hi = rel(n - xs0);
-            XT za[NREG][ZROUNDS], zb[NREG][ZROUNDS];
-            if (x_lo <= 0 && x_hi >= static_cast<int>((HALF ? 0 : NWIN - 1) * dq + ZR)) {
+        // One branch per thread (HALVES): the tile goes through LDS in two passes of NREG / 2 regions — windows 0-7, then 8-15
+        // — so that the work-rate stages' 26 KB, not the 45-52 KB of sixteen windows' input, set the footprint (three
+        // workgroups per CU until round 6); the taps stay in their registers across both passes.
+        constexpr bool HALVES = phase_halves(NQ, STREAM, NTHR, T2, FAST);
+        constexpr int NPASS = HALVES ? 2 : 1, RPP = NREG / NPASS;  // passes; regions per pass
+        static_assert(!HALVES || NREG % 2 == 0, "two passes of whole regions");
+        // every load of a pass issued before its first LDS write (regions x rounds unrolled: a loop
+        // that waited for each round's loads cost 26 HBM latencies per tile)
+        // ceil(ZR / NTHR) at most (phase_geom: ZR <= 1024; the fast profile's long periods — 44 100 Hz: m = 2205 — 2304,
+        // with one or two regions only)
+        constexpr int ZROUNDS = (T2 == 43 && NQ > 2) ? 9 : 1024 / kFusedThreads;
+        const XT *xt0 = x + xs0;    // only dereferenced inside [x_lo, x_hi)
+        const int x_lo = rel(-xs0), x_hi = rel(n - xs0);
+        const bool x_interior = x_lo <= 0 && x_hi >= static_cast<int>((HALF ? 0 : NWIN - 1) * dq + ZR);
+        auto load_pass = [&](auto pp) {
+            constexpr int J0 = decltype(pp)::value * RPP;  // first region of the pass
+            XT za[RPP][ZROUNDS], zb[RPP][ZROUNDS];
+            if (x_interior) {
                 // interior tile (wave-uniform): every sample exists.  A scalar base per region half, advanced in scalar
                 // registers (the empty asm keeps the steps from being folded into per-lane 64-bit adds, as in load_tile),
                 // plus the lane's 32-bit byte offset — the guarded form below spends ten VALU instructions per sample
@@ -533,7 +541,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                     const uint32_t s_in = static_cast<uint32_t>(tid + rr * kFusedThreads);
                     const uint32_t voff = s_in * static_cast<uint32_t>(sizeof(XT));
 #pragma unroll
-                    for (int jj = 0; jj < NREG; ++jj) {
+                    for (int jj = 0; jj < RPP; ++jj) {
                         za[jj][rr] = XT(0);
                         zb[jj][rr] = XT(0);
                     }
@@ -545,8 +553,12 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                         const uint32_t xa_hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(xa >> 32))));
                         const uint64_t xu = static_cast<uint64_t>(xa_lo) | (static_cast<uint64_t>(xa_hi) << 32);
                         gchar_ptr sb = (gchar_ptr)(xu);
+                        if constexpr (J0 > 0) {
+                            sb += static_cast<uint64_t>(2 * J0) * dqb;
+                            asm volatile("" : "+s"(sb));
+                        }
 #pragma unroll
-                        for (int jj = 0; jj < NREG; ++jj) {
+                        for (int jj = 0; jj < RPP; ++jj) {
                             za[jj][rr] = *(gx_ptr)(sb + voff);
                             sb += dqb;
                             asm volatile("" : "+s"(sb));
@@ -558,11 +570,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 }
             } else {
 #pragma unroll
-            for (int jj = 0; jj < NREG; ++jj) {
+            for (int jj = 0; jj < RPP; ++jj) {
 #pragma unroll
                 for (int rr = 0; rr < ZROUNDS; ++rr) {
                     const uint32_t s_in = static_cast<uint32_t>(tid + rr * kFusedThreads);
-                    const int ia = static_cast<int>(static_cast<uint32_t>(2 * jj) * dq + s_in);
+                    const int ia = static_cast<int>(static_cast<uint32_t>(2 * (J0 + jj)) * dq + s_in);
                     const int ib = ia + static_cast<int>(dq);
                     za[jj][rr] = (s_in < ZR && ia >= x_lo && ia < x_hi) ? xt0[ia] : XT(0);
                     zb[jj][rr] = (!HALF && s_in < ZR && ib >= x_lo && ib < x_hi) ? xt0[ib] : XT(0);
@@ -570,14 +582,15 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             }
             }
 #pragma unroll
-            for (int jj = 0; jj < NREG; ++jj) {
+            for (int jj = 0; jj < RPP; ++jj) {
 #pragma unroll
                 for (int rr = 0; rr < ZROUNDS; ++rr) {
                     const uint32_t s_in = static_cast<uint32_t>(tid + rr * kFusedThreads);
                     if (s_in < ZR) Z[jj * ZR + s_in] = (f2){static_cast<float>(za[jj][rr]), static_cast<float>(zb[jj][rr])};
                 }
             }
-        }
+        };
+        load_pass(std::integral_constant<int, 0>{});
         // its taps -> registers (16-byte loads from the L2-resident table; the first ones in flight across the barrier).
         // The branches are worked through one after the other.
         typedef float f4v __attribute__((ext_vector_type(4)));
@@ -585,7 +598,10 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         // next is requested when a segment has been used up.  One branch per thread: the whole branch is one segment,
         // loaded before the first multiplication (one buffer).  Two branches (tpp <= 36): segments of 20 taps — 40
         // registers where both branches' rows took 72.  Four / eight: a branch per segment.
-        constexpr int SEG = NQ == 2 ? 20 : TPPM;
+        // (round 6, HALVES with a long filter — 44 100 Hz at the standard profile, 68 taps: segments of 20 as well, fetched
+        // again for the second pass; a resident branch, 76 registers, left no room for the second pass's loads at four waves
+        // per SIMD: 228 registers spilled)
+        constexpr int SEG = (NQ == 2 || (HALVES && TPPM > 40)) ? 20 : TPPM;
         constexpr int SPB = (TPPM + SEG - 1) / SEG;      // segments per branch
         constexpr int NSEG = NQ * SPB;
         constexpr int NTB = NSEG > 1 ? 2 : 1;
@@ -617,6 +633,8 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int jj = 0; jj < NREG; ++jj) acc[q][jj] = (f2){0.f, 0.f};
+        auto compute_pass = [&](auto pp) {
+        constexpr int J0 = decltype(pp)::value * RPP;  // first region (= output pair) of the pass
         if (act) {
             static_for<0, NQ>([&](auto qq) {
             constexpr int q = decltype(qq)::value;
@@ -625,13 +643,13 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             if constexpr (NQ > 1) {
                 if (__builtin_amdgcn_ballot_w64(vq[q]) == 0ull) return;
             }
-            const f2 *zw[NREG];  // window of the branch's output pair (2jj, 2jj+1)
+            const f2 *zw[RPP];  // window of the branch's output pair (2jj, 2jj+1)
 #pragma unroll
-            for (int jj = 0; jj < NREG; ++jj) zw[jj] = Z + jj * ZR + (xrel0 + cq[q]);
+            for (int jj = 0; jj < RPP; ++jj) zw[jj] = Z + jj * ZR + (xrel0 + cq[q]);
             // Software pipeline over the taps: the 8-byte reads of tap i + 1 are issued before the arithmetic of tap i
             // (until round 5 a chunk's reads were issued and waited for in place: one exposed LDS latency per two taps, at
-            // three waves per SIMD).  Two buffers of NREG pairs (NQ = 1: the same registers a two-tap chunk held).
-            f2 xb[2][NREG];
+            // three waves per SIMD).  Two buffers of RPP pairs (NQ = 1: the same registers a two-tap chunk held).
+            f2 xb[2][RPP];
             if constexpr (STREAM) {
                 constexpr int TCH = 16;  // taps per chunk: four 16-byte loads of the branch's row (rows are padded to chunks)
                 const uint32_t tt_off = tp->tab.tt_off;
@@ -640,9 +658,9 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                                         : reinterpret_cast<const f4v *>(tp->table) + static_cast<size_t>(phq[q]) * (tpp / 4);
                 const uint32_t estep = tt_off ? static_cast<uint32_t>(kFusedThreads) : 1u;
                 f4v tb[2][TCH / 4];
-                const f2 *zp[NREG];
+                const f2 *zp[RPP];
 #pragma unroll
-                for (int jj = 0; jj < NREG; ++jj) zp[jj] = zw[jj];
+                for (int jj = 0; jj < RPP; ++jj) zp[jj] = zw[jj];
                 auto fetch = [&](auto bb, uint32_t ch) {
                     constexpr int b = decltype(bb)::value;
 #pragma unroll
@@ -653,32 +671,32 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 auto chunk = [&](auto bb, uint32_t i0) {
                     constexpr int b = decltype(bb)::value;
 #pragma unroll
-                    for (int jj = 0; jj < NREG; ++jj) xb[0][jj] = zp[jj][0];
+                    for (int jj = 0; jj < RPP; ++jj) xb[0][jj] = zp[jj][0];
                     static_for<0, TCH>([&](auto kk) {
                         constexpr int k = decltype(kk)::value;
                         if (i0 + static_cast<uint32_t>(k) < jl_a) {
                             if constexpr (k + 1 < TCH) {
 #pragma unroll
-                                for (int jj = 0; jj < NREG; ++jj) xb[(k + 1) & 1][jj] = zp[jj][k + 1];
+                                for (int jj = 0; jj < RPP; ++jj) xb[(k + 1) & 1][jj] = zp[jj][k + 1];
                             }
                             __builtin_amdgcn_sched_barrier(0);
                             const f4v q4 = tb[b][k / 4];
                             const float t = (k & 3) == 0 ? q4.x : (k & 3) == 1 ? q4.y : (k & 3) == 2 ? q4.z : q4.w;
                             if constexpr (FAST) {
 #pragma unroll
-                                for (int jj = 0; jj < NREG; ++jj) acc[q][jj] = __builtin_elementwise_fma((f2){t, t}, xb[k & 1][jj], acc[q][jj]);
+                                for (int jj = 0; jj < RPP; ++jj) acc[q][J0 + jj] = __builtin_elementwise_fma((f2){t, t}, xb[k & 1][jj], acc[q][J0 + jj]);
                             } else {
-                                f2 pr[NREG];
+                                f2 pr[RPP];
 #pragma unroll
-                                for (int jj = 0; jj < NREG; ++jj) pr[jj] = (f2){t, t} * xb[k & 1][jj];
+                                for (int jj = 0; jj < RPP; ++jj) pr[jj] = (f2){t, t} * xb[k & 1][jj];
 #pragma unroll
-                                for (int jj = 0; jj < NREG; ++jj) acc[q][jj] = acc[q][jj] + pr[jj];
+                                for (int jj = 0; jj < RPP; ++jj) acc[q][J0 + jj] = acc[q][J0 + jj] + pr[jj];
                             }
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     });
 #pragma unroll
-                    for (int jj = 0; jj < NREG; ++jj) zp[jj] += TCH;
+                    for (int jj = 0; jj < RPP; ++jj) zp[jj] += TCH;
                 };
                 const uint32_t nch = (jl_a + TCH - 1) / TCH;
                 fetch(std::integral_constant<int, 0>{}, 0);
@@ -695,7 +713,7 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             auto issue = [&](auto ii) {
                 constexpr int i = decltype(ii)::value;
 #pragma unroll
-                for (int jj = 0; jj < NREG; ++jj) xb[i & 1][jj] = zw[jj][i];
+                for (int jj = 0; jj < RPP; ++jj) xb[i & 1][jj] = zw[jj][i];
             };
             auto tap = [&](auto ii) {
                 constexpr int i = decltype(ii)::value;
@@ -703,13 +721,13 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
                 const float t = (i & 3) == 0 ? q4.x : (i & 3) == 1 ? q4.y : (i & 3) == 2 ? q4.z : q4.w;
                 if constexpr (FAST) {
 #pragma unroll
-                    for (int jj = 0; jj < NREG; ++jj) acc[q][jj] = __builtin_elementwise_fma((f2){t, t}, xb[i & 1][jj], acc[q][jj]);
+                    for (int jj = 0; jj < RPP; ++jj) acc[q][J0 + jj] = __builtin_elementwise_fma((f2){t, t}, xb[i & 1][jj], acc[q][J0 + jj]);
                 } else {
-                    f2 pr[NREG];
+                    f2 pr[RPP];
 #pragma unroll
-                    for (int jj = 0; jj < NREG; ++jj) pr[jj] = (f2){t, t} * xb[i & 1][jj];
+                    for (int jj = 0; jj < RPP; ++jj) pr[jj] = (f2){t, t} * xb[i & 1][jj];
 #pragma unroll
-                    for (int jj = 0; jj < NREG; ++jj) acc[q][jj] = acc[q][jj] + pr[jj];
+                    for (int jj = 0; jj < RPP; ++jj) acc[q][J0 + jj] = acc[q][J0 + jj] + pr[jj];
                 }
             };
             // taps 0 .. jl_a - 1 for every branch, tap jl_a for the branches p < jl_b (the reference's
@@ -738,17 +756,26 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
             // the predicated last tap, read from the table again (a run-time index)
             if (phq[q] < jl_b) {
                 const float t = tp->table[static_cast<size_t>(phq[q]) * tpp + jl_a];
-                f2 xp[NREG];
+                f2 xp[RPP];
 #pragma unroll
-                for (int jj = 0; jj < NREG; ++jj) xp[jj] = zw[jj][jl_a];
+                for (int jj = 0; jj < RPP; ++jj) xp[jj] = zw[jj][jl_a];
 #pragma unroll
-                for (int jj = 0; jj < NREG; ++jj) {
-                    if constexpr (FAST) acc[q][jj] = __builtin_elementwise_fma((f2){t, t}, xp[jj], acc[q][jj]);
-                    else acc[q][jj] = acc[q][jj] + (f2){t, t} * xp[jj];
+                for (int jj = 0; jj < RPP; ++jj) {
+                    if constexpr (FAST) acc[q][J0 + jj] = __builtin_elementwise_fma((f2){t, t}, xp[jj], acc[q][J0 + jj]);
+                    else acc[q][J0 + jj] = acc[q][J0 + jj] + (f2){t, t} * xp[jj];
                 }
             }
 
             });
+        }
+        };
+        compute_pass(std::integral_constant<int, 0>{});
+        if constexpr (HALVES) {
+            if constexpr (NSEG > 1) static_for<0, NTB>(load_taps);  // (the branch's first segments again: both buffers are free)
+            __syncthreads();  // everyone is done with windows 0-7
+            load_pass(std::integral_constant<int, 1>{});
+            __syncthreads();
+            compute_pass(std::integral_constant<int, 1>{});
         }
         __syncthreads();  // everyone is done with the input tile: R may land on it
         if (act) {

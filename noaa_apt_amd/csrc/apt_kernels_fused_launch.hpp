@@ -28,6 +28,18 @@ constexpr int kModeMfma = 3;
 // again sample by sample from HBM, in the reference's order.  default_settings.toml:108-140 is a user-editable file:
 // a tuned resample_atten / resample_delta_freq changes the tap count, and until round 6 such a plan fell to k_fused_any.
 constexpr int kModeStrictPad = 4;
+// PHASE stage 1 with ONE branch per thread (l <= 256: 44 100 Hz, 48 kHz at the fast profile, 8 / 16 / 24 / 32 kHz ...): the
+// paired input tile goes through LDS in two halves of eight windows each (round 6; kernel and phase_geom must agree, hence
+// a macro).  Its 45-52 KB were what held these kernels at three workgroups per CU.
+#ifndef APT_PHASE_HALVES
+#define APT_PHASE_HALVES 1
+#endif
+// (not the standard profile's kernel in APTGPU_MODE_FAST: its 68-tap branch is then fetched twice, in segments, by a kernel
+// that has half the arithmetic to hide it under — 0.80 -> 0.86 ms per 16 at 44 100 Hz, profiles/r06_phase_halves_ab.txt)
+constexpr bool phase_halves(int nq, bool stream, int nthr, int t2, bool fast)
+{
+    return APT_PHASE_HALVES != 0 && nq == 1 && !stream && nthr == 256 && !(fast && t2 == 37);
+}
 // kModeStrictPad2 (round 6): kModeStrictPad whose LOW-PASS length is a bound too (T2 = kPadT2Max: h2 / h2p hold zeros behind
 // the filter's last tap — the taps an output meets last, since stage 3 walks them in ascending order — and a tile whose F
 // values are not all finite is filtered again from D in LDS with the run-time tap count).  demodulation_atten is as

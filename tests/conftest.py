@@ -29,3 +29,18 @@ def oracle():
     from oracle import binding
     binding.lib()
     return binding
+
+
+@pytest.fixture(autouse=True)
+def _no_cached_sessions_across_gpu_tests(request):
+    """The one-shot entry points keep idle sessions (plan + device buffers) per (settings, rate, sync, mode); the library's
+    A/B switches (APTGPU_FUSED_ANY, APTGPU_PHASE_*, APTGPU_FUSED_PAD ...) are read when a plan is created.  A test that sets
+    one must not be served the plan an earlier test left behind — which of them did depended on the order and the -k
+    filter of the run — so every GPU test starts and ends with an empty cache."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import noaa_apt_amd as apt
+    apt.cache_clear()
+    yield
+    apt.cache_clear()

@@ -574,6 +574,7 @@ ANY_CASES = [  # (rate, seconds, profile): the run-time fused kernel on every ki
 @pytest.mark.parametrize("sync", [True, False])
 def test_runtime_fused_kernel_bitexact(oracle, monkeypatch, rate, seconds, profile, sync):
     monkeypatch.setenv("APTGPU_FUSED_ANY", "1")
+    apt.cache_clear()  # (the switch is read at plan creation: a cached session of an earlier test would ignore it)
     x = synth_apt(rate, seconds, seed=rate % 89 + seconds)
     s = apt.Settings.profile(profile)
     os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
