@@ -20,6 +20,12 @@ from noaa_apt_amd.testing.synth import synth_apt
 
 pytestmark = pytest.mark.gpu
 
+
+def _seeds(default):
+    """APT_SOAK_SEEDS=101,102,... replaces a test's own seeds (the long runs of profiles/r06_soak.txt)."""
+    e = os.environ.get("APT_SOAK_SEEDS", "")
+    return [int(v) for v in e.split(",") if v.strip()] or default
+
 STOCK_RATES = [48000, 44100, 22050, 11025, 96000, 8000, 16000, 32000, 24000, 60000, 192000, 250000, 12000, 20800]
 
 
@@ -81,7 +87,7 @@ def make_signal(c, synth_apt):
 
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", _seeds([1, 2, 3]))
 def test_soak_decode_against_oracle(oracle, seed):
     cases = int(os.environ.get("APT_SOAK_CASES", "40"))
     rng = np.random.default_rng(seed)
@@ -126,7 +132,7 @@ def test_soak_decode_against_oracle(oracle, seed):
     assert not bad, "\n".join(bad)
 
 
-@pytest.mark.parametrize("seed", [11, 12])
+@pytest.mark.parametrize("seed", _seeds([11, 12]))
 def test_soak_decode_batch_against_oracle(oracle, seed):
     """The same draw for aptgpu_decode_batch: one rate / Settings / sync per batch, two to nine recordings of mixed
     lengths and kinds (some too short: their error is the oracle's, the others still decode), one to three worker
@@ -178,7 +184,7 @@ def test_soak_decode_batch_against_oracle(oracle, seed):
     assert not bad, "\n".join(bad)
 
 
-@pytest.mark.parametrize("seed", [21])
+@pytest.mark.parametrize("seed", _seeds([21]))
 def test_soak_fast_mode_within_its_tolerance(oracle, seed):
     """APTGPU_MODE_FAST over the same draw of rates and Settings (finite signals: synthetic APT, the kinds whose sync
     positions are well defined): SURVEY.md 8(d)'s tolerance — same row count, sync positions identical on >= 99.9 % of the
