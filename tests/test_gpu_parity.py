@@ -446,6 +446,35 @@ def test_phase_stage1_slot_stride_bitexact(oracle, monkeypatch, rate, seconds, p
     assert_bitexact(got, want, f"slot stride (balanced={balanced}) at {rate} Hz, {profile}")
 
 
+@pytest.mark.parametrize("rate,seconds,profile", [
+    (48035, 14, "fast"), (22035, 20, "fast"),      # l = 256 (m = 739 / 339): sixteen tile phases — no per-phase tables (exact == 0)
+    (47970, 14, "fast"),                            # l = 128
+    (44100, 14, "standard"), (8000, 30, "standard"), (12000, 25, "standard"), (32000, 15, "standard"),  # l = 208, 39, 26, 39
+])
+@pytest.mark.parametrize("sync", [True, False])
+def test_phase_one_branch_tile_in_two_halves_bitexact(oracle, rate, seconds, profile, sync):
+    """The PHASE stage 1 with one branch per thread takes its paired input tile through LDS in two halves (windows 0-7, then
+    8-15: APT_PHASE_HALVES), the standard profile's long branches in segments fetched once per half — with the per-phase
+    tables and without them (l = 256 at the fast profile: sixteen tile phases, the kernel divides), short and long
+    branches, a NaN and an infinity in the input, the recording's first and last tiles."""
+    x = synth_apt(rate, seconds, seed=rate % 71 + seconds)
+    x[x.size // 2] = np.nan
+    x[7] = np.inf
+    s = apt.Settings.profile(profile)
+    os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                       "resample_cutout", "demodulation_atten")}
+    try:
+        want = oracle.decode(x, rate, sync, settings=os_)
+    except oracle.OracleError as e:
+        with pytest.raises(apt.AptError) as ge:
+            apt.decode(apt.Context(device=0), s, x, apt.Rate.hz(rate), sync)
+        assert str(ge.value) == str(e)
+        return
+    got, st = apt.decode(apt.Context(device=0), s, x, apt.Rate.hz(rate), sync, return_stats=True)
+    assert st.fused == 4, (rate, profile, st.l, st.m, st.fused)
+    assert_same_values(got, want, f"one-branch PHASE, two halves: {rate} Hz, {profile}, sync={sync}")
+
+
 def test_phase_stage1_long_ragged_batched_and_pcm16(oracle):
     """Many tiles, lengths that end mid-tile / mid-group, several recordings per call, PCM16 payloads at
     odd 2-byte offsets, non-finite samples, and the fast mode's tolerance — all at 44 100 Hz."""
