@@ -223,3 +223,110 @@ def test_soak_fast_mode_within_its_tolerance(oracle, seed):
                                        "kernel_paths_stats_fused": dict(sorted(paths.items())),
                                        "seconds": round(time.perf_counter() - t0, 1)}), flush=True)
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("seed", _seeds([31]))
+def test_soak_image_stage_and_wav_ingest_against_oracle(seed):
+    """The rows either side of the path, same idea: random WAV file images (8 / 16 / 24 / 32-bit PCM,
+    float, one to three channels, junk chunks that move the payload to odd addresses) through load(); random row images
+    (a noisy frame, with NaN / Inf pixels, constant, tiny, negated) through process() with every contrast mode and
+    rotation, and through read_telemetry().  Bit-identical to the oracle or the same error."""
+    from oracle import image_binding as oi, wav_binding as ow
+    from noaa_apt_amd.testing.synth import make_image
+    from noaa_apt_amd.testing.wavfile import make_wav
+    cases = max(6, int(os.environ.get("APT_SOAK_CASES", "40")) // 2)
+    rng = np.random.default_rng(seed)
+    bad = []
+    f32 = np.float32
+    same = lambda a, b: np.asarray(a, f32).tobytes() == np.asarray(b, f32).tobytes()  # noqa: E731
+    for i in range(cases):
+        # ---- N1: load()
+        bits = int(rng.choice([8, 16, 24, 32]))
+        is_float = bool(rng.random() < 0.25)
+        channels = int(rng.integers(1, 4))
+        frames = int(rng.choice([1, 2, 7, 255, 4099, int(rng.integers(10, 300000))]))
+        if is_float:
+            vals = (rng.standard_normal(frames * channels) * 10.0 ** rng.integers(-3, 6)).astype(f32)
+            if vals.size > 3:
+                vals[int(rng.integers(0, vals.size))] = np.nan
+                vals[int(rng.integers(0, vals.size))] = -np.inf
+            kw = dict(is_float=True, channels=channels)
+        else:
+            lo, hi = -(1 << (bits - 1)), (1 << (bits - 1)) - 1
+            vals = rng.integers(lo, hi + 1, size=frames * channels, dtype=np.int64)
+            kw = dict(bits=bits, channels=channels)
+        if rng.random() < 0.5:
+            kw["extra_chunks"] = [(b"junk", bytes(int(rng.integers(1, 9))))]
+        rate_hz = int(rng.choice([11025, 44100, 48000, 96000, 8000]))
+        data = make_wav(vals, rate_hz, **kw)
+        what = f"seed {seed} case {i} load {kw} frames={frames}"
+        try:
+            want, _ = ow.load_wav(data)
+            want_err = None
+        except Exception as e:  # noqa: BLE001
+            want_err = str(e)
+        try:
+            got, rate = apt.load(data)
+            got_err = None
+        except Exception as e:  # noqa: BLE001
+            got_err = str(e)
+        if want_err is not None or got_err is not None:
+            if want_err != got_err:
+                bad.append(f"{what}: oracle error {want_err!r}, product error {got_err!r}")
+        elif not (same(got, want) and rate.get_hz() == rate_hz):
+            bad.append(f"{what}: samples differ")
+        # ---- N2 / N3: process(), read_telemetry()
+        rows = int(rng.choice([1, 3, 199, 200, 201, int(rng.integers(202, 1400))]))
+        kind = str(rng.choice(["frame", "frame", "nan", "inf", "const", "tiny", "negated"]))
+        img = make_image(rows, seed=int(rng.integers(1, 1 << 20)))
+        sig = (img * f32(37.5) + rng.standard_normal(img.shape).astype(f32) * f32(rng.uniform(1.0, 300.0))).astype(f32).ravel()
+        if kind == "nan":
+            sig[rng.integers(0, sig.size, 5)] = np.nan
+        elif kind == "inf":
+            sig[rng.integers(0, sig.size, 3)] = np.inf
+            sig[rng.integers(0, sig.size, 2)] = -np.inf
+        elif kind == "const":
+            sig[:] = f32(rng.uniform(-5, 5))
+        elif kind == "tiny":
+            sig *= f32(1e-35)
+        elif kind == "negated":
+            sig = -sig
+        cname = str(rng.choice(["telemetry", "percent", "minmax"]))
+        p = float(np.float32(rng.choice([0.98, 0.9, 0.5, 1.0, 0.0, float(rng.uniform(0, 1))])))
+        ca = {"telemetry": apt.Contrast.TELEMETRY, "percent": apt.Contrast.Percent(p), "minmax": apt.Contrast.MINMAX}[cname]
+        ck = {"telemetry": oi.CONTRAST_TELEMETRY, "percent": oi.CONTRAST_PERCENT, "minmax": oi.CONTRAST_MINMAX}[cname]
+        what = f"seed {seed} case {i} process rows={rows} kind={kind} contrast={cname} p={p}"
+        try:
+            want_img, lo_, hi_ = oi.process_gray(sig, ck, p)
+            want_err = None
+        except Exception as e:  # noqa: BLE001
+            want_err = str(e)
+        try:
+            got_img, info = apt.process(apt.Context(device=0), sig, ca, rotate=0, return_info=True)
+            got_err = None
+        except Exception as e:  # noqa: BLE001
+            got_err = str(e)
+        if want_err is not None or got_err is not None:
+            if want_err != got_err:
+                bad.append(f"{what}: oracle error {want_err!r}, product error {got_err!r}")
+        elif not (np.array_equal(got_img.ravel(), np.asarray(want_img).ravel()) and same(info.low, lo_) and same(info.high, hi_)):
+            bad.append(f"{what}: image or limits differ")
+        what = f"seed {seed} case {i} telemetry rows={rows} kind={kind}"
+        try:
+            wt = oi.read_telemetry(sig)
+            want_err = None
+        except Exception as e:  # noqa: BLE001
+            want_err = str(e)
+        try:
+            gt = apt.read_telemetry(apt.Context(device=0), sig)
+            got_err = None
+        except Exception as e:  # noqa: BLE001
+            got_err = str(e)
+        if want_err is not None or got_err is not None:
+            if want_err != got_err:
+                bad.append(f"{what}: oracle error {want_err!r}, product error {got_err!r}")
+        elif not (gt.row == wt.row and same(gt.quality, wt.quality) and gt.values_a.tobytes() == wt.values_a.tobytes()
+                  and gt.values_b.tobytes() == wt.values_b.tobytes()):
+            bad.append(f"{what}: telemetry differs")
+    print("\nsoak-sides " + json.dumps({"seed": seed, "cases": cases, "mismatches": len(bad)}), flush=True)
+    assert not bad, "\n".join(bad[:20])
