@@ -146,6 +146,9 @@ uint32_t fused_pad_t1(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t
 // kModeStrictPad2: the low-pass bound of the padded kernel when t2 is not the profile's own (a tuned demodulation_atten:
 // h2 / h2p must then be laid out for that many taps, zeros behind the filter's last), else 0
 uint32_t fused_pad_t2(uint32_t l, uint32_t m, uint32_t t2, uint32_t pw);
+// ... and of the PHASE kernels (fused_phase_supported accepts such a t2 at the standard profile's pixel width): 0 = t2 is
+// the profile's own or beyond the bound
+uint32_t fused_phase_pad_t2(uint32_t t2, uint32_t pw);
 int fused_chunk_of(uint32_t m, bool fast);  // window samples per stage-1 chunk of the specialised kernel for (m, strict / fast)
 // host: stage-3 tap pairs h2p[k] = (h2[k-1], h2[k]), k = 0 .. t2  (2*(t2+1) floats)
 void fused_lowpass_pairs(const float *h2, uint32_t t2, float *h2p);

@@ -511,6 +511,22 @@ bool phase_geom(uint32_t threads, uint32_t nq, uint32_t l, uint32_t m, uint32_t 
 }
 }  // namespace
 
+// kModeStrictPad2 on the PHASE kernels: the low-pass bound of the instantiation that serves a low-pass of t2 taps other than
+// the standard profile's 37 (a tuned demodulation_atten at a sound-card rate), or 0
+namespace {
+uint32_t phase_pad_t2_bound(uint32_t t2, uint32_t pw)
+{
+    if (pw != 3 || (t2 & 1u) == 0 || t2 == 37 || t2 > static_cast<uint32_t>(kPadT2Max)) return 0;
+    return static_cast<uint32_t>(kPadT2Max);
+}
+}  // namespace
+uint32_t fused_phase_pad_t2(uint32_t t2, uint32_t pw)  // (plan creation: reads the A/B switch)
+{
+    const char *off = std::getenv("APTGPU_FUSED_PAD");  // (tests: 0 = as until round 6, k_fused_any)
+    if (off && off[0] == '0') return 0;
+    return phase_pad_t2_bound(t2, pw);
+}
+
 bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uint32_t pw, TableGeom *geom)
 {
     if (l < 2 || m == 0 || t1 == 0) return false;
@@ -524,7 +540,15 @@ bool fused_phase_supported(uint32_t l, uint32_t m, uint32_t t1, uint32_t t2, uin
     if (t2 == 61 && pw == 5)
         return phase_geom(256, 1, l, m, t1, t2, pw, geom, true) || phase_geom(256, 2, l, m, t1, t2, pw, geom, true) ||
                phase_geom(256, 4, l, m, t1, t2, pw, geom, true);
-    if (t2 != 37 || pw != 3) return false;
+    if (pw != 3) return false;
+    if (t2 != 37) {
+        // a tuned demodulation_atten: the instantiations compiled for a low-pass BOUND (kModeStrictPad2), 256 threads only
+        // (geometry by the kernel's T2, the bound: phase_geom tells the profiles apart by their low-pass lengths)
+        const uint32_t tb = fused_phase_pad_t2(t2, pw);
+        if (tb == 0) return false;
+        return phase_geom(256, 1, l, m, t1, tb, pw, geom) || phase_geom(256, 2, l, m, t1, tb, pw, geom) ||
+               phase_geom(256, 4, l, m, t1, tb, pw, geom);
+    }
     const char *wide = std::getenv("APTGPU_PHASE_WIDE");  // A/B switch (plan creation): the 512- / 1024-thread forms first
     if (wide && wide[0] == '1' && (phase_geom(512, 1, l, m, t1, t2, pw, geom) || phase_geom(1024, 1, l, m, t1, t2, pw, geom)))
         return true;
@@ -709,8 +733,10 @@ bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, uint32_t t2, ui
         for (uint32_t i = 0; i < call.count; ++i)
             if (reinterpret_cast<uintptr_t>(call.rec[i].x) & 1u) return false;
     // (one branch per thread: the kernel takes the paired tile through LDS in two halves — apt_kernels_fused_launch.hpp)
+    // (a tuned low-pass at the standard profile runs the strict kModeStrictPad2 instantiation whatever the mode)
+    const bool fast_kernel = mode == kModeFast && !(pw == 3 && t2 != 37);
     const bool halves = phase_halves(static_cast<int>(geom.nq ? geom.nq : 1u), geom.stream != 0, static_cast<int>(geom.nthr),
-                                     static_cast<int>(t2), mode == kModeFast);
+                                     static_cast<int>(t2), fast_kernel);
     const FusedLaunch a{s, &call, d_prm, max_w, static_cast<size_t>(halves ? geom.xt / 2 : geom.xt)};
     const bool wide = geom.nthr == 512, huge = geom.nthr == 1024;
     if (t2 == 61 && pw == 5) {  // the slow profile's work-rate stages, streamed taps (strict instantiations only: they serve fast mode too)
@@ -733,6 +759,14 @@ bool fused_phase_front_end(hipStream_t s, const TableGeom &geom, uint32_t t2, ui
         if (wide || huge) return false;
         if (mode == kModeFast) pcm16 ? fused_launch_phase_fastp_fast_i16(a) : fused_launch_phase_fastp_fast_f32(a);
         else if (mode == kModeStrict) pcm16 ? fused_launch_phase_fastp_i16(a) : fused_launch_phase_fastp_f32(a);
+        else return false;
+        return true;
+    }
+    if (pw == 3 && t2 != 37) {  // a tuned low-pass: kModeStrictPad2 (strict arithmetic: it serves APTGPU_MODE_FAST too)
+        if (wide || huge || phase_pad_t2_bound(t2, pw) == 0) return false;
+        if (geom.nq == 1 || geom.nq == 0) pcm16 ? fused_launch_phase_std_pad2_i16(a) : fused_launch_phase_std_pad2_f32(a);
+        else if (geom.nq == 2) pcm16 ? fused_launch_phase2_std_pad2_i16(a) : fused_launch_phase2_std_pad2_f32(a);
+        else if (geom.nq == 4) pcm16 ? fused_launch_phase4_std_pad2_i16(a) : fused_launch_phase4_std_pad2_f32(a);
         else return false;
         return true;
     }

@@ -413,6 +413,9 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
     const bool interior = k_lo < 0 && c_hi >= Gm::TILE_K;
     APT_MARK("END tile_prologue");
     float r[L];
+    // (kModeStrictPad2's "F not all finite" flag: a word behind everything else in LDS — a constant in the SPLIT kernels, behind
+    // the run-time input tile in the PHASE ones)
+    [[maybe_unused]] uint32_t lp_flag_off = static_cast<uint32_t>(Gm::LP_FLAG_OFF);
     if constexpr (Gm::PHASE) {
         // ---- stages 0 + 1, taps of the thread's polyphase branches in registers (dsp.rs:252-263):
         // k*m - X0*l = v;  x0 - X0 = c = ceil(v / l);  phase p = c*l - v;  output k = sum_i h[p + i*l] * x[x0 + i]
@@ -517,6 +520,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
         constexpr bool HALVES = phase_halves(NQ, STREAM, NTHR, T2, FAST);
         constexpr int NPASS = HALVES ? 2 : 1, RPP = NREG / NPASS;  // passes; regions per pass
         static_assert(!HALVES || NREG % 2 == 0, "two passes of whole regions");
+        if constexpr (PADLP && sizeof(XT) == 4) {
+            const uint32_t xt_used = HALVES ? tp->tab.xt / 2u : tp->tab.xt;
+            lp_flag_off = xt_used > static_cast<uint32_t>(Gm::W_LDS_FLOATS) ? xt_used : static_cast<uint32_t>(Gm::W_LDS_FLOATS);
+            if (tid == 0) reinterpret_cast<uint32_t *>(lds)[lp_flag_off] = 0u;  // (read behind several barriers, after stage 3)
+        }
         // every load of a pass issued before its first LDS write (regions x rounds unrolled: a loop
         // that waited for each round's loads cost 26 HBM latencies per tile)
         // ceil(ZR / NTHR) at most (phase_geom: ZR <= 1024; the fast profile's long periods — 44 100 Hz: m = 2205 — 2304,
@@ -1752,11 +1760,11 @@ k_fused(const CallArgs call_by_value, const FusedParams *__restrict__ prm)
 #pragma unroll
         for (int b = 0; b < L; ++b) chk = chk + f[b];
         if (tid >= kPreThreads && (__float_as_uint(chk) & 0x7F800000u) == 0x7F800000u)
-            reinterpret_cast<uint32_t *>(lds)[Gm::LP_FLAG_OFF] = 1u;
+            reinterpret_cast<uint32_t *>(lds)[lp_flag_off] = 1u;
     }
     __syncthreads();
     if constexpr (PADLP && sizeof(XT) == 4) {
-        if (reinterpret_cast<const uint32_t *>(lds)[Gm::LP_FLAG_OFF] != 0u) {
+        if (reinterpret_cast<const uint32_t *>(lds)[lp_flag_off] != 0u) {
             // (workgroup-uniform; never on recordings) the reference's loop over the filter's own taps (dsp.rs:396-404),
             // from D, which still lies in Q
             const uint32_t t2r = late->t2;
@@ -2147,7 +2155,7 @@ void launch_fused_args(const FusedLaunch &a)
 {
     using Gm = FusedGeom<L, M, T1, T2, PW, NTHR, static_cast<int>(sizeof(XT)), fused_geom_var(MODE)>;
     size_t lds = static_cast<size_t>(Gm::LDS_FLOATS) * sizeof(float);
-    if constexpr (Gm::TABLE) lds = std::max<size_t>(a.table_lds_floats, Gm::W_LDS_FLOATS) * sizeof(float);
+    if constexpr (Gm::TABLE) lds = (std::max<size_t>(a.table_lds_floats, Gm::W_LDS_FLOATS) + (Gm::PAD ? 4 : 0)) * sizeof(float);
     // APTGPU_FUSED_LDS_PAD=bytes (A/B switch, read at plan creation): more dynamic LDS than the kernel uses = fewer workgroups
     // per CU (2048 takes the 48 kHz kernels from six back to five)
     lds += static_cast<size_t>(a.lds_pad > 0 ? a.lds_pad : 0);

@@ -141,6 +141,13 @@ void fused_launch_48k_pad2_f32(const FusedLaunch &a);
 void fused_launch_48k_pad2_i16(const FusedLaunch &a);
 void fused_launch_96k_pad2_f32(const FusedLaunch &a);
 void fused_launch_96k_pad2_i16(const FusedLaunch &a);
+// ... and the standard profile's PHASE kernels (every rate a sound card records at) with a low-pass of up to kPadT2Max taps
+void fused_launch_phase_std_pad2_f32(const FusedLaunch &a);
+void fused_launch_phase_std_pad2_i16(const FusedLaunch &a);
+void fused_launch_phase2_std_pad2_f32(const FusedLaunch &a);
+void fused_launch_phase2_std_pad2_i16(const FusedLaunch &a);
+void fused_launch_phase4_std_pad2_f32(const FusedLaunch &a);
+void fused_launch_phase4_std_pad2_i16(const FusedLaunch &a);
 // 48 kHz at the slow profile (13 / 30, 2783 taps; 61-tap low-pass, pixel width 5): the same SPLIT form
 void fused_launch_48k_slow_f32(const FusedLaunch &a);
 void fused_launch_48k_slow_i16(const FusedLaunch &a);

@@ -308,7 +308,9 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
         plan->fused_fast = plan->mode == APTGPU_MODE_FAST &&
                            ((plan->fused == 1 && plan->fused_pad_t1 == 0 &&
                              (plan->fused_mfma || gpu::fused_fast_supported(plan->l, plan->m, t1, t2, plan->pw))) ||
-                            plan->fused == 3 || plan->fused == 4);
+                            plan->fused == 3 ||
+                            // (a tuned low-pass on the PHASE kernels: strict kModeStrictPad2 instantiations only)
+                            (plan->fused == 4 && gpu::fused_phase_pad_t2(t2, plan->pw) == 0));
         // fp16-tap mode inside the specialised fused kernel where one exists (else the generic kernel)
         // (not with export_resample_filtered: the fused kernels decimate at t = off + k m, the flag moves the phase —
         // dsp.rs:265-273 — and work_len_for() follows the flag; the unfused k_resample_at path serves such a plan)
@@ -343,9 +345,17 @@ aptgpu_plan *plan_create(const aptgpu_context *ctx, const aptgpu_settings &setti
                                    plan->taps_resample.data(), t1, tab.data());
         else gpu::fused_any_table(plan->l, plan->taps_resample.data(), t1, tab.data());
         upload(plan->d_taps_any, tab);
-        Signal h2p(2 * (plan->taps_lowpass.size() + 1) + 16, 0.f);
-        gpu::fused_lowpass_pairs(plan->taps_lowpass.data(), static_cast<uint32_t>(plan->taps_lowpass.size()),
-                                 h2p.data());
+        // (PHASE kernels with a tuned low-pass — kModeStrictPad2: the low-pass tables laid out for the kernel's bound)
+        Signal lp(plan->taps_lowpass);
+        plan->fused_pad_t2 = plan->fused == 4 ? gpu::fused_phase_pad_t2(static_cast<uint32_t>(lp.size()), plan->pw) : 0u;
+        if (plan->fused_pad_t2) {
+            lp.resize(plan->fused_pad_t2, 0.f);
+            Signal padded(lp);
+            padded.resize(lp.size() + 16, 0.f);
+            upload(plan->d_taps_lowpass_pad, padded);
+        }
+        Signal h2p(2 * (lp.size() + 1) + 16, 0.f);
+        gpu::fused_lowpass_pairs(lp.data(), static_cast<uint32_t>(lp.size()), h2p.data());
         upload(plan->d_taps_lowpass_pairs, h2p);
     }
     if (plan->fused == 1) {

@@ -1203,6 +1203,61 @@ def test_tuned_demodulation_atten_non_finite_samples_pcm16_and_the_bound(oracle)
     apt.cache_clear()
 
 
+DEMOD_TUNED_PHASE = [(44100, 14, dict(demodulation_atten=24.0)), (44100, 14, dict(demodulation_atten=28.0)),
+                     (22050, 20, dict(demodulation_atten=26.0)), (11025, 30, dict(demodulation_atten=24.0)),
+                     (11025, 30, dict(demodulation_atten=29.0, resample_atten=31.0)), (16000, 20, dict(demodulation_atten=20.0)),
+                     (32000, 15, dict(demodulation_atten=27.5))]
+
+
+@pytest.mark.parametrize("rate,seconds,kw", DEMOD_TUNED_PHASE)
+@pytest.mark.parametrize("sync", [True, False])
+def test_tuned_demodulation_atten_at_the_sound_card_rates(oracle, rate, seconds, kw, sync):
+    """kModeStrictPad2 on the PHASE kernels (one, two, four branches per thread): a tuned demodulation_atten at 44 100 /
+    22 050 / 11 025 Hz (and 16 / 32 kHz) keeps stats.fused == 4 — the low-pass tables zero-padded to 45 taps, a tile whose F
+    is not all finite filtered again with the run-time count — bit-exact, with a NaN and an infinity in the input, in
+    strict mode and (the same strict kernels) in APTGPU_MODE_FAST; APTGPU_FUSED_PAD=0: k_fused_any as until round 6."""
+    s = apt.Settings(**kw)
+    os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                       "resample_cutout", "demodulation_atten")}
+    x = synth_apt(rate, seconds, seed=rate % 67 + seconds)
+    x[x.size // 3] = np.nan
+    x[11] = -np.inf
+    want = oracle.decode(x, rate, sync, settings=os_)
+    for mode in (apt.MODE_STRICT, apt.MODE_FAST):
+        got, stats = apt.decode(apt.Context(device=0, mode=mode), s, x, apt.Rate.hz(rate), sync, return_stats=True)
+        assert stats.fused == 4 and stats.n_lowpass_taps != 37, (rate, kw, stats.fused, stats.n_lowpass_taps)
+        assert_same_values(got, want, f"tuned low-pass on the PHASE kernels: {rate} {kw} sync={sync} mode={mode}")
+
+
+def test_tuned_demodulation_atten_phase_switch_off_and_pcm16(oracle, monkeypatch):
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    s = apt.Settings(demodulation_atten=26.0)
+    os_ = {k: getattr(s, k) for k in ("work_rate", "resample_atten", "resample_delta_freq",
+                                       "resample_cutout", "demodulation_atten")}
+    # PCM16 payloads, two recordings per call, 11 025 Hz
+    recs = [synth_apt(11025, 40, seed=71), synth_apt(11025, 25, seed=72)[:11025 * 25 - 5]]
+    plan = apt.Plan(s, apt.Rate.hz(11025), True, max_samples=max(r.size for r in recs), max_batch=2)
+    assert plan.info.fused == 4 and plan.info.n_lowpass_taps == 39
+    d_pcm = [torch.from_numpy(r.astype(np.int16)).to(dev) for r in recs]
+    cap = int(plan.info.max_rows)
+    d_out = [torch.empty(cap * 2080, dtype=torch.float32, device=dev) for _ in recs]
+    torch.cuda.synchronize()
+    specs = [apt.WavSpec(1, 16, 2, 0, 11025, 1, 0, 2 * r.size, r.size, r.size) for r in recs]
+    plan.decode_device_wav([d.data_ptr() for d in d_pcm], specs, [d.data_ptr() for d in d_out], [cap] * 2)
+    for i, (r, res) in enumerate(zip(recs, plan.results(2))):
+        assert_bitexact(d_out[i][:res.n_out].cpu().numpy(), oracle.decode(r, 11025, True, settings=os_), f"PHASE pad2, PCM16 {i}")
+    plan.close()
+    # the switch
+    monkeypatch.setenv("APTGPU_FUSED_PAD", "0")
+    apt.cache_clear()
+    x = synth_apt(44100, 14, seed=73)
+    got, stats = apt.decode(apt.Context(device=0), s, x, apt.Rate.hz(44100), True, return_stats=True)
+    assert stats.fused == 2
+    assert_bitexact(got, oracle.decode(x, 44100, True, settings=os_), "tuned low-pass, APTGPU_FUSED_PAD=0")
+    apt.cache_clear()
+
+
 def _random_tunings(n, seed):
     rng = np.random.default_rng(seed)
     out = []

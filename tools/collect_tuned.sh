@@ -34,6 +34,12 @@ for kv in demodulation_atten=24 demodulation_atten=26 demodulation_atten=29; do
   run ${kv}_any APTGPU_QUIET=1 APTGPU_FUSED_PAD=0 -- --set $kv
 done
 run atten31_demod26_pad2 APTGPU_QUIET=1 -- --set resample_atten=31 --set demodulation_atten=26
+# ... and at the rates a sound card records at (the PHASE kernels' kModeStrictPad2 instantiations)
+for r in 44100 11025; do
+  run ${r}_stock APTGPU_QUIET=1 -- --rate $r
+  run ${r}_demodulation_atten=26_pad2 APTGPU_QUIET=1 -- --rate $r --set demodulation_atten=26
+  run ${r}_demodulation_atten=26_any APTGPU_QUIET=1 APTGPU_FUSED_PAD=0 -- --rate $r --set demodulation_atten=26 --steps 30
+done
 run fast_stock APTGPU_QUIET=1 -- --mode fast
 run fast_atten31_mfma APTGPU_QUIET=1 -- --mode fast --set resample_atten=31
 run fast_atten31_any APTGPU_QUIET=1 APTGPU_FAST_MFMA=0 APTGPU_FUSED_PAD=0 -- --mode fast --set resample_atten=31
